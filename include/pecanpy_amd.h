@@ -1,0 +1,132 @@
+/*
+ * pecanpy_amd.h -- C ABI of the MI355X-native node2vec walk engine (libpecanpy_amd.so).
+ *
+ * The reference (krishnanlab/PecanPy) has no FFI: its operator boundary for walk generation is
+ * the njit function
+ *     Base._random_walks(tot_num_jobs, walk_length, random_state, start_node_idx_ary,
+ *                        has_nbrs, move_forward, progress_proxy) -> uint32[tot_num_jobs, L+2]
+ * (reference src/pecanpy/pecanpy.py:164-210) whose callbacks are built from the graph arrays by
+ * get_has_nbrs()/get_move_forward() (pecanpy.py:522-561, 576-614; rw/sparse_rw.py:12-20).
+ * The entry points below are what a ctypes/cffi binding of that boundary binds to: the graph
+ * arrays become a device-resident handle (pw_csr_create / pw_dense_create), and one call
+ * (pw_simulate*) replaces _random_walks + the two callbacks.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pw_status on failure; pw_last_error()
+ *     returns a thread-local human-readable message.  Nothing prints or aborts.
+ *   - host buffers are borrowed for the duration of a call; device copies of the graph are owned
+ *     by the handle until pw_graph_destroy().
+ *   - one in-flight pw_simulate* per handle.
+ *   - walk matrix layout = the reference's: row i = [start, n_1 .. n_L, len_i], unused cells 0,
+ *     len_i = L+1 normally, 1 for a start without neighbours, j for a dead end before step j
+ *     (pecanpy.py:182-206).
+ *   - random stream = ONE MT19937 stream seeded like the reference (np.random.seed(random_state)
+ *     inside _random_walks, pecanpy.py:177-178); walk i step j consumes double #(S_i + j),
+ *     S_i = sum of (len-1) over earlier walks.  stream_skip shifts S_0 (multi-GPU shards).
+ */
+#ifndef PECANPY_AMD_H
+#define PECANPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pw_graph pw_graph; /* opaque, device resident */
+
+typedef enum {
+    PW_OK = 0,
+    PW_ERR_INVALID = -1,     /* bad argument */
+    PW_ERR_HIP = -2,         /* HIP runtime error (message has the hipError string) */
+    PW_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    PW_ERR_UNSUPPORTED = -4, /* mode/option not available for this graph kind */
+    PW_ERR_NOMEM = -5
+} pw_status;
+
+/* walk modes = the reference's mode classes (pecanpy.py:293-614) */
+typedef enum {
+    PW_MODE_SPARSE_OTF = 0,            /* SparseOTF.move_forward, pecanpy.py:543-559 */
+    PW_MODE_DENSE_OTF = 1,             /* DenseOTF.move_forward,  pecanpy.py:597-612 */
+    PW_MODE_PRECOMP = 2,               /* PreComp.move_forward,   pecanpy.py:409-438 */
+    PW_MODE_FIRST_ORDER_UNWEIGHTED = 3,/* FirstOrderUnweighted,   pecanpy.py:299-309 */
+    PW_MODE_PRECOMP_FIRST_ORDER = 4    /* PreCompFirstOrder,      pecanpy.py:319-334 */
+} pw_mode;
+
+typedef struct {
+    uint64_t total_steps;     /* sampled transitions = sum_i (len_i - 1) */
+    uint64_t overflow_reads;  /* steps where the float CDF never reached r (choice == degree,
+                                 SURVEY.md App. D quirk 1; mirrored from the reference) */
+    uint64_t clamped_reads;   /* of those, reads that would have left the index buffer */
+    uint64_t dead_end_walks;  /* walks that stopped early at a vertex without out-edges */
+    uint64_t repair_rounds;   /* extra passes needed to re-address the stream after dead ends */
+    double walk_kernel_ms;    /* HIP-event time of the walk kernel launches of this call */
+    double rng_kernel_ms;     /* HIP-event time of the MT19937 expansion kernels */
+    uint32_t walk_kernel_launches;
+    uint32_t reserved;
+} pw_stats;
+
+/* ---- introspection ------------------------------------------------------------------- */
+const char *pw_version(void);
+const char *pw_last_error(void);
+int pw_device_count(void);
+
+/* ---- graph handles --------------------------------------------------------------------- */
+/* CSR in the reference's SparseGraph layout (graph.py:409-413): indptr uint32[n_nodes+1],
+ * indices uint32[nnz] ascending and duplicate-free per row, data float32[nnz].
+ * data may be NULL: all weights 1.0 (the reference's unweighted graphs, graph.py:170,480). */
+int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
+                  uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out);
+
+/* Dense adjacency in the reference's DenseGraph layout (graph.py:576-580): float64[n, n]
+ * row-major; nonzero mask = (data != 0). */
+int pw_dense_create(const double *data, uint32_t n_nodes, int device, pw_graph **out);
+
+/* node2vec+ noise thresholds, float32[n_nodes] (sparse_rw.py:22-35 / dense_rw.py:11-19);
+ * required before a call with extend != 0. */
+int pw_graph_set_thresholds(pw_graph *g, const float *thr);
+
+void pw_graph_destroy(pw_graph *g);
+
+/* ---- the walk operator ----------------------------------------------------------------- */
+/*
+ * Replaces Base._random_walks + has_nbrs + move_forward.
+ *   starts      uint32[n_jobs]  (already shuffled by the caller, pecanpy.py:135-141)
+ *   out         uint32[n_jobs * (walk_length + 2)]
+ *   has_seed=0  -> seed taken from the OS (reference: random_state=None)
+ *   stream_skip doubles of the stream consumed by earlier shards (0 for a whole job array)
+ * pw_simulate takes host pointers (copies in/out); pw_simulate_device takes device pointers on
+ * the handle's GPU (nothing crosses PCIe) and is what bench.py times.
+ */
+int pw_simulate(pw_graph *g, int mode, double p, double q, int extend, const uint32_t *starts,
+                uint64_t n_jobs, uint32_t walk_length, int has_seed, uint32_t seed,
+                uint64_t stream_skip, uint32_t *out, pw_stats *stats);
+
+int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
+                       const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
+                       int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
+                       pw_stats *stats);
+
+/* Number of stream doubles the jobs starts[0..n_jobs) consume when no walk dead-ends mid-way
+ * (= walk_length x number of starts with at least one neighbour).  Lets a multi-GPU driver
+ * compute each shard's stream_skip without running the walks. */
+int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
+                          uint32_t walk_length, uint64_t *out_draws);
+
+/* ---- random stream service (host side; usable without a GPU) ---------------------------- */
+/* doubles #offset.. of RandomState(seed).random_sample, produced with MT19937 jump-ahead. */
+int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out);
+
+/* ---- self test hooks (host only, no GPU needed) ------------------------------------------ */
+/* Runs the binade-scan emulation of csrc/seqscan.h on a host array: returns through *index the
+ * position np.searchsorted(np.cumsum(x), r) would return under sequential float32 semantics
+ * (n if never reached) and through *sum the sequential float32 sum.  chunk = elements per pass. */
+int pw_selftest_seqscan_f32(const float *x, uint32_t n, double r, int use_target, uint32_t chunk,
+                            uint32_t *index, float *sum);
+int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_target, uint32_t chunk,
+                            uint32_t *index, double *sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

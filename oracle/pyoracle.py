@@ -222,3 +222,33 @@ def shuffled_starts(num_nodes, num_walks, seed):
     rs = np.random.RandomState(seed)
     rs.shuffle(starts)
     return starts
+
+
+def baseline_lib():
+    global _BASE
+    if _BASE is None:
+        path = os.path.join(_HERE, "libcpu_baseline.so")
+        if not os.path.exists(path):
+            build()
+        _BASE = C.CDLL(path)
+    return _BASE
+
+
+def cpu_baseline_walks(indptr, indices, data, p, q, starts, walk_length, seed, n_threads=0,
+                       faithful=True, want_walks=False):
+    """OpenMP port of the Numba-parallel SparseOTF path (oracle/cpu_baseline.c).
+    Returns (steps, walks-or-None).  n_threads=0 -> all cores."""
+    indptr, indices, data = _csr(indptr, indices, data)
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    out = np.zeros((starts.size, walk_length + 2), dtype=np.uint32) if want_walks else None
+    steps = C.c_uint64(0)
+    baseline_lib().cpub_walks_sparse(
+        _ptr(indptr, C.c_uint32), _ptr(indices, C.c_uint32), _ptr(data, C.c_float),
+        C.c_uint32(indptr.size - 1), C.c_double(p), C.c_double(q), _ptr(starts, C.c_uint32),
+        C.c_uint64(starts.size), C.c_uint32(walk_length), C.c_uint32(seed), C.c_int(n_threads),
+        C.c_int(1 if faithful else 0), _ptr(out, C.c_uint32), C.byref(steps))
+    return int(steps.value), out
+
+
+def cpu_baseline_max_threads():
+    return int(baseline_lib().cpub_max_threads())

@@ -1,0 +1,108 @@
+"""ctypes binding of libpecanpy_amd.so (the C ABI declared in include/pecanpy_amd.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible the walk operator
+raises, loudly.  ``build()`` compiles the library in-tree with hipcc (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpecanpy_amd.so")
+_lib = None
+
+
+class PwStats(C.Structure):
+    _fields_ = [
+        ("total_steps", C.c_uint64),
+        ("overflow_reads", C.c_uint64),
+        ("clamped_reads", C.c_uint64),
+        ("dead_end_walks", C.c_uint64),
+        ("repair_rounds", C.c_uint64),
+        ("walk_kernel_ms", C.c_double),
+        ("rng_kernel_ms", C.c_double),
+        ("walk_kernel_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+MODE_IDS = {
+    "SparseOTF": 0,
+    "DenseOTF": 1,
+    "PreComp": 2,
+    "FirstOrderUnweighted": 3,
+    "PreCompFirstOrder": 4,
+}
+
+# every symbol include/pecanpy_amd.h declares: (restype, argtypes)
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_SIM_ARGS = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32,
+             C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(PwStats)]
+SYMBOLS = {
+    "pw_version": (C.c_char_p, []),
+    "pw_last_error": (C.c_char_p, []),
+    "pw_device_count": (C.c_int, []),
+    "pw_csr_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                C.POINTER(C.c_void_p)]),
+    "pw_dense_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "pw_graph_set_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pw_graph_destroy": (None, [C.c_void_p]),
+    "pw_simulate": (C.c_int, _SIM_ARGS),
+    "pw_simulate_device": (C.c_int, _SIM_ARGS),
+    "pw_count_stream_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                        C.POINTER(C.c_uint64)]),
+    "pw_mt_random_sample": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pw_selftest_seqscan_f32": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32,
+                                          _u32p, _f32p]),
+    "pw_selftest_seqscan_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32,
+                                          _u32p, _f64p]),
+}
+
+
+class PwError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libpecanpy_amd.so for gfx950 with hipcc (in-tree, so it travels with the repo)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise PwError("building libpecanpy_amd.so failed:\n" + res.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and type every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PwError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pecanpy_amd/csrc` -- the walk engine has no CPU fallback."
+        )
+    try:  # share torch's HIP runtime (same soname) when torch is used for device buffers / RCCL
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().pw_last_error()
+        raise PwError(f"libpecanpy_amd error {rc}: {msg.decode() if msg else '?'}")

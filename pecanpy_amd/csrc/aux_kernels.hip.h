@@ -1,0 +1,180 @@
+// aux_kernels.hip.h -- MT19937 stream expansion and stream-offset bookkeeping kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pw {
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 expansion: generator `gen` owns n_blocks consecutive 624-word blocks of the stream and
+// writes them as 312 doubles each (np.random.random(): two words -> 53 bits; reference call
+// site src/pecanpy/pecanpy.py:557; numba:cpython/randomimpl.py:133-146).
+//   states_in : [n_gen][624] pre-twist state of each generator's first block
+//   states_out: optional [n_gen][624] state after the last block (carry to the next batch)
+//   out       : doubles, generator g writes out[(g * n_blocks + b) * 312 + t]
+// One 256-thread workgroup per generator; the 624-word recurrence is evaluated in three
+// dependency phases (i<227 | 227<=i<454 | 454<=i<624) straight from LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_mix_dev(uint32_t hi, uint32_t lo, uint32_t far) {
+    uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper_dev(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__global__ void __launch_bounds__(256)
+mt_expand_kernel(const uint32_t *__restrict__ states_in, uint32_t *__restrict__ states_out,
+                 double *__restrict__ out, uint64_t n_blocks, uint64_t total_blocks) {
+    __shared__ uint32_t mt[624];
+    const int t = threadIdx.x;
+    const uint64_t gen = blockIdx.x;
+    for (int i = t; i < 624; i += 256) mt[i] = states_in[gen * 624 + i];
+    __syncthreads();
+    uint64_t first = gen * n_blocks;
+    uint64_t nb = first >= total_blocks ? 0 : (total_blocks - first < n_blocks ? total_blocks - first : n_blocks);
+    double *dst = out + first * 312;
+    for (uint64_t b = 0; b < nb; b++) {
+        // phase 1: i in [0, 227): needs old[i], old[i+1], old[i+397]
+        uint32_t v0 = 0, v1 = 0, v2 = 0;
+        if (t < 227) v0 = mt_mix_dev(mt[t], mt[t + 1], mt[t + 397]);
+        __syncthreads();
+        if (t < 227) mt[t] = v0;
+        __syncthreads();
+        // phase 2: i in [227, 454): needs old[i], old[i+1], new[i-227]
+        if (t < 227) v1 = mt_mix_dev(mt[t + 227], mt[t + 228], mt[t]);
+        __syncthreads();
+        if (t < 227) mt[t + 227] = v1;
+        __syncthreads();
+        // phase 3: i in [454, 624): needs old[i], old[i+1] (new[0] for i = 623), new[i-227]
+        if (t < 170) v2 = mt_mix_dev(mt[t + 454], (t + 455 < 624) ? mt[t + 455] : mt[0], mt[t + 227]);
+        __syncthreads();
+        if (t < 170) mt[t + 454] = v2;
+        __syncthreads();
+        for (int i = t; i < 312; i += 256) {
+            uint32_t a = mt_temper_dev(mt[2 * i]) >> 5;
+            uint32_t c = mt_temper_dev(mt[2 * i + 1]) >> 6;
+            dst[b * 312 + i] = ((double)a * 67108864.0 + (double)c) * (1.0 / 9007199254740992.0);
+        }
+        // the next phase-1 reads happen after its own barrier; writes above only read mt
+    }
+    __syncthreads();
+    if (states_out)
+        for (int i = t; i < 624; i += 256) states_out[gen * 624 + i] = mt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stream offsets.  draws[i] = number of doubles job i consumes.  First pass assumes every walk
+// from a start with neighbours runs its full length (always true on undirected graphs); repair
+// passes use the lengths the walk kernel actually produced (out[i][L+1] - 1).
+// Three small kernels = exclusive prefix sum over n_jobs 64-bit counts.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ uint64_t job_draws(const uint32_t *indptr, const uint32_t *starts,
+                                              const uint32_t *walks, uint32_t L, uint64_t i) {
+    if (walks) return (uint64_t)walks[i * ((uint64_t)L + 2) + L + 1] - 1;
+    uint32_t v = starts[i];
+    return indptr[v] != indptr[v + 1] ? (uint64_t)L : 0ull;
+}
+
+__device__ __forceinline__ uint64_t block_reduce_u64(uint64_t v, uint64_t *sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = SCAN_BLOCK / 2; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    uint64_t r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+draws_tile_sums_kernel(const uint32_t *indptr, const uint32_t *starts, const uint32_t *walks,
+                       uint32_t L, uint64_t n_jobs, uint64_t *tile_sums) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n_jobs) s += job_draws(indptr, starts, walks, L, base + k);
+    s = block_reduce_u64(s, sh);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
+}
+
+// single block: exclusive scan of tile sums in place; total goes to tile_sums[n_tiles]
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_tile_sums_kernel(uint64_t *tile_sums, uint64_t n_tiles) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    __shared__ uint64_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_tiles; base += SCAN_BLOCK) {
+        uint64_t v = base + t < n_tiles ? tile_sums[base + t] : 0;
+        sh[t] = v;
+        __syncthreads();
+        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+            uint64_t add = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += add;
+            __syncthreads();
+        }
+        uint64_t incl = sh[t];
+        uint64_t c = carry;
+        if (base + t < n_tiles) tile_sums[base + t] = c + incl - v;
+        __syncthreads();
+        if (t == SCAN_BLOCK - 1) carry = c + incl;
+        __syncthreads();
+    }
+    if (t == 0) tile_sums[n_tiles] = carry;
+}
+
+// stream_off[i] = skip + exclusive prefix of draws.  If prev_off != nullptr, jobs whose offset
+// changed are appended to changed_list (repair passes re-run exactly those).
+__global__ void __launch_bounds__(SCAN_BLOCK)
+draws_offsets_kernel(const uint32_t *indptr, const uint32_t *starts, const uint32_t *walks,
+                     uint32_t L, uint64_t n_jobs, const uint64_t *tile_sums, uint64_t skip,
+                     uint64_t *stream_off, uint32_t *changed_list,
+                     unsigned long long *changed_count) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    const int t = threadIdx.x;
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)t * SCAN_ITEMS;
+    uint64_t loc[SCAN_ITEMS];
+    uint64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        loc[k] = base + k < n_jobs ? job_draws(indptr, starts, walks, L, base + k) : 0;
+        s += loc[k];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint64_t add = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = skip + tile_sums[blockIdx.x] + sh[t] - s;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        uint64_t i = base + k;
+        if (i < n_jobs) {
+            if (changed_list) {
+                if (stream_off[i] != run && loc[k] != 0) {
+                    unsigned long long slot = atomicAdd(changed_count, 1ull);
+                    changed_list[slot] = (uint32_t)i;
+                }
+            }
+            stream_off[i] = run;
+        }
+        run += loc[k];
+    }
+}
+
+}  // namespace pw

@@ -1,0 +1,449 @@
+// pecanpy_amd.hip -- C ABI (include/pecanpy_amd.h) over the gfx950 walk kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off is mandatory: the reference's Numba code never fuses a*b+c, and the
+// bit-exact float chain depends on separately rounded operations.)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/pecanpy_amd.h"
+#include "aux_kernels.hip.h"
+#include "mtjump.hpp"
+#include "seqscan.h"
+#include "walk_sparse.hip.h"
+
+#define PW_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(PW_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) return fail(PW_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        cap = n;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct pw_graph {
+    int device = 0;
+    int kind = 0;  // 0 = CSR, 1 = dense
+    uint32_t n_nodes = 0, nnz = 0;
+    bool unit = false;  // all weights are 1.0f (data not stored)
+    uint32_t max_degree = 0;
+    uint32_t *d_indptr = nullptr, *d_indices = nullptr;
+    float *d_data = nullptr, *d_thr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_cu = 0;
+    // scratch reused across calls
+    DevBuf<uint64_t> stream_off, tile_sums;
+    DevBuf<double> rng;
+    DevBuf<uint32_t> mt_state, changed;
+    DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
+};
+
+namespace {
+
+int set_device(const pw_graph *g) {
+    HIP_TRY(hipSetDevice(g->device));
+    return 0;
+}
+
+uint32_t os_seed() {
+    std::random_device rd;
+    return (uint32_t)rd();
+}
+
+// host emulation of seq_scan (walk_sparse.hip.h) used by the self test: identical arithmetic,
+// `chunk` elements per pass instead of one wavefront pass.
+template <typename T>
+uint32_t seqscan_emulate(const T *x, uint32_t n, double r, bool use_target, uint32_t chunk, T *sum) {
+    using B = pw::Binade<T>;
+    using U = typename B::UInt;
+    T c = (T)0;
+    uint32_t k = 0;
+    std::vector<pw::Inc<T>> f(chunk);
+    while (k < n) {
+        const int eb = B::eb_of(c);
+        const U C = B::sig_of(c);
+        const U Tt = use_target ? B::threshold(r, eb) : B::TOP;
+        uint32_t m = n - k < chunk ? n - k : chunk;
+        pw::Inc<T> run = {0, 0};
+        uint32_t first = m;
+        U Cprev = C, Cn = C;
+        for (uint32_t l = 0; l < m; l++) {
+            f[l] = B::quantize(x[k + l], eb);
+            pw::Inc<T> incl = l ? B::compose(run, f[l]) : f[l];
+            U Ci = B::apply(C, incl);
+            if (Ci >= Tt) { first = l; Cn = Ci; break; }
+            Cprev = Ci;
+            run = incl;
+        }
+        if (first == m) {
+            c = B::make(Cprev, eb);
+            k += m;
+            continue;
+        }
+        uint32_t kf = k + first;
+        if (Cn < B::TOP) { c = B::make(Cn, eb); *sum = c; return kf; }
+        c = B::make(Cprev, eb) + x[kf];
+        if (use_target && (double)c >= r) { *sum = c; return kf; }
+        k = kf + 1;
+    }
+    *sum = c;
+    return n;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+PW_EXPORT const char *pw_version(void) { return "pecanpy_amd 0.1.0 (gfx950)"; }
+PW_EXPORT const char *pw_last_error(void) { return g_err.c_str(); }
+
+PW_EXPORT int pw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+PW_EXPORT void pw_graph_destroy(pw_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->d_indptr) (void)hipFree(g->d_indptr);
+    if (g->d_indices) (void)hipFree(g->d_indices);
+    if (g->d_data) (void)hipFree(g->d_data);
+    if (g->d_thr) (void)hipFree(g->d_thr);
+    g->stream_off.release();
+    g->tile_sums.release();
+    g->rng.release();
+    g->mt_state.release();
+    g->changed.release();
+    g->counters.release();
+    for (auto &e : g->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static int graph_common_init(pw_graph *g, int device) {
+    int n = pw_device_count();
+    if (n <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible (libpecanpy_amd needs a GPU; there is no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PW_ERR_INVALID, "device index out of range");
+    g->device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    g->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    for (auto &e : g->ev) HIP_TRY(hipEventCreate(&e));
+    return 0;
+}
+
+PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
+                            uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out) {
+    if (!indptr || !out || (nnz && !indices)) return fail(PW_ERR_INVALID, "null pointer");
+    if (indptr[n_nodes] != nnz) return fail(PW_ERR_INVALID, "indptr[n_nodes] != nnz");
+    pw_graph *g = new pw_graph();
+    int rc = graph_common_init(g, device);
+    if (rc) { pw_graph_destroy(g); return rc; }
+    g->kind = 0;
+    g->n_nodes = n_nodes;
+    g->nnz = nnz;
+    uint32_t md = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (indptr[i + 1] < indptr[i]) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "indptr not monotone"); }
+        uint32_t d = indptr[i + 1] - indptr[i];
+        if (d > md) md = d;
+    }
+    g->max_degree = md;
+    bool unit = true;
+    if (data) {
+        for (uint32_t k = 0; k < nnz; k++)
+            if (data[k] != 1.0f) { unit = false; break; }
+    }
+    g->unit = unit;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 4));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    rc = up((void **)&g->d_indptr, indptr, sizeof(uint32_t) * ((size_t)n_nodes + 1));
+    if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
+    if (!rc && !unit) rc = up((void **)&g->d_data, data, sizeof(float) * (size_t)nnz);
+    if (rc) { pw_graph_destroy(g); return rc; }
+    *out = g;
+    return PW_OK;
+}
+
+PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, pw_graph **out) {
+    (void)data; (void)n_nodes; (void)device; (void)out;
+    return fail(PW_ERR_UNSUPPORTED, "dense graphs: not implemented yet");
+}
+
+PW_EXPORT int pw_graph_set_thresholds(pw_graph *g, const float *thr) {
+    if (!g || !thr) return fail(PW_ERR_INVALID, "null pointer");
+    if (set_device(g)) return PW_ERR_HIP;
+    if (!g->d_thr) HIP_TRY(hipMalloc((void **)&g->d_thr, sizeof(float) * (size_t)g->n_nodes));
+    HIP_TRY(hipMemcpy(g->d_thr, thr, sizeof(float) * (size_t)g->n_nodes, hipMemcpyHostToDevice));
+    return PW_OK;
+}
+
+// exclusive prefix of per-job draw counts -> g->stream_off; returns total through *total
+static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t *d_walks, uint32_t L,
+                           uint64_t n_jobs, uint64_t skip, bool track_changes, uint64_t *total,
+                           uint64_t *n_changed) {
+    uint64_t n_tiles = (n_jobs + pw::SCAN_TILE - 1) / pw::SCAN_TILE;
+    if (g->stream_off.ensure(n_jobs + 1)) return PW_ERR_NOMEM;
+    if (g->tile_sums.ensure(n_tiles + 1)) return PW_ERR_NOMEM;
+    if (track_changes && g->changed.ensure(n_jobs)) return PW_ERR_NOMEM;
+    unsigned long long *cc = g->counters.p + 5;
+    if (track_changes) HIP_TRY(hipMemsetAsync(cc, 0, sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(pw::draws_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
+                       g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p);
+    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, g->tile_sums.p, n_tiles);
+    hipLaunchKernelGGL(pw::draws_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
+                       g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p,
+                       track_changes ? g->changed.p : nullptr, cc);
+    HIP_TRY(hipGetLastError());
+    uint64_t tot = 0;
+    HIP_TRY(hipMemcpyAsync(&tot, g->tile_sums.p + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    unsigned long long nc = 0;
+    if (track_changes) HIP_TRY(hipMemcpyAsync(&nc, cc, sizeof(nc), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    *total = tot;
+    if (n_changed) *n_changed = nc;
+    return 0;
+}
+
+PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
+                                    uint32_t walk_length, uint64_t *out_draws) {
+    if (!g || !starts || !out_draws) return fail(PW_ERR_INVALID, "null pointer");
+    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "pw_count_stream_draws: CSR graphs only");
+    if (set_device(g)) return PW_ERR_HIP;
+    if (g->counters.ensure(8)) return PW_ERR_NOMEM;
+    uint32_t *d_starts = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
+    hipError_t e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
+    int rc = 0;
+    uint64_t tot = 0;
+    if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    if (!rc && n_jobs) rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, 0, false, &tot, nullptr);
+    (void)hipFree(d_starts);
+    *out_draws = tot;
+    return rc;
+}
+
+static int launch_walks(pw_graph *g, pw::WalkArgs &wa) {
+    int occ = 0;
+    const void *fn = g->unit ? (const void *)pw::walk_sparse_kernel<true> : (const void *)pw::walk_sparse_kernel<false>;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ < 1) occ = 1;
+    uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
+    uint64_t want = (n_work + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
+    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
+    if (grid > want) grid = want;
+    if (grid < 1) grid = 1;
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    if (g->unit)
+        hipLaunchKernelGGL(pw::walk_sparse_kernel<true>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+    else
+        hipLaunchKernelGGL(pw::walk_sparse_kernel<false>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
+                                 const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
+                                 int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
+                                 pw_stats *stats) {
+    if (!g || (n_jobs && (!d_starts || !d_out))) return fail(PW_ERR_INVALID, "null pointer");
+    if (mode != PW_MODE_SPARSE_OTF) return fail(PW_ERR_UNSUPPORTED, "mode not implemented on the device yet");
+    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph");
+    if (extend) return fail(PW_ERR_UNSUPPORTED, "node2vec+ not implemented on the device yet");
+    if (!(p > 0) || !(q > 0)) return fail(PW_ERR_INVALID, "p and q must be positive");
+    if (walk_length < 1) return fail(PW_ERR_INVALID, "walk_length must be >= 1");
+    if (n_jobs >= 0xffffffffull) return fail(PW_ERR_INVALID, "n_jobs must fit uint32");
+    if (set_device(g)) return PW_ERR_HIP;
+    pw_stats st;
+    memset(&st, 0, sizeof(st));
+    if (n_jobs == 0) { if (stats) *stats = st; return PW_OK; }
+    if (!has_seed) seed = os_seed();
+    if (g->counters.ensure(8)) return PW_ERR_NOMEM;
+
+    // 1. stream offsets (nominal: every walk from a start with neighbours runs L steps)
+    uint64_t total = 0;
+    int rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, false, &total, nullptr);
+    if (rc) return rc;
+
+    // 2. MT19937 doubles covering [stream_skip, stream_skip + total)
+    const uint64_t first_block = stream_skip / 312;
+    const uint64_t end_block = (stream_skip + total + 311) / 312;
+    const uint64_t n_blocks = end_block > first_block ? end_block - first_block : 1;
+    if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
+    if (g->mt_state.ensure(pw::MT_N)) return PW_ERR_NOMEM;
+    {
+        uint32_t st0[pw::MT_N];
+        pw::MtJump::instance().state_at_block(seed, first_block, st0);
+        HIP_TRY(hipMemcpyAsync(g->mt_state.p, st0, sizeof(st0), hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));  // st0 is on the stack
+    }
+    HIP_TRY(hipEventRecord(g->ev[0], g->stream));
+    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(1), dim3(256), 0, g->stream, g->mt_state.p, (uint32_t *)nullptr,
+                       g->rng.p, n_blocks, n_blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[1], g->stream));
+
+    // 3. walks
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, 8 * sizeof(unsigned long long), g->stream));
+    pw::WalkArgs wa;
+    wa.g.indptr = g->d_indptr;
+    wa.g.indices = g->d_indices;
+    wa.g.data = g->d_data;
+    wa.g.thr = g->d_thr;
+    wa.g.n_nodes = g->n_nodes;
+    wa.g.nnz = g->nnz;
+    wa.p = p;
+    wa.q = q;
+    wa.L = walk_length;
+    wa.n_jobs = n_jobs;
+    wa.starts = d_starts;
+    wa.stream_off = g->stream_off.p;
+    wa.job_list = nullptr;
+    wa.n_list = 0;
+    wa.rng = g->rng.p;
+    wa.rng_base = first_block * 312;
+    wa.out = d_out;
+    wa.job_counter = g->counters.p;
+    wa.stats = g->counters.p + 1;
+    HIP_TRY(hipEventRecord(g->ev[2], g->stream));
+    rc = launch_walks(g, wa);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->ev[3], g->stream));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+    st.rng_kernel_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
+    st.walk_kernel_ms = ms;
+    st.walk_kernel_launches = 1;
+
+    // 4. dead ends shift the stream addresses of every later walk: re-address and re-run the
+    //    affected walks until the addressing is self-consistent (directed graphs only).
+    uint64_t dead = h[4];
+    const uint64_t max_rounds = 256;
+    while (dead > 0) {
+        uint64_t tot2 = 0, n_changed = 0;
+        rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, true, &tot2, &n_changed);
+        if (rc) return rc;
+        if (n_changed == 0) break;
+        if (st.repair_rounds >= max_rounds)
+            return fail(PW_ERR_UNSUPPORTED, "stream re-addressing after dead ends did not converge "
+                                            "(directed graph with many sinks)");
+        st.repair_rounds++;
+        wa.job_list = g->changed.p;
+        wa.n_list = n_changed;
+        HIP_TRY(hipEventRecord(g->ev[2], g->stream));
+        rc = launch_walks(g, wa);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(g->ev[3], g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
+        st.walk_kernel_ms += ms;
+        st.walk_kernel_launches++;
+    }
+    if (st.repair_rounds) {
+        // statistics of the final, self-consistent matrix
+        HIP_TRY(hipMemcpy(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        uint64_t tot2 = 0;
+        rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, false, &tot2, nullptr);
+        if (rc) return rc;
+        st.total_steps = tot2;
+    } else {
+        st.total_steps = h[1];
+    }
+    st.overflow_reads = h[2];
+    st.clamped_reads = h[3];
+    st.dead_end_walks = dead;
+    if (stats) *stats = st;
+    return PW_OK;
+}
+
+PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend, const uint32_t *starts,
+                          uint64_t n_jobs, uint32_t walk_length, int has_seed, uint32_t seed,
+                          uint64_t stream_skip, uint32_t *out, pw_stats *stats) {
+    if (!g || (n_jobs && (!starts || !out))) return fail(PW_ERR_INVALID, "null pointer");
+    if (set_device(g)) return PW_ERR_HIP;
+    uint32_t *d_starts = nullptr, *d_out = nullptr;
+    size_t out_elems = (size_t)n_jobs * ((size_t)walk_length + 2);
+    HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
+    hipError_t e = hipMalloc((void **)&d_out, sizeof(uint32_t) * (out_elems ? out_elems : 1));
+    if (e != hipSuccess) { (void)hipFree(d_starts); return fail(PW_ERR_NOMEM, hipGetErrorString(e)); }
+    int rc = 0;
+    e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    if (!rc) rc = pw_simulate_device(g, mode, p, q, extend, d_starts, n_jobs, walk_length, has_seed, seed,
+                                     stream_skip, d_out, stats);
+    if (!rc) {
+        e = hipMemcpy(out, d_out, sizeof(uint32_t) * out_elems, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_starts);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+PW_EXPORT int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out) {
+    if (n && !out) return fail(PW_ERR_INVALID, "null pointer");
+    pw::mt_random_sample_host(seed, offset, n, out);
+    return PW_OK;
+}
+
+PW_EXPORT int pw_selftest_seqscan_f32(const float *x, uint32_t n, double r, int use_target, uint32_t chunk,
+                                      uint32_t *index, float *sum) {
+    if (!x || !index || !sum || chunk == 0) return fail(PW_ERR_INVALID, "bad argument");
+    *index = seqscan_emulate<float>(x, n, r, use_target != 0, chunk, sum);
+    return PW_OK;
+}
+
+PW_EXPORT int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_target, uint32_t chunk,
+                                      uint32_t *index, double *sum) {
+    if (!x || !index || !sum || chunk == 0) return fail(PW_ERR_INVALID, "bad argument");
+    *index = seqscan_emulate<double>(x, n, r, use_target != 0, chunk, sum);
+    return PW_OK;
+}

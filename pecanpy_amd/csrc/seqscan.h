@@ -1,0 +1,168 @@
+// seqscan.h -- bit-exact *parallel* evaluation of a sequential floating-point running sum.
+//
+// The reference samples the next vertex with  cdf = np.cumsum(probs); np.searchsorted(cdf, r)
+// (src/pecanpy/pecanpy.py:556-557) after  probs = w / w.sum()  (src/pecanpy/rw/sparse_rw.py:89);
+// under Numba both reductions are naive left-to-right loops in the array dtype, so the sampled
+// index depends on the rounding of every partial sum.  A wavefront prefix-scan of floats rounds
+// differently.  This header provides the arithmetic that makes a wave-parallel scan reproduce the
+// sequential chain bit for bit:
+//
+//   While the running sum c stays inside one binade [2^e, 2^(e+1)) it is an integer multiple C of
+//   ulp = 2^(e-MANT).  Adding x >= 0 with round-to-nearest-even gives  C' = C + inc(x, parity(C)),
+//   where inc is the integer rounding of x/ulp (ties resolved by the parity of C + floor(x/ulp)).
+//   So inside a binade the chain is an *integer* scan of per-element parity-functions
+//   (a0 = increment when C is even, a1 = when C is odd), which is associative and exact.
+//   The one element per binade whose sum reaches 2^(e+1) is added with a real floating-point add,
+//   and the scan restarts after it in the new binade.
+//
+// Everything here is plain integer code usable on host (tests / CPU emulation) and device.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PW_HD __host__ __device__ __forceinline__
+#else
+#define PW_HD inline
+#endif
+
+namespace pw {
+
+template <typename T> struct FloatTraits;
+
+template <> struct FloatTraits<float> {
+    using UInt = uint32_t;
+    static constexpr int MANT = 23;          // explicit mantissa bits
+    static constexpr int EXP_MASK = 0xff;
+    static PW_HD UInt bits(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __float_as_uint(x);
+#else
+        UInt u; memcpy(&u, &x, sizeof(u)); return u;
+#endif
+    }
+    static PW_HD float from_bits(UInt u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __uint_as_float(u);
+#else
+        float x; memcpy(&x, &u, sizeof(u)); return x;
+#endif
+    }
+};
+
+template <> struct FloatTraits<double> {
+    using UInt = uint64_t;
+    static constexpr int MANT = 52;
+    static constexpr int EXP_MASK = 0x7ff;
+    static PW_HD UInt bits(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (UInt)__double_as_longlong(x);
+#else
+        UInt u; memcpy(&u, &x, sizeof(u)); return u;
+#endif
+    }
+    static PW_HD double from_bits(UInt u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __longlong_as_double((long long)u);
+#else
+        double x; memcpy(&x, &u, sizeof(u)); return x;
+#endif
+    }
+};
+
+// Parity function: C -> C + (C even ? a0 : a1).  Values saturate at SAT (anything >= the binade
+// top 2^(MANT+1) is only ever compared against it, never used numerically).
+template <typename T> struct Inc {
+    typename FloatTraits<T>::UInt a0, a1;
+};
+
+template <typename T> struct Binade {
+    using UInt = typename FloatTraits<T>::UInt;
+    static constexpr int MANT = FloatTraits<T>::MANT;
+    static constexpr UInt ONE = (UInt)1;
+    static constexpr UInt TOP = ONE << (MANT + 1);   // C reaches TOP  <=>  sum leaves the binade
+    static constexpr UInt SAT = ONE << (MANT + 2);   // saturation value for increments
+
+    // Biased exponent / integer significand of a finite c > 0 (denormals: eb = 1, C < 2^MANT).
+    static PW_HD int eb_of(T c) {
+        int eb = (int)((FloatTraits<T>::bits(c) >> MANT) & FloatTraits<T>::EXP_MASK);
+        return eb == 0 ? 1 : eb;
+    }
+    static PW_HD UInt sig_of(T c) {
+        UInt b = FloatTraits<T>::bits(c);
+        UInt frac = b & ((ONE << MANT) - 1);
+        int eb = (int)((b >> MANT) & FloatTraits<T>::EXP_MASK);
+        return eb == 0 ? frac : (frac | (ONE << MANT));
+    }
+    // c = C * 2^(eb - bias - MANT) for C < TOP
+    static PW_HD T make(UInt C, int eb) {
+        if (C < (ONE << MANT)) return FloatTraits<T>::from_bits(C);               // denormal (eb == 1)
+        return FloatTraits<T>::from_bits(((UInt)eb << MANT) | (C & ((ONE << MANT) - 1)));
+    }
+
+    // Increment function of adding x >= 0 to an accumulator whose biased exponent is eb.
+    static PW_HD Inc<T> quantize(T x, int eb) {
+        UInt M = sig_of(x);
+        int s = eb - eb_of(x);
+        Inc<T> r;
+        if (M == 0) { r.a0 = r.a1 = 0; return r; }
+        if (s <= 0) { r.a0 = r.a1 = SAT; return r; }        // x >= 2^e: the sum certainly leaves the binade
+        if (s > MANT + 2) { r.a0 = r.a1 = 0; return r; }    // x < ulp/4: absorbed
+        UInt fl = M >> s;
+        UInt rem = M & ((ONE << s) - 1);
+        UInt half = ONE << (s - 1);
+        if (rem > half) { r.a0 = r.a1 = fl + 1; }
+        else if (rem < half) { r.a0 = r.a1 = fl; }
+        else {                                              // exact tie: round half to even
+            UInt odd = fl & 1;
+            r.a0 = fl + odd;        // C even: C+fl has the parity of fl
+            r.a1 = fl + (odd ^ 1);  // C odd : C+fl is odd iff fl is even
+        }
+        return r;
+    }
+
+    // h = "f then g"
+    static PW_HD Inc<T> compose(Inc<T> f, Inc<T> g) {
+        Inc<T> h;
+        UInt x0 = f.a0 + ((f.a0 & 1) ? g.a1 : g.a0);
+        UInt x1 = f.a1 + ((f.a1 & 1) ? g.a0 : g.a1);
+        h.a0 = x0 > SAT ? SAT : x0;
+        h.a1 = x1 > SAT ? SAT : x1;
+        return h;
+    }
+
+    static PW_HD UInt apply(UInt C, Inc<T> f) { return C + ((C & 1) ? f.a1 : f.a0); }
+
+    // Smallest integer T_r with  C >= T_r  <=>  (double)(C * ulp) >= r   (r >= 0), clamped to TOP.
+    static PW_HD UInt threshold(double r, int eb);
+};
+
+template <> PW_HD uint32_t Binade<float>::threshold(double r, int eb) {
+    // ulp = 2^(eb-150); r/ulp = r * 2^(150-eb) is an exact scaling (no overflow: r < 1, eb >= 1)
+    double scaled = r;
+    int k = 150 - eb;               // 0 < k <= 149
+    // multiply by 2^k in two exact steps (2^k itself always fits a double)
+    scaled *= FloatTraits<double>::from_bits((uint64_t)(1023 + (k >> 1)) << 52);
+    scaled *= FloatTraits<double>::from_bits((uint64_t)(1023 + (k - (k >> 1))) << 52);
+    if (!(scaled < 16777216.0)) return TOP;
+    uint32_t t = (uint32_t)scaled;  // floor
+    if ((double)t < scaled) t++;
+    return t;
+}
+
+template <> PW_HD uint64_t Binade<double>::threshold(double r, int eb) {
+    int k = 1075 - eb;              // ulp = 2^(eb-1075)
+    double scaled = r;
+    // up to three exact power-of-two scalings keep every intermediate finite
+    while (k > 0 && scaled < 9007199254740992.0) {
+        int step = k > 512 ? 512 : k;
+        scaled *= FloatTraits<double>::from_bits((uint64_t)(1023 + step) << 52);
+        k -= step;
+    }
+    if (k > 0 || !(scaled < 9007199254740992.0)) return TOP;
+    uint64_t t = (uint64_t)scaled;
+    if ((double)t < scaled) t++;
+    return t;
+}
+
+}  // namespace pw

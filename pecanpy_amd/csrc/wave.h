@@ -1,0 +1,61 @@
+// wave.h -- 64-lane wavefront primitives for gfx950 (CDNA4).  Device code only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pw {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// v_readlane_b32 with a wave-uniform lane index
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    uint32_t lo = readlane_u32((uint32_t)v, l);
+    uint32_t hi = readlane_u32((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __uint_as_float(readlane_u32(__float_as_uint(v), l));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), l));
+}
+__device__ __forceinline__ uint32_t readfirst_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t readfirst_u64(uint64_t v) {
+    uint32_t lo = readfirst_u32((uint32_t)v);
+    uint32_t hi = readfirst_u32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename U> __device__ __forceinline__ U readlane_uint(U v, int l);
+template <> __device__ __forceinline__ uint32_t readlane_uint<uint32_t>(uint32_t v, int l) { return readlane_u32(v, l); }
+template <> __device__ __forceinline__ uint64_t readlane_uint<uint64_t>(uint64_t v, int l) { return readlane_u64(v, l); }
+
+template <typename T> __device__ __forceinline__ T readlane_fp(T v, int l);
+template <> __device__ __forceinline__ float readlane_fp<float>(float v, int l) { return readlane_f32(v, l); }
+template <> __device__ __forceinline__ double readlane_fp<double>(double v, int l) { return readlane_f64(v, l); }
+
+// value of lane (lane - delta); lanes < delta receive their own value
+template <typename U> __device__ __forceinline__ U shfl_up_uint(U v, int delta);
+template <> __device__ __forceinline__ uint32_t shfl_up_uint<uint32_t>(uint32_t v, int delta) {
+    return (uint32_t)__shfl_up((int)v, (unsigned)delta, WAVE);
+}
+template <> __device__ __forceinline__ uint64_t shfl_up_uint<uint64_t>(uint64_t v, int delta) {
+    return (uint64_t)__shfl_up((long long)v, (unsigned)delta, WAVE);
+}
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+
+// orders this wave's LDS traffic (cross-lane hand-off through LDS inside one wavefront)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace pw

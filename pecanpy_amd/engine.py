@@ -1,0 +1,115 @@
+"""Device-side walk engine: Python face of the C ABI (include/pecanpy_amd.h).
+
+``WalkEngine`` owns one device-resident graph handle (``pw_csr_create`` / ``pw_dense_create``) and
+exposes the walk operator that replaces the reference's ``Base._random_walks`` + ``has_nbrs`` +
+``move_forward`` (reference src/pecanpy/pecanpy.py:164-210).  NumPy arrays go through
+``pw_simulate`` (host pointers); torch CUDA tensors go through ``pw_simulate_device`` (nothing
+crosses PCIe).  ``simulate_sharded`` is the multi-GPU path: one process per GPU, the shuffled job
+array split into contiguous ranges, graph replicated, one gather of the walk shards at the end.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_IDS, PwError, PwStats
+
+__all__ = ["WalkEngine", "shard_bounds", "PwError"]
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def shard_bounds(n_jobs, world_size):
+    """Contiguous job ranges [lo, hi) per rank."""
+    return [((r * n_jobs) // world_size, ((r + 1) * n_jobs) // world_size) for r in range(world_size)]
+
+
+class WalkEngine:
+    def __init__(self, handle, lib, kind, n_nodes, device):
+        self._h = handle
+        self._lib = lib
+        self.kind = kind
+        self.n_nodes = n_nodes
+        self.device = device
+        self.last_stats = None
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def from_csr(cls, indptr, indices, data=None, device=0):
+        lib = _lib.load()
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=np.float32)
+        h = C.c_void_p()
+        _lib.check(lib.pw_csr_create(_np_ptr(indptr), _np_ptr(indices), _np_ptr(data),
+                                     indptr.size - 1, indices.size, int(device), C.byref(h)))
+        return cls(h, lib, "csr", indptr.size - 1, int(device))
+
+    @classmethod
+    def from_dense(cls, data, device=0):
+        lib = _lib.load()
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.ndim != 2 or data.shape[0] != data.shape[1]:
+            raise ValueError("dense adjacency must be a square matrix")
+        h = C.c_void_p()
+        _lib.check(lib.pw_dense_create(_np_ptr(data), data.shape[0], int(device), C.byref(h)))
+        return cls(h, lib, "dense", data.shape[0], int(device))
+
+    def set_thresholds(self, thr):
+        thr = np.ascontiguousarray(thr, dtype=np.float32)
+        if thr.size != self.n_nodes:
+            raise ValueError("threshold array must have one entry per node")
+        _lib.check(self._lib.pw_graph_set_thresholds(self._h, _np_ptr(thr)))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.pw_graph_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    # ---- the walk operator ----------------------------------------------------------------
+    def simulate(self, mode, p, q, extend, starts, walk_length, seed=None, stream_skip=0):
+        """Host-buffer variant: returns ``uint32[n_jobs, walk_length + 2]`` (NumPy)."""
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        out = np.empty((starts.size, walk_length + 2), dtype=np.uint32)
+        st = PwStats()
+        _lib.check(self._lib.pw_simulate(
+            self._h, MODE_IDS[mode], float(p), float(q), int(bool(extend)), _np_ptr(starts),
+            starts.size, int(walk_length), int(seed is not None), int(seed or 0) & 0xFFFFFFFF,
+            int(stream_skip), _np_ptr(out), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out
+
+    def simulate_device(self, mode, p, q, extend, d_starts, walk_length, seed=None, stream_skip=0,
+                        out=None):
+        """Device-buffer variant on torch CUDA tensors (int32 storage viewed as uint32)."""
+        import torch
+
+        if not d_starts.is_cuda or d_starts.dtype != torch.int32 or not d_starts.is_contiguous():
+            raise ValueError("d_starts must be a contiguous int32 CUDA tensor")
+        n = d_starts.numel()
+        if out is None:
+            out = torch.empty((n, walk_length + 2), dtype=torch.int32, device=d_starts.device)
+        torch.cuda.current_stream(d_starts.device).synchronize()  # inputs were produced on torch's stream
+        st = PwStats()
+        _lib.check(self._lib.pw_simulate_device(
+            self._h, MODE_IDS[mode], float(p), float(q), int(bool(extend)),
+            C.c_void_p(d_starts.data_ptr()), n, int(walk_length), int(seed is not None),
+            int(seed or 0) & 0xFFFFFFFF, int(stream_skip), C.c_void_p(out.data_ptr()), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out
+
+    def count_stream_draws(self, starts, walk_length):
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        n = C.c_uint64(0)
+        _lib.check(self._lib.pw_count_stream_draws(self._h, _np_ptr(starts), starts.size,
+                                                   int(walk_length), C.byref(n)))
+        return int(n.value)

@@ -1,0 +1,259 @@
+"""node2vec walk strategies: the reference's mode classes on the MI355X walk engine.
+
+Drop-in mirror of ``pecanpy.pecanpy`` (reference src/pecanpy/pecanpy.py): same class names,
+constructor signature ``(p, q, workers, verbose, extend, gamma, random_state)`` (:83-101) and
+methods ``simulate_walks`` (:116-162), ``preprocess_transition_probs`` (:231-238), ``embed``
+(:240-290).  What differs is where the walks run: ``Base._random_walks`` (the Numba ``prange``
+kernel, :164-210) and the per-mode ``move_forward`` closures are replaced by one call into
+``libpecanpy_amd.so`` (HIP kernels for gfx950).  Seeded runs reproduce the reference's
+*single-thread* walks bit for bit, independent of how many GPUs execute them.
+"""
+import numpy as np
+
+from .engine import WalkEngine
+from .graph import BaseGraph, DenseGraph, SparseGraph
+from .wrappers import Timer
+
+__all__ = ["Base", "FirstOrderUnweighted", "PreCompFirstOrder", "PreComp", "SparseOTF", "DenseOTF"]
+
+
+class Base(BaseGraph):
+    """Skeleton shared by all walk modes (reference ``Base``, pecanpy.py:27-290).
+
+    Args mirror the reference: ``p`` return parameter, ``q`` in-out parameter, ``workers`` (used
+    for Word2Vec only), ``verbose``, ``extend`` (node2vec+), ``gamma`` (noise-threshold factor),
+    ``random_state`` (seed; ``None`` = entropy from the OS).
+    """
+
+    _mode = None  # name understood by the C ABI (pw_mode)
+
+    def __init__(self, p=1, q=1, workers=1, verbose=False, extend=False, gamma=0, random_state=None):
+        super().__init__()
+        self.p = p
+        self.q = q
+        self.workers = workers
+        self.verbose = verbose
+        self.extend = extend
+        self.gamma = gamma
+        self.random_state = random_state
+        self._preprocessed = False
+        self._engine = None
+        self._engine_key = None
+        self.device = None  # GPU index; None -> LOCAL_RANK / 0
+        self.last_stats = None
+
+    # ---- engine plumbing -------------------------------------------------------------------
+    def _device_index(self):
+        if self.device is not None:
+            return int(self.device)
+        import os
+
+        return int(os.environ.get("LOCAL_RANK", "0"))
+
+    def _graph_key(self):
+        raise NotImplementedError
+
+    def _make_engine(self, device):
+        raise NotImplementedError
+
+    def _get_engine(self):
+        key = (self._graph_key(), self._device_index())
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._make_engine(self._device_index())
+            self._engine_key = key
+            if self.extend:
+                self._engine.set_thresholds(self.get_noise_thresholds())
+        return self._engine
+
+    # ---- reference API ---------------------------------------------------------------------
+    def _map_walk(self, walk_idx_ary):
+        """Index row -> ID list; the last cell is the effective length (pecanpy.py:103-114)."""
+        n = int(walk_idx_ary[-1])
+        ids = self.nodes
+        return [ids[i] for i in walk_idx_ary[:n].tolist()]
+
+    def _start_array(self, num_walks):
+        """Each node ``num_walks`` times, then NumPy's legacy seeded shuffle (pecanpy.py:135-141)."""
+        nodes = np.arange(self.num_nodes, dtype=np.uint32)
+        starts = np.concatenate([nodes] * num_walks)
+        np.random.seed(self.random_state)
+        np.random.shuffle(starts)
+        return starts
+
+    def simulate_walks_array(self, num_walks, walk_length):
+        """The walk index matrix ``uint32[n_jobs, walk_length + 2]`` (what ``_random_walks``
+        returns in the reference); ``simulate_walks`` maps it to ID lists."""
+        self._preprocess_transition_probs()
+        starts = self._start_array(num_walks)
+        return self._random_walks(starts, walk_length)
+
+    def simulate_walks(self, num_walks, walk_length):
+        """Generate ``num_walks`` walks from every node; returns ``List[List[str]]``."""
+        mat = self.simulate_walks_array(num_walks, walk_length)
+        return [self._map_walk(row) for row in mat]
+
+    def _random_walks(self, starts, walk_length):
+        """GPU replacement of the reference's njit ``_random_walks`` (pecanpy.py:164-210)."""
+        eng = self._get_engine()
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return self._random_walks_sharded(eng, starts, walk_length)
+        mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length,
+                           seed=self.random_state)
+        self.last_stats = eng.last_stats
+        return mat
+
+    def _random_walks_sharded(self, eng, starts, walk_length):
+        import torch
+
+        from .sharding import sharded_walk_matrix, to_uint32_numpy
+
+        dev = torch.device("cuda", eng.device)
+        seed = self.random_state
+        if seed is None:  # every rank must address the same stream
+            import torch.distributed as dist
+
+            box = [int(np.random.SeedSequence().generate_state(1)[0])]
+            dist.broadcast_object_list(box, src=0)
+            seed = box[0]
+
+        def run_shard(sl, skip):
+            d_starts = torch.from_numpy(np.ascontiguousarray(sl).view(np.int32)).to(dev)
+            out = eng.simulate_device(self._mode, self.p, self.q, self.extend, d_starts,
+                                      walk_length, seed=seed, stream_skip=skip)
+            return out, eng.last_stats["total_steps"]
+
+        full = sharded_walk_matrix(run_shard, lambda sl: eng.count_stream_draws(sl, walk_length),
+                                   starts, walk_length)
+        self.last_stats = eng.last_stats
+        return to_uint32_numpy(full)
+
+    def setup_get_normalized_probs(self):
+        """Kept for API compatibility: returns ``(None, thresholds-or-None)``; the transition
+        probabilities themselves are computed inside the HIP kernels."""
+        return None, (self.get_noise_thresholds() if self.extend else None)
+
+    def preprocess_transition_probs(self):
+        """No-op for on-the-fly modes (pecanpy.py:231-233)."""
+
+    def _preprocess_transition_probs(self):
+        if not self._preprocessed:
+            self.preprocess_transition_probs()
+            self._preprocessed = True
+
+    def embed(self, dim=128, num_walks=10, walk_length=80, window_size=10, epochs=1, verbose=False):
+        """``simulate_walks`` + gensim skip-gram (pecanpy.py:240-290).  Embedding training is out
+        of scope for the GPU engine; gensim is used when installed."""
+        try:
+            from gensim.models import Word2Vec
+        except ImportError as exc:  # pragma: no cover
+            raise ImportError("embed() needs gensim for the Word2Vec step; walk generation "
+                              "(simulate_walks) does not") from exc
+        walks = Timer("generate walks", verbose)(self.simulate_walks)(num_walks, walk_length)
+        w2v = Timer("train embeddings", verbose)(Word2Vec)(
+            walks, vector_size=dim, window=window_size, sg=1, min_count=0, workers=self.workers,
+            epochs=epochs, seed=self.random_state)
+        return w2v.wv[self.nodes]
+
+
+class _SparseBase(Base, SparseGraph):
+    """CSR-backed modes (reference ``SparseRWGraph`` mixin, rw/sparse_rw.py:9-35)."""
+
+    def __init__(self, *args, **kwargs):
+        Base.__init__(self, *args, **kwargs)
+        self.data = None
+        self.indptr = None
+        self.indices = None
+
+    def _graph_key(self):
+        return (id(self.indptr), id(self.indices), id(self.data))
+
+    def _make_engine(self, device):
+        return WalkEngine.from_csr(self.indptr, self.indices, self.data, device=device)
+
+    def get_has_nbrs(self):
+        """``has_nbrs(idx)`` callback (sparse_rw.py:12-20); host-side helper, not used by the GPU path."""
+        indptr = self.indptr
+        return lambda idx: indptr[idx] != indptr[idx + 1]
+
+    def get_noise_thresholds(self):
+        """Per-node noisy-edge threshold mean + gamma*std, clipped at 0 (sparse_rw.py:22-35).
+        Plain NumPy on the host, evaluated row by row exactly like the reference."""
+        data, indptr = self.data, self.indptr
+        n = self.num_nodes
+        thr = np.zeros(n, dtype=np.float32)
+        if data.size and np.all(data == data[0]) and np.all(indptr[1:] != indptr[:-1]):
+            thr[:] = data[0]  # constant rows: mean = w, std = 0 (exact)
+            return np.maximum(thr, 0)
+        for i in range(n):
+            row = data[indptr[i]:indptr[i + 1]]
+            thr[i] = row.mean() + self.gamma * row.std()
+        return np.maximum(thr, 0)
+
+
+class SparseOTF(_SparseBase):
+    """Sparse graph, transition probabilities on the fly (reference pecanpy.py:510-561)."""
+
+    _mode = "SparseOTF"
+
+
+class FirstOrderUnweighted(_SparseBase):
+    """Uniform neighbour pick, p = q = 1, unweighted (reference pecanpy.py:293-309)."""
+
+    _mode = "FirstOrderUnweighted"
+
+
+class PreCompFirstOrder(_SparseBase):
+    """First-order alias tables (reference pecanpy.py:312-361)."""
+
+    _mode = "PreCompFirstOrder"
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alias_j = self.alias_q = None
+
+
+class PreComp(_SparseBase):
+    """Second-order alias tables (reference pecanpy.py:364-507)."""
+
+    _mode = "PreComp"
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alias_dim = None
+        self.alias_j = None
+        self.alias_q = None
+        self.alias_indptr = None
+
+
+class DenseOTF(Base, DenseGraph):
+    """Dense graph, transition probabilities on the fly (reference pecanpy.py:564-614)."""
+
+    _mode = "DenseOTF"
+
+    def __init__(self, *args, **kwargs):
+        Base.__init__(self, *args, **kwargs)
+        self._data = None
+        self._nonzero = None
+
+    def _graph_key(self):
+        return (id(self._data),)
+
+    def _make_engine(self, device):
+        return WalkEngine.from_dense(self.data, device=device)
+
+    def get_has_nbrs(self):
+        nonzero = self.nonzero
+        return lambda idx: bool(nonzero[idx].any())
+
+    def get_noise_thresholds(self):
+        """Dense variant (rw/dense_rw.py:11-19)."""
+        n = self.num_nodes
+        thr = np.zeros(n, dtype=np.float32)
+        for i in range(n):
+            w = self.data[i, self.nonzero[i]]
+            thr[i] = w.mean() + self.gamma * w.std()
+        return np.maximum(thr, 0)

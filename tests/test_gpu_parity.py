@@ -1,0 +1,157 @@
+"""GPU parity tests: the HIP path through the C ABI vs the CPU oracle and the golden fixtures.
+
+Bit-exact comparisons (integer node-id output).  Run with ``-m gpu`` on an MI355X.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from pecanpy_amd.engine import WalkEngine
+from pecanpy_amd.synth import rmat_csr
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sparse_fixtures(extend):
+    out = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        b = os.path.basename(f)
+        if "_SparseOTF_" not in b:
+            continue
+        if ("n2vplus" in b) != extend:
+            continue
+        out.append(f)
+    return out
+
+
+def _diff_report(got, want):
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    if bad.size == 0:
+        return ""
+    i = int(bad[0])
+    j = int(np.nonzero(got[i] != want[i])[0][0])
+    return f"{bad.size}/{got.shape[0]} walks differ; first: walk {i} step {j}: got {got[i, j]} want {want[i, j]}"
+
+
+@pytest.mark.parametrize("path", _sparse_fixtures(False), ids=lambda f: os.path.basename(f)[:-4])
+def test_golden_sparse_otf(path):
+    z = np.load(path)
+    eng = WalkEngine.from_csr(z["indptr"], z["indices"], z["data"])
+    got = eng.simulate("SparseOTF", float(z["p"]), float(z["q"]), False, z["starts"],
+                       int(z["walk_length"]), seed=int(z["seed"]))
+    assert got.shape == z["walks"].shape
+    assert np.array_equal(got, z["walks"]), _diff_report(got, z["walks"])
+
+
+def _check_vs_oracle(indptr, indices, data, p, q, num_walks, L, seed, stream_skip=0, job_slice=None):
+    n = indptr.size - 1
+    starts = orc.shuffled_starts(n, num_walks, seed)
+    if job_slice is not None:
+        starts = starts[job_slice]
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, L, seed,
+                                     stream_skip=stream_skip, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", p, q, False, starts, L, seed=seed, stream_skip=stream_skip)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    st = eng.last_stats
+    assert st["total_steps"] == ost.total_steps
+    assert st["overflow_reads"] == ost.overflow_reads
+    return st
+
+
+@pytest.mark.parametrize("scale,p,q", [(10, 0.5, 2), (12, 0.25, 4), (13, 2, 0.5), (12, 1, 1)])
+def test_rmat_unweighted_vs_oracle(scale, p, q):
+    indptr, indices, data = rmat_csr(scale, seed=scale)
+    _check_vs_oracle(indptr, indices, data, p, q, 2, 40, seed=scale)
+
+
+@pytest.mark.parametrize("p,q", [(0.5, 2), (0.3, 1.7), (3.0, 0.37)])
+def test_rmat_weighted_vs_oracle(p, q):
+    indptr, indices, data = rmat_csr(11, seed=5, weighted=True)
+    _check_vs_oracle(indptr, indices, data, p, q, 2, 30, seed=9)
+
+
+def test_unweighted_non_dyadic_pq():
+    indptr, indices, data = rmat_csr(11, seed=6)
+    _check_vs_oracle(indptr, indices, data, 0.3, 1.7, 2, 30, seed=2)
+
+
+def _hub_graph(n_leaves, extra_edges, seed, weighted):
+    """A few very high degree hubs (rows longer than one LDS mask segment) plus random edges."""
+    rng = np.random.default_rng(seed)
+    n = n_leaves + 3
+    src = [np.full(n_leaves, 0), np.full(n_leaves // 2, 1), np.full(n_leaves // 3, 2)]
+    dst = [np.arange(3, 3 + n_leaves), 3 + rng.choice(n_leaves, n_leaves // 2, replace=False),
+           3 + rng.choice(n_leaves, n_leaves // 3, replace=False)]
+    src.append(rng.integers(0, n, extra_edges))
+    dst.append(rng.integers(0, n, extra_edges))
+    src.append(np.array([0, 0, 1]))
+    dst.append(np.array([1, 2, 2]))
+    s, d = np.concatenate(src), np.concatenate(dst)
+    keep = s != d
+    s, d = s[keep], d[keep]
+    from pecanpy_amd.synth import csr_from_edges, hash_edge_weights
+
+    indptr, indices, data = csr_from_edges(np.concatenate([s, d]), np.concatenate([d, s]), n)
+    if weighted:
+        data = hash_edge_weights(indptr, indices, seed)
+    return indptr, indices, data
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_hub_rows_longer_than_mask_segment(weighted):
+    indptr, indices, data = _hub_graph(70000, 50000, 1, weighted)
+    assert (np.diff(indptr.astype(np.int64)).max()) > 32768
+    n = indptr.size - 1
+    rng = np.random.default_rng(0)
+    starts = np.concatenate([np.array([0, 1, 2] * 20), rng.integers(0, n, 400)]).astype(np.uint32)
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 12, 4, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, 12, seed=4)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    assert eng.last_stats["overflow_reads"] == ost.overflow_reads
+
+
+def test_overflow_reads_are_mirrored():
+    """choice == degree (float32 CDF short of 1) must read the next row's first neighbour
+    exactly like the reference; RMAT-14 produces a few of those."""
+    indptr, indices, data = rmat_csr(14, seed=14)
+    st = _check_vs_oracle(indptr, indices, data, 0.5, 2, 4, 80, seed=0)
+    assert st["total_steps"] > 10**6
+
+
+def test_stream_skip_shard():
+    indptr, indices, data = rmat_csr(11, seed=7)
+    n = indptr.size - 1
+    starts = orc.shuffled_starts(n, 3, 1)
+    full = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 25, 1)
+    cut = starts.size // 3 + 5
+    skip = int((full[:cut, -1].astype(np.int64) - 1).sum())
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    assert eng.count_stream_draws(starts[:cut], 25) == skip
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts[cut:], 25, seed=1, stream_skip=skip)
+    assert np.array_equal(got, full[cut:]), _diff_report(got, full[cut:])
+
+
+def test_long_walks_and_large_offsets():
+    """walk_length > 128 and a stream offset beyond 2^32 words (jump-ahead + expansion)."""
+    indptr, indices, data = rmat_csr(9, seed=2)
+    n = indptr.size - 1
+    starts = orc.shuffled_starts(n, 1, 3)[:64]
+    skip = 10**7 + 17
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 200, 3, stream_skip=skip)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, 200, seed=3, stream_skip=skip)
+    assert np.array_equal(got, want), _diff_report(got, want)
+
+
+def test_mode_classes_drop_in():
+    from pecanpy import pecanpy  # the alias package
+    from ref_test_walk import IDS, MAT, WALKS
+
+    g = pecanpy.SparseOTF.from_mat(MAT, IDS, p=1, q=1, random_state=0)
+    assert g.simulate_walks(2, 3) == WALKS["SparseOTF"]
