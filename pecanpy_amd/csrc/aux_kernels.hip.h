@@ -68,6 +68,53 @@ mt_expand_kernel(const uint32_t *__restrict__ states_in, uint32_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Jump-ahead on the device: dst_state = g(A) src_state for a polynomial g of degree < 19937
+// (host table MtJump::pow2_table(): g = x^(624*2^m) moves a generator 2^m blocks forward).
+// With w_0.. the raw word sequence started by src_state,  dst[i] = XOR_{j : g_j = 1} w[i + j].
+// One 640-thread workgroup per jump: 32 further blocks of the sequence are generated into LDS
+// (33 * 624 words = 82 KB), then thread i folds the ~10^4 taps of g for output word i
+// (consecutive threads read consecutive LDS words: conflict free).
+// Block b jumps states[b * src_stride] -> states[b * src_stride + dst_offset] (in place allowed).
+// ---------------------------------------------------------------------------------------------
+constexpr int MT_SEQ_BLOCKS = 33;
+constexpr int MT_POLY_WORDS = 312;
+
+__global__ void __launch_bounds__(640)
+mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly, uint32_t src_stride,
+               uint32_t dst_offset) {
+    __shared__ uint32_t seq[MT_SEQ_BLOCKS * 624];
+    __shared__ uint64_t spoly[MT_POLY_WORDS];
+    const int t = threadIdx.x;
+    const uint64_t src = (uint64_t)blockIdx.x * src_stride;
+    if (t < 624) seq[t] = states[src * 624 + t];
+    if (t < MT_POLY_WORDS) spoly[t] = poly[t];
+    __syncthreads();
+    for (int blk = 1; blk < MT_SEQ_BLOCKS; blk++) {
+        uint32_t *nw = seq + blk * 624;
+        const uint32_t *od = nw - 624;
+        if (t < 227) nw[t] = mt_mix_dev(od[t], od[t + 1], od[t + 397]);
+        __syncthreads();
+        if (t >= 227 && t < 454) nw[t] = mt_mix_dev(od[t], od[t + 1], nw[t - 227]);
+        __syncthreads();
+        if (t >= 454 && t < 624) nw[t] = mt_mix_dev(od[t], (t < 623) ? od[t + 1] : nw[0], nw[t - 227]);
+        __syncthreads();
+    }
+    if (t < 624) {
+        uint32_t acc = 0;
+        for (int jw = 0; jw < MT_POLY_WORDS; jw++) {
+            uint64_t word = spoly[jw];
+            const uint32_t *base = seq + t + jw * 64;
+            while (word) {
+                int b = __builtin_ctzll(word);
+                word &= word - 1;
+                acc ^= base[b];
+            }
+        }
+        states[(src + dst_offset) * 624 + t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stream offsets.  draws[i] = number of doubles job i consumes.  First pass assumes every walk
 // from a start with neighbours runs its full length (always true on undirected graphs); repair
 // passes use the lengths the walk kernel actually produced (out[i][L+1] - 1).

@@ -130,8 +130,43 @@ class MtJump {
         return phi_terms_;
     }
 
+    // Table of jump polynomials T[m] = x^(624 * 2^m) mod phi, m = 0..MAX_POW2 (MT_PW words each):
+    // T[m] moves a generator forward by 2^m blocks.  Seed independent; built once per process.
+    static constexpr int MAX_POW2 = 44;
+    const uint64_t *pow2_table() {
+        std::call_once(table_once_, [this] {
+            ensure_phi();
+            table_.assign((size_t)(MAX_POW2 + 1) * MT_PW, 0);
+            MtPoly g;
+            pow_x((uint64_t)MT_N, g);
+            for (int m = 0; m <= MAX_POW2; m++) {
+                memcpy(&table_[(size_t)m * MT_PW], g.w, sizeof(uint64_t) * MT_PW);
+                if (m < MAX_POW2) square(g);
+            }
+        });
+        return table_.data();
+    }
+
+    // g <- g^2 mod phi
+    void square(MtPoly &g) {
+        ensure_phi();
+        MtPoly sq;
+        sq.clear();
+        for (int wi = 0; wi < MT_PW; wi++) {
+            uint64_t v = g.w[wi];
+            while (v) {
+                int bit = __builtin_ctzll(v);
+                v &= v - 1;
+                sq.flip(2 * (wi * 64 + bit));
+            }
+        }
+        reduce(sq);
+        g = sq;
+    }
+
   private:
-    std::once_flag once_;
+    std::once_flag once_, table_once_;
+    std::vector<uint64_t> table_;
     std::vector<int> phi_terms_;  // exponents with a non-zero coefficient, excluding nothing
 
     void ensure_phi() { std::call_once(once_, [this] { derive_phi(); }); }

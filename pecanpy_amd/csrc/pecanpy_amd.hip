@@ -73,6 +73,8 @@ struct pw_graph {
     DevBuf<uint64_t> stream_off, tile_sums;
     DevBuf<double> rng;
     DevBuf<uint32_t> mt_state, changed;
+    DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
+    bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
 };
 
@@ -151,6 +153,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->tile_sums.release();
     g->rng.release();
     g->mt_state.release();
+    g->jump_table.release();
     g->changed.release();
     g->counters.release();
     for (auto &e : g->ev)
@@ -309,21 +312,53 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     int rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, false, &total, nullptr);
     if (rc) return rc;
 
-    // 2. MT19937 doubles covering [stream_skip, stream_skip + total)
+    // 2. MT19937 doubles covering [stream_skip, stream_skip + total): n_gen generators, each
+    //    expanding `per_gen` (a power of two) consecutive blocks; generator states come from the
+    //    seed state by polynomial jump-ahead on the device (binary tree of x^(624*2^m) jumps).
     const uint64_t first_block = stream_skip / 312;
     const uint64_t end_block = (stream_skip + total + 311) / 312;
     const uint64_t n_blocks = end_block > first_block ? end_block - first_block : 1;
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
-    if (g->mt_state.ensure(pw::MT_N)) return PW_ERR_NOMEM;
+    uint64_t per_gen = 1;
+    int per_gen_log = 0;
+    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }
+    const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
+    if (g->mt_state.ensure((size_t)pw::MT_N * n_gen)) return PW_ERR_NOMEM;
+    if (!g->jump_table_ready) {
+        const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
+        if (g->jump_table.ensure(words)) return PW_ERR_NOMEM;
+        HIP_TRY(hipMemcpy(g->jump_table.p, pw::MtJump::instance().pow2_table(), words * sizeof(uint64_t),
+                          hipMemcpyHostToDevice));
+        g->jump_table_ready = true;
+    }
     {
         uint32_t st0[pw::MT_N];
-        pw::MtJump::instance().state_at_block(seed, first_block, st0);
+        pw::mt_seed_state(st0, seed);
         HIP_TRY(hipMemcpyAsync(g->mt_state.p, st0, sizeof(st0), hipMemcpyHostToDevice, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));  // st0 is on the stack
     }
     HIP_TRY(hipEventRecord(g->ev[0], g->stream));
-    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(1), dim3(256), 0, g->stream, g->mt_state.p, (uint32_t *)nullptr,
-                       g->rng.p, n_blocks, n_blocks);
+    if ((first_block >> (pw::MtJump::MAX_POW2 + 1)) != 0) return fail(PW_ERR_INVALID, "stream offset too large");
+    for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
+        if ((first_block >> m) & 1)
+            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(1), dim3(640), 0, g->stream, g->mt_state.p,
+                               g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
+    {
+        uint32_t top = 1;
+        int top_log = 0;
+        while (top < n_gen) { top <<= 1; top_log++; }
+        for (int lvl = top_log - 1; lvl >= 0; lvl--) {  // generator i -> i + 2^lvl, for i % 2^(lvl+1) == 0
+            uint32_t s = 1u << lvl;
+            if (s >= n_gen) continue;
+            uint32_t pairs = (n_gen - s + 2 * s - 1) / (2 * s);
+            int m = lvl + per_gen_log;
+            if (m > pw::MtJump::MAX_POW2) return fail(PW_ERR_INVALID, "stream too long");
+            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(pairs), dim3(640), 0, g->stream, g->mt_state.p,
+                               g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
+        }
+    }
+    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, g->mt_state.p,
+                       (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[1], g->stream));
 
