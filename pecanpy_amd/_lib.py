@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpecanpy_amd.so")
+LIB_PATH = os.environ.get("PECANPY_AMD_LIB") or os.path.join(_HERE, "libpecanpy_amd.so")  # env override: A/B kernel variants
 _lib = None
 
 

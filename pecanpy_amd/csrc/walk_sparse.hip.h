@@ -7,14 +7,19 @@
 //   1. membership  : which neighbours of `cur` are also neighbours of `prev`
 //                    (reference: two-pointer isnotin, sparse_rw.py:142-230).  Done here by
 //                    binary-searching the *shorter* of the two sorted rows into the longer one
-//                    (min(d_cur,d_prev) * log2(max) probes) and recording the result as one bit
-//                    per neighbour of `cur` in an LDS bitmask owned by the wave.
+//                    (min(d_cur,d_prev) * log2(max) probes, several independent probe chains per
+//                    lane) and recording the result as one bit per neighbour of `cur` in an LDS
+//                    bitmask owned by the wave.
 //   2. tot         : sequential float32 sum of the biased weights      (sparse_rw.py:89)
 //   3. cdf search  : first k with cumsum(w/tot)[k] >= r, sequential float32 (pecanpy.py:556-557)
 //   4. next        : indices[indptr[cur] + k], k == degree mirrored     (pecanpy.py:559, App. D)
 //
 // 2 and 3 use the binade scan of seqscan.h so that the wave-parallel evaluation is bit-identical
-// to the reference's left-to-right float32 loops.
+// to the reference's left-to-right float32 loops.  Unweighted graphs take a closed-form variant
+// of the same chain (run lengths of equal values, see "unit-weight fast path").
+//
+// Everything a wave decides on is wave-uniform; values loaded from memory are passed through
+// readfirstlane so that the compiler keeps them in SGPRs (scalar address arithmetic, scalar loads).
 #pragma once
 #include "seqscan.h"
 #include "wave.h"
@@ -22,10 +27,10 @@
 namespace pw {
 
 struct CsrDev {
-    const uint32_t *indptr;
-    const uint32_t *indices;
-    const float *data;  // nullptr: every weight is 1.0f
-    const float *thr;   // node2vec+ thresholds or nullptr
+    const uint32_t *__restrict__ indptr;
+    const uint32_t *__restrict__ indices;
+    const float *__restrict__ data;  // nullptr: every weight is 1.0f
+    const float *__restrict__ thr;   // node2vec+ thresholds or nullptr
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -35,75 +40,142 @@ struct WalkArgs {
     double p, q;
     uint32_t L;
     uint64_t n_jobs;
-    const uint32_t *starts;
-    const uint64_t *stream_off;  // per job: absolute index of its first double in the stream
-    const uint32_t *job_list;    // optional: run only these jobs (repair passes); nullptr = all
+    const uint32_t *__restrict__ starts;
+    const uint64_t *__restrict__ stream_off;  // per job: absolute index of its first double
+    const uint32_t *__restrict__ job_list;    // optional: run only these jobs (repair passes)
     uint64_t n_list;
-    const double *rng;           // rng[n - rng_base]
+    const double *__restrict__ rng;           // rng[n - rng_base]
     uint64_t rng_base;
-    uint32_t *out;               // [n_jobs, L + 2]
+    uint32_t *out;                            // [n_jobs, L + 2]
     unsigned long long *job_counter;
-    unsigned long long *stats;   // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
+    unsigned long long *stats;  // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int MASK_WORDS = 1024;                 // per wave: 32768 neighbours of `cur` per segment
+#ifndef PW_MASK_WORDS
+#define PW_MASK_WORDS 512
+#endif
+constexpr int MASK_WORDS = PW_MASK_WORDS;        // per wave: 32*MASK_WORDS neighbours per segment
 constexpr uint32_t SEG = MASK_WORDS * 32;
-constexpr int EPL = 4;                           // elements per lane per scan pass
+constexpr int EPL = 4;                           // elements per lane per generic scan pass
 constexpr uint32_t NOT_FOUND = 0xffffffffu;
+#ifndef PW_MLP
+#define PW_MLP 4
+#endif
+constexpr int MLP = PW_MLP;                      // independent probe chains per lane
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __longlong_as_double((long long)readfirst_u64((uint64_t)__double_as_longlong(v)));
+}
 
 // ---- lower_bound over a sorted global row; every lane searches its own key --------------------
+// Branch-free form with a wave-uniform trip count (n only depends on the row length).
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ base, uint32_t n,
                                                     uint32_t key) {
+    if (n == 0) return 0;
     uint32_t lo = 0, len = n;
-    while (len > 0) {  // n is wave-uniform, so the trip count is too
+    while (len > 1) {
         uint32_t half = len >> 1;
-        uint32_t mid = lo + half;
-        uint32_t v = base[mid];
-        if (v < key) { lo = mid + 1; len -= half + 1; }
-        else len = half;
+        lo = (base[lo + half - 1] < key) ? lo + half : lo;
+        len -= half;
     }
-    return lo;
+    return lo + ((base[lo] < key) ? 1u : 0u);
+}
+
+// NJ independent searches per lane, advanced in lockstep: the probe chain of one search is a
+// string of dependent L2/HBM loads, so several chains per lane are what hides the latency.
+template <int NJ>
+__device__ __forceinline__ void lower_bound_multi(const uint32_t *__restrict__ base, uint32_t n,
+                                                  const uint32_t (&key)[MLP], uint32_t (&lo)[MLP]) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) lo[j] = 0;
+    if (n == 0) return;
+    uint32_t len = n;
+    while (len > 1) {
+        uint32_t half = len >> 1;
+        uint32_t v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) v[j] = base[lo[j] + half - 1];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) lo[j] = (v[j] < key[j]) ? lo[j] + half : lo[j];
+        len -= half;
+    }
+    uint32_t v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) v[j] = base[lo[j]];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) lo[j] += (v[j] < key[j]) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict__ base, uint32_t n,
+                                                     const uint32_t (&key)[MLP], uint32_t (&lo)[MLP],
+                                                     uint32_t nj) {
+    if (MLP >= 4 && nj > 2) lower_bound_multi<MLP>(base, n, key, lo);
+    else if (MLP >= 2 && nj > 1) lower_bound_multi<(MLP >= 2 ? 2 : 1)>(base, n, key, lo);
+    else lower_bound_multi<1>(base, n, key, lo);
 }
 
 // ---- step 1: membership bitmask of one segment [a, a+len) of cur's row ---------------------------
 // mask bit (k - a) = 1  <=>  indices[s0 + k] is a neighbour of prev.   Returns (wave-uniform) the
 // position of `prev` itself inside the segment, or NOT_FOUND.
-__device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, uint32_t s0,
-                                               uint32_t a, uint32_t len, uint32_t t0, uint32_t dp,
-                                               uint32_t prev) {
+__device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indices, uint32_t *mask,
+                                               uint32_t s0, uint32_t a, uint32_t len, uint32_t t0,
+                                               uint32_t dp, uint32_t prev) {
     const int lane = lane_id();
-    const uint32_t *crow = g.indices + s0 + a;
-    const uint32_t *prow = g.indices + t0;
+    const uint32_t *__restrict__ crow = indices + s0 + a;
+    const uint32_t *__restrict__ prow = indices + t0;
     uint32_t prev_pos = NOT_FOUND;
     const uint32_t nwords = (len + 31) >> 5;
     if (dp <= len) {
         // scatter: every neighbour of prev (plus prev itself) looks itself up in cur's segment
         for (uint32_t w = lane; w < nwords; w += WAVE) mask[w] = 0;
         wave_lds_fence();
-        for (uint32_t base = 0; base <= dp; base += WAVE) {
-            uint32_t i = base + lane;
-            bool valid = i <= dp;
-            uint32_t y = (i < dp) ? prow[i] : prev;
-            uint32_t pos = lower_bound_u32(crow, len, y);
-            bool found = valid && pos < len && crow[pos < len ? pos : 0] == y;
-            if (found && i < dp) atomicOr(&mask[pos >> 5], 1u << (pos & 31));
-            uint64_t pb = ballot(found && i == dp);
-            if (pb) prev_pos = a + readlane_u32(pos, __builtin_ctzll(pb));
+        for (uint32_t base = 0; base <= dp; base += WAVE * MLP) {
+            const uint32_t nj = (dp + 1 - base + WAVE - 1) / WAVE;  // live chains (uniform)
+            uint32_t key[MLP], pos[MLP];
+#pragma unroll
+            for (int j = 0; j < MLP; j++) {
+                uint32_t i = base + (uint32_t)j * WAVE + lane;
+                key[j] = ((uint32_t)j < nj && i < dp) ? prow[i] : prev;
+            }
+            lower_bound_dispatch(crow, len, key, pos, nj);
+#pragma unroll
+            for (int j = 0; j < MLP; j++) {
+                if ((uint32_t)j < nj) {
+                    uint32_t i = base + (uint32_t)j * WAVE + lane;
+                    bool found = i <= dp && pos[j] < len && crow[pos[j] < len ? pos[j] : 0] == key[j];
+                    if (found && i < dp) atomicOr(&mask[pos[j] >> 5], 1u << (pos[j] & 31));
+                    uint64_t pb = ballot(found && i == dp);
+                    if (pb) prev_pos = a + readlane_u32(pos[j], __builtin_ctzll(pb));
+                }
+            }
         }
     } else {
         // gather: every neighbour of cur in the segment looks itself up in prev's row
-        for (uint32_t base = 0; base < len; base += WAVE) {
-            uint32_t k = base + lane;
-            bool valid = k < len;
-            uint32_t x = valid ? crow[k] : 0u;
-            uint32_t pos = lower_bound_u32(prow, dp, x);
-            bool found = valid && pos < dp && prow[pos < dp ? pos : 0] == x;
-            uint64_t fb = ballot(found);
-            if (lane == 0) mask[base >> 5] = (uint32_t)fb;
-            if (lane == 32) mask[(base >> 5) + 1] = (uint32_t)(fb >> 32);
-            uint64_t pb = ballot(valid && x == prev);
-            if (pb) prev_pos = a + base + __builtin_ctzll(pb);
+        for (uint32_t base = 0; base < len; base += WAVE * MLP) {
+            const uint32_t nj = (len - base + WAVE - 1) / WAVE;
+            uint32_t key[MLP], pos[MLP];
+#pragma unroll
+            for (int j = 0; j < MLP; j++) {
+                uint32_t k = base + (uint32_t)j * WAVE + lane;
+                key[j] = ((uint32_t)j < nj && k < len) ? crow[k] : 0u;
+            }
+            lower_bound_dispatch(prow, dp, key, pos, nj);
+#pragma unroll
+            for (int j = 0; j < MLP; j++) {
+                if ((uint32_t)j < nj) {
+                    uint32_t kb = base + (uint32_t)j * WAVE;
+                    uint32_t k = kb + lane;
+                    bool valid = k < len;
+                    bool found = valid && pos[j] < dp && prow[pos[j] < dp ? pos[j] : 0] == key[j];
+                    uint64_t fb = ballot(found);
+                    if (lane == 0) mask[kb >> 5] = (uint32_t)fb;
+                    if (lane == 32) mask[(kb >> 5) + 1] = (uint32_t)(fb >> 32);
+                    uint64_t pb = ballot(valid && key[j] == prev);
+                    if (pb) prev_pos = a + kb + __builtin_ctzll(pb);
+                }
+            }
         }
     }
     wave_lds_fence();
@@ -115,11 +187,11 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
 //   w_k = data[k]; out edges: fl32(f64(w)/q); return edge: fl32(f64(w)/p)  (sparse_rw.py:84-87)
 //   normalised: fl32(w_k / tot)                                             (sparse_rw.py:89)
 template <bool UNIT> struct RowVals {
-    const float *drow;     // data + s0 (unused when UNIT)
-    const uint32_t *mask;  // LDS bitmask of the current segment
-    uint32_t seg_a;        // first neighbour index covered by mask
-    uint32_t prev_pos;     // NOT_FOUND when prev is not a neighbour of cur
-    uint32_t kend;         // neighbours >= kend contribute 0
+    const float *__restrict__ drow;  // data + s0 (unused when UNIT)
+    const uint32_t *mask;            // LDS bitmask of the current segment
+    uint32_t seg_a;                  // first neighbour index covered by mask
+    uint32_t prev_pos;               // NOT_FOUND when prev is not a neighbour of cur
+    uint32_t kend;                   // neighbours >= kend contribute 0
     bool has_prev;
     bool normalize;
     double p, q;
@@ -180,30 +252,22 @@ template <typename T> __device__ __forceinline__ Inc<T> wave_scan_inc(Inc<T> f) 
     return f;
 }
 
-// Continues the running sum `c` over elements [kbeg, kend) of `vals`.
-//   HAS_TARGET: returns the first k with (double)c_k >= r, or NOT_FOUND; c is updated either way.
-// head: number of leading elements to add one by one (cheap while the sum doubles every few
-// elements and would otherwise leave its binade on almost every pass).
+// One binade of the running sum: processes elements from k on while `c` stays in its binade.
+//   returns SCAN_END     : reached kend (k == kend, c updated)
+//           SCAN_CROSSED : c left the binade at element k-1 (added with a real floating-point add)
+//           SCAN_FOUND   : element `found` is the first with (double)c_k >= r   (HAS_TARGET only)
+enum { SCAN_END = 0, SCAN_CROSSED = 1, SCAN_FOUND = 2 };
+
 template <typename T, bool HAS_TARGET, typename Vals>
-__device__ __forceinline__ uint32_t seq_scan(T &c, uint32_t kbeg, uint32_t kend, double r,
-                                             const Vals &vals, uint32_t head) {
+__device__ __forceinline__ int seq_scan_binade(T &c, uint32_t &k, uint32_t kend, double r,
+                                               const Vals &vals, uint32_t &found) {
     using B = Binade<T>;
     using U = typename B::UInt;
     const int lane = lane_id();
-    uint32_t k = kbeg;
-    if (head) {
-        uint32_t n = kend - kbeg < head ? kend - kbeg : head;
-        T v = (lane < (int)n) ? (T)vals.one(kbeg + lane) : (T)0;
-        for (uint32_t j = 0; j < n; j++) {
-            c = c + readlane_fp<T>(v, (int)j);
-            if (HAS_TARGET && (double)c >= r) return kbeg + j;
-        }
-        k += n;
-    }
+    const int eb = B::eb_of(c);
+    const U Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
     while (k < kend) {
-        const int eb = B::eb_of(c);
         const U C = B::sig_of(c);
-        const U Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
         const uint32_t kb = k & ~(uint32_t)(EPL - 1);
         const uint32_t kl = kb + (uint32_t)lane * EPL;
         T xs[EPL];
@@ -243,27 +307,278 @@ __device__ __forceinline__ uint32_t seq_scan(T &c, uint32_t kbeg, uint32_t kend,
             }
         }
         const uint32_t kf = kb + (uint32_t)fl * EPL + (uint32_t)ef;
-        if (Cn < B::TOP) { c = B::make(Cn, eb); return kf; }  // only reachable with a target
-        // the sum leaves the binade at element kf: one real floating-point add, then rescan
+        if (Cn < B::TOP) { c = B::make(Cn, eb); found = kf; return SCAN_FOUND; }  // target reached
+        // the sum leaves the binade at element kf: one real floating-point add
         c = B::make(Cprev, eb) + xf;
-        if (HAS_TARGET && (double)c >= r) return kf;
         k = kf + 1;
+        if (HAS_TARGET && (double)c >= r) { found = kf; return SCAN_FOUND; }
+        return SCAN_CROSSED;
+    }
+    if (k > kend) k = kend;
+    return SCAN_END;
+}
+
+// Leading elements added one by one (cheap while the sum doubles every few elements and would
+// otherwise leave its binade on almost every pass).  Returns true when the target was reached.
+// The adds run without per-element target checks first (the sum is monotone: if the last partial
+// sum is below r no element reached it); only a head that contains the target is replayed.
+template <typename T, bool HAS_TARGET, typename Vals>
+__device__ __forceinline__ bool seq_head(T &c, uint32_t &k, uint32_t kend, double r, const Vals &vals,
+                                         uint32_t head, uint32_t &found) {
+    const int lane = lane_id();
+    uint32_t n = kend - k < head ? kend - k : head;
+    T v = (lane < (int)n) ? (T)vals.one(k + lane) : (T)0;
+    T cc = c;
+    for (uint32_t j = 0; j < n; j++) cc = cc + readlane_fp<T>(v, (int)j);
+    if (!HAS_TARGET || (double)cc < r) {
+        c = cc;
+        k += n;
+        return false;
+    }
+    for (uint32_t j = 0; j < n; j++) {
+        c = c + readlane_fp<T>(v, (int)j);
+        if ((double)c >= r) { found = k + j; return true; }
+    }
+    k += n;  // unreachable: cc >= r guarantees a hit above
+    return false;
+}
+
+// Continues the running sum `c` over elements [kbeg, kend) of `vals`.
+//   HAS_TARGET: returns the first k with (double)c_k >= r, or NOT_FOUND; c is updated either way.
+template <typename T, bool HAS_TARGET, typename Vals>
+__device__ __forceinline__ uint32_t seq_scan(T &c, uint32_t kbeg, uint32_t kend, double r,
+                                             const Vals &vals, uint32_t head) {
+    uint32_t k = kbeg, found = NOT_FOUND;
+    if (head && seq_head<T, HAS_TARGET>(c, k, kend, r, vals, head, found)) return found;
+    while (k < kend) {
+        int rc = seq_scan_binade<T, HAS_TARGET>(c, k, kend, r, vals, found);
+        if (rc == SCAN_FOUND) return found;
     }
     return NOT_FOUND;
 }
 
-// ---- one transition --------------------------------------------------------------------------------
-// Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
-template <bool UNIT>
-__device__ __forceinline__ uint32_t sample_step(const WalkArgs &a, uint32_t *mask, uint32_t cur,
-                                                bool has_prev, uint32_t prev, double r,
-                                                uint32_t s0, uint32_t d) {
-    const CsrDev &g = a.g;
-    uint32_t t0 = 0, dp = 0;
-    if (has_prev) { t0 = g.indptr[prev]; dp = g.indptr[prev + 1] - t0; }
+// ---- unit-weight fast path: run-length closed form of the same chain -------------------------------
+// On an unweighted graph every neighbour of `cur` carries one of three values (common neighbour of
+// prev: 1, other: 1/q, prev itself: 1/p; after normalisation x_in, x_out, x_prev).  Inside one binade
+// adding a fixed value is adding a fixed integer number of ulps (seqscan.h), so the partial sum
+// after element k is   C0 + n_in(k)*inc_in + n_out(k)*inc_out + n_prev(k)*inc_prev   with the
+// class counts read from the membership bitmask (rank = prefix popcount).  The first element
+// reaching the target / the binade top is found with a 64-ary search over k (one probe per lane),
+// i.e. O(log64 d) per binade instead of touching all d elements.  Exact ties (round-half-even,
+// parity dependent) fall back to the generic element scan for that binade.
+struct UnitRow {
+    const uint32_t *mask;   // LDS: bit (k - seg_a) set <=> common neighbour (prev's own bit cleared)
+    const uint16_t *rank;   // LDS: rank[w] = popcount(mask[0..w))
+    uint32_t seg_a, seg_len;
+    uint32_t prev_pos;      // global position of prev in cur's row, or NOT_FOUND
+    bool has_prev;
+    // number of common neighbours among segment elements [seg_a, k), seg_a <= k <= seg_a + seg_len
+    __device__ __forceinline__ uint32_t rank_at(uint32_t k) const {
+        if (!has_prev) return 0;
+        uint32_t r = k - seg_a, w = r >> 5, b = r & 31;
+        uint32_t base = rank[w];
+        return b ? base + (uint32_t)__popc(mask[w] & ((1u << b) - 1u)) : base;
+    }
+    __device__ __forceinline__ uint32_t bit_at(uint32_t k) const {
+        if (!has_prev) return 0;
+        uint32_t r = k - seg_a;
+        return (mask[r >> 5] >> (r & 31)) & 1u;
+    }
+};
 
-    RowVals<UNIT> rv;
-    rv.drow = UNIT ? nullptr : g.data + s0;
+__device__ __forceinline__ void build_rank(const uint32_t *mask, uint16_t *rank, uint32_t nwords) {
+    const int lane = lane_id();
+    const uint32_t per = (nwords + WAVE - 1) / WAVE;
+    const uint32_t w0 = (uint32_t)lane * per;
+    uint32_t local = 0;
+    for (uint32_t i = 0; i < per; i++) {
+        uint32_t w = w0 + i;
+        if (w < nwords) local += (uint32_t)__popc(mask[w]);
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        uint32_t t = shfl_up_uint<uint32_t>(incl, off);
+        if (lane >= off) incl += t;
+    }
+    uint32_t run = incl - local;
+    for (uint32_t i = 0; i < per; i++) {
+        uint32_t w = w0 + i;
+        if (w < nwords) {
+            rank[w] = (uint16_t)run;
+            run += (uint32_t)__popc(mask[w]);
+        }
+    }
+    if (lane == WAVE - 1) rank[nwords] = (uint16_t)incl;
+    wave_lds_fence();
+}
+
+template <bool HAS_TARGET>
+__device__ __forceinline__ int unit_chain(float &c, uint32_t &k, uint32_t kend, double r,
+                                          const UnitRow &ur, const RowVals<true> &rv, float x_in,
+                                          float x_out, float x_prev, uint32_t &found) {
+    using B = Binade<float>;
+    const int lane = lane_id();
+    while (k < kend) {
+        const int eb = B::eb_of(c);
+        const uint32_t C = B::sig_of(c);
+        const uint32_t Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
+        const Inc<float> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb), qp = B::quantize(x_prev, eb);
+        const bool prev_in = ur.has_prev && ur.prev_pos != NOT_FOUND && ur.prev_pos >= k && ur.prev_pos < kend;
+        // ties are parity dependent: hand this binade to the generic element scan (rare)
+        if (qi.a0 != qi.a1 || qo.a0 != qo.a1 || (prev_in && qp.a0 != qp.a1)) {
+            int rc = seq_scan_binade<float, HAS_TARGET>(c, k, kend, r, rv, found);
+            if (rc == SCAN_FOUND) return SCAN_FOUND;
+            continue;
+        }
+        const uint64_t ii = qi.a0, io = qo.a0, ipv = qp.a0;
+        const uint32_t rk0 = ur.rank_at(k);
+        uint32_t lo = k, hi = kend - 1, kf = 0;
+        uint64_t Cf = 0;
+        bool crossed = true;
+        for (;;) {
+            const uint32_t n = hi - lo + 1;
+            const uint32_t step = (n + WAVE - 1) / WAVE;
+            uint64_t kp64 = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+            const uint32_t kp = kp64 > hi ? hi : (uint32_t)kp64;
+            const uint32_t cin = ur.rank_at(kp + 1) - rk0;
+            const uint32_t cpv = (prev_in && ur.prev_pos <= kp) ? 1u : 0u;
+            const uint32_t cout = (kp + 1 - k) - cin - cpv;
+            const uint64_t G = (uint64_t)C + cin * ii + cout * io + cpv * ipv;
+            const uint64_t hitm = ballot(G >= Tt);
+            if (!hitm) {  // only possible in the first round: the whole range stays below Tt
+                Cf = readlane_u64(G, WAVE - 1);
+                crossed = false;
+                break;
+            }
+            const int first = __builtin_ctzll(hitm);
+            if (step == 1) { kf = lo + (uint32_t)first; Cf = readlane_u64(G, first); break; }
+            uint64_t nhi = (uint64_t)lo + (uint64_t)(first + 1) * step - 1;
+            lo = lo + (uint32_t)first * step;
+            if (nhi < hi) hi = (uint32_t)nhi;
+        }
+        if (!crossed) {
+            c = B::make((uint32_t)Cf, eb);
+            k = kend;
+            break;
+        }
+        const bool f_prev = prev_in && kf == ur.prev_pos;
+        const bool f_in = !f_prev && ur.bit_at(kf);
+        const uint64_t incf = f_prev ? ipv : (f_in ? ii : io);
+        const float xf = f_prev ? x_prev : (f_in ? x_in : x_out);
+        const uint32_t Cprev = (uint32_t)(Cf - incf);
+        if (Cf < B::TOP) { c = B::make((uint32_t)Cf, eb); found = kf; return SCAN_FOUND; }
+        c = B::make(Cprev, eb) + xf;
+        k = kf + 1;
+        if (HAS_TARGET && (double)c >= r) { found = kf; return SCAN_FOUND; }
+    }
+    return SCAN_END;
+}
+
+__device__ __forceinline__ bool is_pow2_f32(float x) { return (__float_as_uint(x) & 0x7fffffu) == 0u; }
+
+// Unit-weight transition: same result as sample_step<true>, closed-form chain.
+// (t0, dp) = CSR row of prev, carried over from the previous step by the caller.
+__device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t *mask, uint16_t *rank,
+                                                     bool has_prev, uint32_t prev, uint32_t t0,
+                                                     uint32_t dp, double r, uint32_t s0, uint32_t d) {
+    const uint32_t *__restrict__ indices = a.g.indices;
+    const int lane = lane_id();
+    const float w_in = 1.0f, w_out = has_prev ? (float)(1.0 / a.q) : 1.0f, w_prev = (float)(1.0 / a.p);
+
+    RowVals<true> rv;  // used by the head and the tie fallback
+    rv.drow = nullptr;
+    rv.mask = mask;
+    rv.has_prev = has_prev;
+    rv.p = a.p;
+    rv.q = a.q;
+    rv.prev_pos = NOT_FOUND;
+    UnitRow ur;
+    ur.mask = mask;
+    ur.rank = rank;
+    ur.has_prev = has_prev;
+    ur.prev_pos = NOT_FOUND;
+
+    const bool multi = has_prev && d > SEG;
+    if (multi) {
+        uint32_t pos = uni(lower_bound_u32(indices + s0, d, prev));
+        if (pos < d && uni(indices[s0 + pos]) == prev) ur.prev_pos = pos;
+    }
+    auto prepare_segment = [&](uint32_t sa, uint32_t len) {
+        if (has_prev) {
+            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
+            if (!multi) ur.prev_pos = pp;
+            if (ur.prev_pos != NOT_FOUND && ur.prev_pos >= sa && ur.prev_pos < sa + len) {
+                uint32_t rr = ur.prev_pos - sa;  // keep the three classes disjoint
+                if (lane == 0) mask[rr >> 5] &= ~(1u << (rr & 31));
+                wave_lds_fence();
+            }
+            build_rank(mask, rank, (len + 31) >> 5);
+        }
+        ur.seg_a = sa;
+        ur.seg_len = len;
+        rv.prev_pos = ur.prev_pos;
+        rv.seg_a = sa;
+        rv.kend = sa + len;
+    };
+
+    // ---- tot = sequential float32 sum of the biased weights ------------------------------------
+    float tot = 0.0f;
+    bool have_tot = false;
+    if (!multi) {
+        prepare_segment(0, d);
+        // all partial sums are exact when the weights are dyadic and the total fits 24 bits of
+        // the smallest weight: then the left-to-right float32 sum equals the exact sum.
+        const uint32_t n_in = has_prev ? ur.rank_at(d) : 0u;
+        const uint32_t n_pv = (has_prev && ur.prev_pos != NOT_FOUND) ? 1u : 0u;
+        const uint32_t n_out = d - n_in - n_pv;
+        if ((n_out == 0 || is_pow2_f32(w_out)) && (n_pv == 0 || is_pow2_f32(w_prev))) {
+            float u = 1.0f;
+            if (n_out && w_out < u) u = w_out;
+            if (n_pv && w_prev < u) u = w_prev;
+            double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
+            if (td / (double)u <= 16777216.0) { tot = (float)td; have_tot = true; }
+        }
+    }
+    if (!have_tot) {
+        rv.normalize = false;
+        rv.tot = 1.0f;
+        rv.setup_unit();
+        if (!has_prev) rv.u_out = rv.u_in;
+        for (uint32_t sa = 0; sa < d; sa += SEG) {
+            uint32_t len = d - sa < SEG ? d - sa : SEG;
+            if (multi) prepare_segment(sa, len);
+            uint32_t k = sa, found = NOT_FOUND;
+            if (sa == 0) (void)seq_head<float, false>(tot, k, sa + len, 0.0, rv, WAVE, found);
+            (void)unit_chain<false>(tot, k, sa + len, 0.0, ur, rv, w_in, w_out, w_prev, found);
+        }
+    }
+
+    // ---- cdf search ----------------------------------------------------------------------------------
+    rv.normalize = true;
+    rv.tot = tot;
+    rv.setup_unit();
+    if (!has_prev) rv.u_out = rv.u_in;
+    const float x_in = w_in / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    float c = 0.0f;
+    for (uint32_t sa = 0; sa < d; sa += SEG) {
+        uint32_t len = d - sa < SEG ? d - sa : SEG;
+        if (multi) prepare_segment(sa, len);  // single segment: mask and rank are still valid
+        uint32_t k = sa, found = NOT_FOUND;
+        if (sa == 0 && seq_head<float, true>(c, k, sa + len, r, rv, WAVE, found)) return found;
+        if (unit_chain<true>(c, k, sa + len, r, ur, rv, x_in, x_out, x_prev, found) == SCAN_FOUND) return found;
+    }
+    return d;
+}
+
+// ---- general (weighted) transition -------------------------------------------------------------------
+// Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
+__device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, bool has_prev,
+                                                         uint32_t prev, uint32_t t0, uint32_t dp,
+                                                         double r, uint32_t s0, uint32_t d) {
+    const uint32_t *__restrict__ indices = a.g.indices;
+    RowVals<false> rv;
+    rv.drow = a.g.data + s0;
     rv.mask = mask;
     rv.has_prev = has_prev;
     rv.p = a.p;
@@ -274,19 +589,17 @@ __device__ __forceinline__ uint32_t sample_step(const WalkArgs &a, uint32_t *mas
     const bool multi = has_prev && d > SEG;
     // prev's position is needed by every segment: find it once when the row is segmented
     if (multi) {
-        uint32_t pos = lower_bound_u32(g.indices + s0, d, prev);
-        pos = readfirst_u32(pos);
-        if (pos < d && g.indices[s0 + pos] == prev) rv.prev_pos = pos;
+        uint32_t pos = uni(lower_bound_u32(indices + s0, d, prev));
+        if (pos < d && uni(indices[s0 + pos]) == prev) rv.prev_pos = pos;
     }
 
     // pass 1: tot
     float tot = 0.0f;
     rv.normalize = false;
-    if (UNIT) rv.setup_unit();
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
         if (has_prev) {
-            uint32_t pp = build_mask(g, mask, s0, sa, len, t0, dp, prev);
+            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
             if (!multi) rv.prev_pos = pp;
         }
         rv.seg_a = sa;
@@ -297,12 +610,11 @@ __device__ __forceinline__ uint32_t sample_step(const WalkArgs &a, uint32_t *mas
     // pass 2: cdf search
     rv.normalize = true;
     rv.tot = tot;
-    if (UNIT) rv.setup_unit();
     float c = 0.0f;
     uint32_t choice = NOT_FOUND;
     for (uint32_t sa = 0; sa < d && choice == NOT_FOUND; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (multi) (void)build_mask(g, mask, s0, sa, len, t0, dp, prev);  // single segment: still valid
+        if (multi) (void)build_mask(indices, mask, s0, sa, len, t0, dp, prev);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
         choice = seq_scan<float, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
@@ -310,17 +622,25 @@ __device__ __forceinline__ uint32_t sample_step(const WalkArgs &a, uint32_t *mas
     return choice == NOT_FOUND ? d : choice;
 }
 
+#ifndef PW_MIN_WAVES
+#define PW_MIN_WAVES 8
+#endif
+
 template <bool UNIT>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
 walk_sparse_kernel(WalkArgs a) {
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
+    __shared__ uint16_t s_rank[UNIT ? WAVES_PER_BLOCK : 1][UNIT ? MASK_WORDS + 2 : 2];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     uint32_t *mask = s_mask[wave];
-    const CsrDev &g = a.g;
+    uint16_t *rank = s_rank[UNIT ? wave : 0];
+    const uint32_t *__restrict__ indptr = a.g.indptr;
+    const uint32_t *__restrict__ indices = a.g.indices;
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
+    const uint32_t nnz = a.g.nnz;
 
     unsigned long long st_steps = 0, st_over = 0, st_clamp = 0, st_dead = 0;
 
@@ -329,29 +649,42 @@ walk_sparse_kernel(WalkArgs a) {
         if (lane == 0) widx = atomicAdd(a.job_counter, 1ull);
         widx = readfirst_u64(widx);
         if (widx >= n_work) break;
-        const uint64_t job = a.job_list ? (uint64_t)a.job_list[widx] : (uint64_t)widx;
+        const uint64_t job = a.job_list ? (uint64_t)uni(a.job_list[widx]) : (uint64_t)widx;
         uint32_t *row = a.out + job * W;
-        const uint32_t start = a.starts[job];
-        const uint64_t soff = a.stream_off[job] - a.rng_base;
+        const uint32_t start = uni(a.starts[job]);
+        const uint64_t soff = readfirst_u64(a.stream_off[job]) - a.rng_base;
 
         uint32_t cur = start, prev = 0;
+        uint32_t s0 = uni(indptr[cur]);
+        uint32_t d = uni(indptr[cur + 1]) - s0;
+        uint32_t t0 = 0, dp = 0;  // row of prev (= row of cur one step earlier)
         uint32_t len_out = L + 1;
+        double rbuf = 0.0;        // lane l holds the draw of step (64 * block + l)
         uint32_t j = 1;
         for (; j <= L; j++) {
-            const uint32_t s0 = g.indptr[cur];
-            const uint32_t d = g.indptr[cur + 1] - s0;
             if (d == 0) { len_out = j; if (j > 1) st_dead++; break; }
-            const double r = a.rng[soff + (j - 1)];
-            const uint32_t choice = sample_step<UNIT>(a, mask, cur, j >= 2, prev, r, s0, d);
+            const uint32_t jr = (j - 1) & (WAVE - 1);
+            if (jr == 0) {
+                uint32_t idx = (j - 1) + (uint32_t)lane;
+                rbuf = idx < L ? a.rng[soff + idx] : 0.0;
+            }
+            const double r = readlane_f64(rbuf, (int)jr);
+            uint32_t choice;
+            if (UNIT) choice = sample_step_unit(a, mask, rank, j >= 2, prev, t0, dp, r, s0, d);
+            else choice = sample_step_weighted(a, mask, j >= 2, prev, t0, dp, r, s0, d);
             uint64_t pos = (uint64_t)s0 + choice;
             if (choice >= d) {
                 st_over++;
-                if (pos >= g.nnz) { pos = g.nnz - 1; st_clamp++; }
+                if (pos >= nnz) { pos = nnz - 1; st_clamp++; }
             }
-            const uint32_t nxt = g.indices[pos];
+            const uint32_t nxt = uni(indices[pos]);
             if (lane == 0) row[j] = nxt;
             prev = cur;
+            t0 = s0;
+            dp = d;
             cur = nxt;
+            s0 = uni(indptr[cur]);
+            d = uni(indptr[cur + 1]) - s0;
             st_steps++;
         }
         // header, tail zeros and length cell (cells j..L stay 0 after an early stop)
