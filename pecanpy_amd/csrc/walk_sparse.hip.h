@@ -206,8 +206,9 @@ template <bool UNIT> struct RowVals {
 
     __device__ __forceinline__ float value(uint32_t k, uint32_t bit) const {
         if (UNIT) {
-            if (!has_prev) return u_in;
-            return k == prev_pos ? u_prev : (bit ? u_in : u_out);
+            const float vi = u_in, vo = u_out, vp = u_prev;
+            float v = bit ? vi : vo;
+            return (has_prev && k == prev_pos) ? vp : v;
         } else {
             float w = drow[k];
             if (has_prev) {
@@ -477,60 +478,70 @@ __device__ __forceinline__ int unit_chain(float &c, uint32_t &k, uint32_t kend, 
 
 __device__ __forceinline__ bool is_pow2_f32(float x) { return (__float_as_uint(x) & 0x7fffffu) == 0u; }
 
-// Unit-weight transition: same result as sample_step<true>, closed-form chain.
+// Membership structures (mask + rank) of one segment; returns prev's position (global) or
+// NOT_FOUND.  known_prev_pos: position found by the caller for segmented rows (else NOT_FOUND).
+__device__ __forceinline__ uint32_t prepare_unit_segment(const uint32_t *__restrict__ indices, uint32_t *mask,
+                                                         uint16_t *rank, uint32_t s0, uint32_t sa,
+                                                         uint32_t len, uint32_t t0, uint32_t dp,
+                                                         uint32_t prev, bool multi, uint32_t known_prev_pos) {
+    uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
+    if (multi) pp = known_prev_pos;
+    if (pp != NOT_FOUND && pp >= sa && pp < sa + len) {
+        uint32_t rr = pp - sa;  // keep the three classes disjoint
+        if (lane_id() == 0) mask[rr >> 5] &= ~(1u << (rr & 31));
+        wave_lds_fence();
+    }
+    build_rank(mask, rank, (len + 31) >> 5);
+    return pp;
+}
+
+// Value view of one segment for the head / tie fallback.  Built fresh (never mutated) so that it
+// stays in registers: a struct that lives in scratch turns every value() into a scratch load.
+__device__ __forceinline__ RowVals<true> make_unit_vals(const uint32_t *mask, uint32_t sa, uint32_t kend,
+                                                         uint32_t prev_pos, bool has_prev, float v_in,
+                                                         float v_out, float v_prev) {
+    RowVals<true> rv;
+    rv.drow = nullptr;
+    rv.mask = mask;
+    rv.seg_a = sa;
+    rv.prev_pos = prev_pos;
+    rv.kend = kend;
+    rv.has_prev = has_prev;
+    rv.normalize = false;
+    rv.p = 1.0;
+    rv.q = 1.0;
+    rv.tot = 1.0f;
+    rv.u_in = v_in;
+    rv.u_out = has_prev ? v_out : v_in;
+    rv.u_prev = v_prev;
+    return rv;
+}
+
+// Unit-weight transition: same result as the generic path, closed-form chain.
 // (t0, dp) = CSR row of prev, carried over from the previous step by the caller.
 __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t *mask, uint16_t *rank,
                                                      bool has_prev, uint32_t prev, uint32_t t0,
                                                      uint32_t dp, double r, uint32_t s0, uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
-    const int lane = lane_id();
     const float w_in = 1.0f, w_out = has_prev ? (float)(1.0 / a.q) : 1.0f, w_prev = (float)(1.0 / a.p);
 
-    RowVals<true> rv;  // used by the head and the tie fallback
-    rv.drow = nullptr;
-    rv.mask = mask;
-    rv.has_prev = has_prev;
-    rv.p = a.p;
-    rv.q = a.q;
-    rv.prev_pos = NOT_FOUND;
-    UnitRow ur;
-    ur.mask = mask;
-    ur.rank = rank;
-    ur.has_prev = has_prev;
-    ur.prev_pos = NOT_FOUND;
-
     const bool multi = has_prev && d > SEG;
+    uint32_t prev_pos = NOT_FOUND;
     if (multi) {
         uint32_t pos = uni(lower_bound_u32(indices + s0, d, prev));
-        if (pos < d && uni(indices[s0 + pos]) == prev) ur.prev_pos = pos;
+        if (pos < d && uni(indices[s0 + pos]) == prev) prev_pos = pos;
     }
-    auto prepare_segment = [&](uint32_t sa, uint32_t len) {
-        if (has_prev) {
-            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
-            if (!multi) ur.prev_pos = pp;
-            if (ur.prev_pos != NOT_FOUND && ur.prev_pos >= sa && ur.prev_pos < sa + len) {
-                uint32_t rr = ur.prev_pos - sa;  // keep the three classes disjoint
-                if (lane == 0) mask[rr >> 5] &= ~(1u << (rr & 31));
-                wave_lds_fence();
-            }
-            build_rank(mask, rank, (len + 31) >> 5);
-        }
-        ur.seg_a = sa;
-        ur.seg_len = len;
-        rv.prev_pos = ur.prev_pos;
-        rv.seg_a = sa;
-        rv.kend = sa + len;
-    };
 
     // ---- tot = sequential float32 sum of the biased weights ------------------------------------
     float tot = 0.0f;
     bool have_tot = false;
     if (!multi) {
-        prepare_segment(0, d);
+        if (has_prev) prev_pos = prepare_unit_segment(indices, mask, rank, s0, 0, d, t0, dp, prev, false, NOT_FOUND);
+        const UnitRow ur{mask, rank, 0u, d, prev_pos, has_prev};
         // all partial sums are exact when the weights are dyadic and the total fits 24 bits of
         // the smallest weight: then the left-to-right float32 sum equals the exact sum.
         const uint32_t n_in = has_prev ? ur.rank_at(d) : 0u;
-        const uint32_t n_pv = (has_prev && ur.prev_pos != NOT_FOUND) ? 1u : 0u;
+        const uint32_t n_pv = (has_prev && prev_pos != NOT_FOUND) ? 1u : 0u;
         const uint32_t n_out = d - n_in - n_pv;
         if ((n_out == 0 || is_pow2_f32(w_out)) && (n_pv == 0 || is_pow2_f32(w_prev))) {
             float u = 1.0f;
@@ -541,13 +552,11 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
         }
     }
     if (!have_tot) {
-        rv.normalize = false;
-        rv.tot = 1.0f;
-        rv.setup_unit();
-        if (!has_prev) rv.u_out = rv.u_in;
         for (uint32_t sa = 0; sa < d; sa += SEG) {
-            uint32_t len = d - sa < SEG ? d - sa : SEG;
-            if (multi) prepare_segment(sa, len);
+            const uint32_t len = d - sa < SEG ? d - sa : SEG;
+            if (multi) (void)prepare_unit_segment(indices, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+            const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
+            const RowVals<true> rv = make_unit_vals(mask, sa, sa + len, prev_pos, has_prev, w_in, w_out, w_prev);
             uint32_t k = sa, found = NOT_FOUND;
             if (sa == 0) (void)seq_head<float, false>(tot, k, sa + len, 0.0, rv, WAVE, found);
             (void)unit_chain<false>(tot, k, sa + len, 0.0, ur, rv, w_in, w_out, w_prev, found);
@@ -555,15 +564,14 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
     }
 
     // ---- cdf search ----------------------------------------------------------------------------------
-    rv.normalize = true;
-    rv.tot = tot;
-    rv.setup_unit();
-    if (!has_prev) rv.u_out = rv.u_in;
     const float x_in = w_in / tot, x_out = w_out / tot, x_prev = w_prev / tot;
     float c = 0.0f;
     for (uint32_t sa = 0; sa < d; sa += SEG) {
-        uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (multi) prepare_segment(sa, len);  // single segment: mask and rank are still valid
+        const uint32_t len = d - sa < SEG ? d - sa : SEG;
+        // single segment: mask and rank from the tot phase are still valid
+        if (multi) (void)prepare_unit_segment(indices, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+        const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
+        const RowVals<true> rv = make_unit_vals(mask, sa, sa + len, prev_pos, has_prev, x_in, x_out, x_prev);
         uint32_t k = sa, found = NOT_FOUND;
         if (sa == 0 && seq_head<float, true>(c, k, sa + len, r, rv, WAVE, found)) return found;
         if (unit_chain<true>(c, k, sa + len, r, ur, rv, x_in, x_out, x_prev, found) == SCAN_FOUND) return found;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Turn a rocprofv3 rocpd sqlite result (--kernel-trace --stats) into a small text summary
-(per-kernel calls / total / average duration, plus PMC counters when present)."""
+"""Turn a rocprofv3 rocpd sqlite result into a small text summary: per-kernel calls / total /
+average duration (--kernel-trace --stats) and, when present, PMC counter sums per kernel (--pmc).
+usage: prof_summary.py results.db [out.txt]"""
 import sqlite3
 import sys
 
@@ -8,22 +9,29 @@ import sys
 def main(db, out=None):
     con = sqlite3.connect(db)
     cur = con.cursor()
-    lines = [f"# rocprofv3 kernel summary of {db}", "name | calls | total_ms | avg_ms | pct   (top_kernels view reports microseconds)"]
-    for name, calls, total, avg, pct in cur.execute(
-            "select name, total_calls, total_duration, average, percentage from top_kernels"):
-        lines.append(f"{name[:110]} | {calls} | {total / 1e3:.3f} | {avg / 1e3:.3f} | {pct:.2f}")
+    lines = [f"# rocprofv3 summary of {db}"]
     try:
         rows = list(cur.execute(
-            "select k.name, p.name, sum(e.value), count(*) from rocpd_pmc_event e "
-            "join rocpd_info_pmc p on e.pmc_id = p.id join kernels k on e.event_id = k.id "
-            "group by k.name, p.name"))
+            "select name, count(*), sum(end - start), avg(end - start) from kernels group by name "
+            "order by 3 desc limit 12"))
+        lines.append("kernel | calls | total_ms | avg_ms")
+        for name, calls, total, avg in rows:
+            lines.append(f"{name[:100]} | {calls} | {total / 1e6:.3f} | {avg / 1e6:.3f}")
+    except sqlite3.Error as e:
+        lines.append(f"# no kernel trace: {e}")
+    try:
+        rows = list(cur.execute(
+            "select name, counter_name, sum(counter_value), count(distinct dispatch_id) from pmc_events "
+            "group by name, counter_name order by name, counter_name"))
         if rows:
             lines.append("")
-            lines.append("kernel | counter | sum | dispatches")
+            lines.append("kernel | counter | sum over dispatches | dispatches")
             for k, c, v, n in rows:
-                lines.append(f"{k[:80]} | {c} | {v:.6g} | {n}")
-    except sqlite3.Error as e:  # no counters in this run
-        lines.append(f"# (no PMC data: {e})")
+                if "at::native" in k or "rocclr" in k:
+                    continue
+                lines.append(f"{k[:70]} | {c} | {v:.6g} | {n}")
+    except sqlite3.Error as e:
+        lines.append(f"# no PMC data: {e}")
     text = "\n".join(lines) + "\n"
     if out:
         with open(out, "w") as f:
