@@ -270,9 +270,11 @@ PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_
     return rc;
 }
 
-static int launch_walks(pw_graph *g, pw::WalkArgs &wa) {
+static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     int occ = 0;
-    const void *fn = g->unit ? (const void *)pw::walk_sparse_kernel<true> : (const void *)pw::walk_sparse_kernel<false>;
+    const void *fn = g->unit ? (const void *)pw::walk_sparse_kernel<true, false>
+                             : (extend ? (const void *)pw::walk_sparse_kernel<false, true>
+                                       : (const void *)pw::walk_sparse_kernel<false, false>);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
@@ -281,10 +283,13 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa) {
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    const dim3 blk(pw::WAVES_PER_BLOCK * pw::WAVE);
     if (g->unit)
-        hipLaunchKernelGGL(pw::walk_sparse_kernel<true>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+        hipLaunchKernelGGL((pw::walk_sparse_kernel<true, false>), dim3((unsigned)grid), blk, 0, g->stream, wa);
+    else if (extend)
+        hipLaunchKernelGGL((pw::walk_sparse_kernel<false, true>), dim3((unsigned)grid), blk, 0, g->stream, wa);
     else
-        hipLaunchKernelGGL(pw::walk_sparse_kernel<false>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+        hipLaunchKernelGGL((pw::walk_sparse_kernel<false, false>), dim3((unsigned)grid), blk, 0, g->stream, wa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -296,7 +301,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (!g || (n_jobs && (!d_starts || !d_out))) return fail(PW_ERR_INVALID, "null pointer");
     if (mode != PW_MODE_SPARSE_OTF) return fail(PW_ERR_UNSUPPORTED, "mode not implemented on the device yet");
     if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph");
-    if (extend) return fail(PW_ERR_UNSUPPORTED, "node2vec+ not implemented on the device yet");
+    if (extend && !g->unit && !g->d_thr)
+        return fail(PW_ERR_INVALID, "extend: call pw_graph_set_thresholds() first");
     if (!(p > 0) || !(q > 0)) return fail(PW_ERR_INVALID, "p and q must be positive");
     if (walk_length < 1) return fail(PW_ERR_INVALID, "walk_length must be >= 1");
     if (n_jobs >= 0xffffffffull) return fail(PW_ERR_INVALID, "n_jobs must fit uint32");
@@ -385,7 +391,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.job_counter = g->counters.p;
     wa.stats = g->counters.p + 1;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-    rc = launch_walks(g, wa);
+    rc = launch_walks(g, wa, extend != 0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->ev[3], g->stream));
     unsigned long long h[8];
@@ -414,7 +420,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         wa.job_list = g->changed.p;
         wa.n_list = n_changed;
         HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-        rc = launch_walks(g, wa);
+        rc = launch_walks(g, wa, extend != 0);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(g->ev[3], g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));

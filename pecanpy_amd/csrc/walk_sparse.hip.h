@@ -119,9 +119,13 @@ __device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict_
 // ---- step 1: membership bitmask of one segment [a, a+len) of cur's row ---------------------------
 // mask bit (k - a) = 1  <=>  indices[s0 + k] is a neighbour of prev.   Returns (wave-uniform) the
 // position of `prev` itself inside the segment, or NOT_FOUND.
+// node2vec+ (in_mask != nullptr): a second bitmask marks the common neighbours x whose edge
+// prev->x is not "noisy", w(prev, x) >= thr[x] (in-edges, isnotin_extended, sparse_rw.py:233-295).
 __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indices, uint32_t *mask,
                                                uint32_t s0, uint32_t a, uint32_t len, uint32_t t0,
-                                               uint32_t dp, uint32_t prev) {
+                                               uint32_t dp, uint32_t prev, uint32_t *in_mask = nullptr,
+                                               const float *__restrict__ data = nullptr,
+                                               const float *__restrict__ thr = nullptr) {
     const int lane = lane_id();
     const uint32_t *__restrict__ crow = indices + s0 + a;
     const uint32_t *__restrict__ prow = indices + t0;
@@ -129,7 +133,10 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
     const uint32_t nwords = (len + 31) >> 5;
     if (dp <= len) {
         // scatter: every neighbour of prev (plus prev itself) looks itself up in cur's segment
-        for (uint32_t w = lane; w < nwords; w += WAVE) mask[w] = 0;
+        for (uint32_t w = lane; w < nwords; w += WAVE) {
+            mask[w] = 0;
+            if (in_mask) in_mask[w] = 0;
+        }
         wave_lds_fence();
         for (uint32_t base = 0; base <= dp; base += WAVE * MLP) {
             const uint32_t nj = (dp + 1 - base + WAVE - 1) / WAVE;  // live chains (uniform)
@@ -145,7 +152,10 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
                 if ((uint32_t)j < nj) {
                     uint32_t i = base + (uint32_t)j * WAVE + lane;
                     bool found = i <= dp && pos[j] < len && crow[pos[j] < len ? pos[j] : 0] == key[j];
-                    if (found && i < dp) atomicOr(&mask[pos[j] >> 5], 1u << (pos[j] & 31));
+                    if (found && i < dp) {
+                        atomicOr(&mask[pos[j] >> 5], 1u << (pos[j] & 31));
+                        if (in_mask && data[t0 + i] >= thr[key[j]]) atomicOr(&in_mask[pos[j] >> 5], 1u << (pos[j] & 31));
+                    }
                     uint64_t pb = ballot(found && i == dp);
                     if (pb) prev_pos = a + readlane_u32(pos[j], __builtin_ctzll(pb));
                 }
@@ -172,6 +182,12 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
                     uint64_t fb = ballot(found);
                     if (lane == 0) mask[kb >> 5] = (uint32_t)fb;
                     if (lane == 32) mask[(kb >> 5) + 1] = (uint32_t)(fb >> 32);
+                    if (in_mask) {
+                        bool is_in = found && data[t0 + pos[j]] >= thr[key[j]];
+                        uint64_t ib = ballot(is_in);
+                        if (lane == 0) in_mask[kb >> 5] = (uint32_t)ib;
+                        if (lane == 32) in_mask[(kb >> 5) + 1] = (uint32_t)(ib >> 32);
+                    }
                     uint64_t pb = ballot(valid && key[j] == prev);
                     if (pb) prev_pos = a + kb + __builtin_ctzll(pb);
                 }
@@ -197,6 +213,15 @@ template <bool UNIT> struct RowVals {
     double p, q;
     float tot;
     float u_in, u_out, u_prev;  // UNIT: the three possible values (already normalised if asked)
+    // node2vec+ (extend): get_extended_normalized_probs, sparse_rw.py:93-130
+    bool extend = false;
+    const uint32_t *in_mask = nullptr;           // LDS: common neighbour that is an in-edge
+    const uint32_t *__restrict__ crow = nullptr; // indices + s0
+    const uint32_t *__restrict__ prow = nullptr; // indices + t0
+    const float *__restrict__ pdata = nullptr;   // data + t0
+    const float *__restrict__ thr = nullptr;
+    uint32_t dp = 0;
+    float thr_cur = 0.0f;
 
     __device__ __forceinline__ void setup_unit() {
         float w_in = 1.0f, w_out = (float)(1.0 / q), w_prev = (float)(1.0 / p);
@@ -211,7 +236,7 @@ template <bool UNIT> struct RowVals {
             return (has_prev && k == prev_pos) ? vp : v;
         } else {
             float w = drow[k];
-            if (has_prev) {
+            if (has_prev && !extend) {
                 if (k == prev_pos) w = (float)((double)w / p);
                 else if (!bit) w = (float)((double)w / q);
             }
@@ -219,8 +244,37 @@ template <bool UNIT> struct RowVals {
         }
     }
 
+    // node2vec+ value of element k (valid: k < kend).  Every lane runs the (uniform trip count)
+    // row search; only common neighbours that are out-edges need its result (t = w(prev,x)/thr[x]).
+    __device__ __forceinline__ float value_ext(uint32_t k, bool valid) const {
+        float w = valid ? drow[k] : 0.0f;
+        if (!has_prev) return (valid && normalize) ? w / tot : w;
+        uint32_t r = valid ? k - seg_a : 0u;
+        const bool common = valid && ((mask[r >> 5] >> (r & 31)) & 1u);
+        const bool is_in = valid && ((in_mask[r >> 5] >> (r & 31)) & 1u);
+        const bool need_t = common && !is_in && k != prev_pos;
+        float t = 0.0f;
+        if (ballot(need_t)) {
+            const uint32_t x = need_t ? crow[k] : 0u;
+            const uint32_t jpos = lower_bound_u32(prow, dp, x);
+            if (need_t) t = pdata[jpos] / thr[x];
+        }
+        if (valid) {
+            if (k == prev_pos) w = (float)((double)w / p);
+            else if (!(common && is_in)) {
+                const double inv_q = 1.0 / q;
+                double alpha = inv_q + (1.0 - inv_q) * (double)t;
+                if (w < thr_cur) alpha = inv_q < 1.0 ? inv_q : 1.0;
+                w = (float)((double)w * alpha);
+            }
+            if (normalize) w = w / tot;
+        }
+        return w;
+    }
+
     // one element (k < kend required)
     __device__ __forceinline__ float one(uint32_t k) const {
+        if (!UNIT && extend) return value_ext(k, k < kend);
         uint32_t bit = 0;
         if (has_prev) { uint32_t r = k - seg_a; bit = (mask[r >> 5] >> (r & 31)) & 1u; }
         return value(k, bit);
@@ -228,6 +282,11 @@ template <bool UNIT> struct RowVals {
 
     // EPL consecutive elements starting at kb (kb multiple of EPL); 0 beyond kend
     __device__ __forceinline__ void vec(uint32_t kb, float (&xs)[EPL]) const {
+        if (!UNIT && extend) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) xs[e] = value_ext(kb + e, kb + e < kend);
+            return;
+        }
         uint32_t bits = 0;
         if (has_prev && kb < kend) { uint32_t r = kb - seg_a; bits = mask[r >> 5] >> (r & 31); }
 #pragma unroll
@@ -581,11 +640,23 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
 
 // ---- general (weighted) transition -------------------------------------------------------------------
 // Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
-__device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, bool has_prev,
-                                                         uint32_t prev, uint32_t t0, uint32_t dp,
-                                                         double r, uint32_t s0, uint32_t d) {
+__device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, uint32_t *in_mask,
+                                                         uint32_t cur, bool has_prev, uint32_t prev,
+                                                         uint32_t t0, uint32_t dp, double r, uint32_t s0,
+                                                         uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
+    const bool extend = in_mask != nullptr;
     RowVals<false> rv;
+    rv.extend = extend;
+    if (extend) {
+        rv.in_mask = in_mask;
+        rv.crow = indices + s0;
+        rv.prow = indices + t0;
+        rv.pdata = a.g.data + t0;
+        rv.thr = a.g.thr;
+        rv.dp = dp;
+        rv.thr_cur = uni(a.g.thr[cur]);
+    }
     rv.drow = a.g.data + s0;
     rv.mask = mask;
     rv.has_prev = has_prev;
@@ -607,7 +678,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
         if (has_prev) {
-            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
+            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev, in_mask, a.g.data, a.g.thr);
             if (!multi) rv.prev_pos = pp;
         }
         rv.seg_a = sa;
@@ -622,7 +693,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     uint32_t choice = NOT_FOUND;
     for (uint32_t sa = 0; sa < d && choice == NOT_FOUND; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (multi) (void)build_mask(indices, mask, s0, sa, len, t0, dp, prev);  // single segment: still valid
+        if (multi) (void)build_mask(indices, mask, s0, sa, len, t0, dp, prev, in_mask, a.g.data, a.g.thr);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
         choice = seq_scan<float, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
@@ -634,11 +705,14 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
 #define PW_MIN_WAVES 8
 #endif
 
-template <bool UNIT>
+// UNIT: every edge weight is 1.0 (closed-form chain); EXTEND: node2vec+ (weighted graphs only --
+// on unit weights node2vec+ degenerates to node2vec bit for bit, so the host routes it to UNIT).
+template <bool UNIT, bool EXTEND>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
 walk_sparse_kernel(WalkArgs a) {
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
     __shared__ uint16_t s_rank[UNIT ? WAVES_PER_BLOCK : 1][UNIT ? MASK_WORDS + 2 : 2];
+    __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     uint32_t *mask = s_mask[wave];
@@ -679,7 +753,7 @@ walk_sparse_kernel(WalkArgs a) {
             const double r = readlane_f64(rbuf, (int)jr);
             uint32_t choice;
             if (UNIT) choice = sample_step_unit(a, mask, rank, j >= 2, prev, t0, dp, r, s0, d);
-            else choice = sample_step_weighted(a, mask, j >= 2, prev, t0, dp, r, s0, d);
+            else choice = sample_step_weighted(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, cur, j >= 2, prev, t0, dp, r, s0, d);
             uint64_t pos = (uint64_t)s0 + choice;
             if (choice >= d) {
                 st_over++;
