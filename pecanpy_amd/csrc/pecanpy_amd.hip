@@ -65,7 +65,10 @@ struct pw_graph {
     bool unit = false;  // all weights are 1.0f (data not stored)
     uint32_t max_degree = 0;
     uint32_t *d_indptr = nullptr, *d_indices = nullptr;
-    float *d_data = nullptr, *d_thr = nullptr;
+    void *d_data = nullptr;          // float32 (CSR graphs) or float64 (dense graphs); null when unit
+    float *d_thr = nullptr;
+    uint64_t *d_adjbits = nullptr;   // dense graphs: bit-packed adjacency rows
+    uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_cu = 0;
@@ -149,6 +152,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_indices) (void)hipFree(g->d_indices);
     if (g->d_data) (void)hipFree(g->d_data);
     if (g->d_thr) (void)hipFree(g->d_thr);
+    if (g->d_adjbits) (void)hipFree(g->d_adjbits);
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -206,15 +210,60 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     };
     rc = up((void **)&g->d_indptr, indptr, sizeof(uint32_t) * ((size_t)n_nodes + 1));
     if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
-    if (!rc && !unit) rc = up((void **)&g->d_data, data, sizeof(float) * (size_t)nnz);
+    if (!rc && !unit) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
     if (rc) { pw_graph_destroy(g); return rc; }
     *out = g;
     return PW_OK;
 }
 
 PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, pw_graph **out) {
-    (void)data; (void)n_nodes; (void)device; (void)out;
-    return fail(PW_ERR_UNSUPPORTED, "dense graphs: not implemented yet");
+    if (!data || !out) return fail(PW_ERR_INVALID, "null pointer");
+    // HBM layout of a dense graph (declared format): bit-packed adjacency rows for O(1)
+    // membership + the non-zero entries of every row compressed in ascending column order
+    // (uint32 column, float64 value -- values dropped when they are all 1.0).
+    const uint64_t n = n_nodes;
+    const uint32_t wpr = (uint32_t)((n + 63) / 64);
+    std::vector<uint32_t> indptr(n + 1, 0);
+    std::vector<uint32_t> cols;
+    std::vector<double> vals;
+    std::vector<uint64_t> bits((size_t)n * wpr, 0);
+    bool unit = true;
+    uint64_t nnz = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const double *row = data + i * n;
+        for (uint64_t x = 0; x < n; x++) {
+            const double v = row[x];
+            if (v != 0.0) {
+                if (nnz >= 0xffffffffull) return fail(PW_ERR_INVALID, "dense graph has more than 2^32-1 edges");
+                cols.push_back((uint32_t)x);
+                vals.push_back(v);
+                bits[i * wpr + (x >> 6)] |= 1ull << (x & 63);
+                if (v != 1.0) unit = false;
+                nnz++;
+            }
+        }
+        indptr[i + 1] = (uint32_t)nnz;
+    }
+    pw_graph *g = new pw_graph();
+    int rc = graph_common_init(g, device);
+    if (rc) { pw_graph_destroy(g); return rc; }
+    g->kind = 1;
+    g->n_nodes = n_nodes;
+    g->nnz = (uint32_t)nnz;
+    g->unit = unit;
+    g->words_per_row = wpr;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    rc = up((void **)&g->d_indptr, indptr.data(), sizeof(uint32_t) * indptr.size());
+    if (!rc) rc = up((void **)&g->d_indices, cols.data(), sizeof(uint32_t) * cols.size());
+    if (!rc && !unit) rc = up((void **)&g->d_data, vals.data(), sizeof(double) * vals.size());
+    if (!rc) rc = up((void **)&g->d_adjbits, bits.data(), sizeof(uint64_t) * bits.size());
+    if (rc) { pw_graph_destroy(g); return rc; }
+    *out = g;
+    return PW_OK;
 }
 
 PW_EXPORT int pw_graph_set_thresholds(pw_graph *g, const float *thr) {
@@ -255,7 +304,6 @@ static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t
 PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
                                     uint32_t walk_length, uint64_t *out_draws) {
     if (!g || !starts || !out_draws) return fail(PW_ERR_INVALID, "null pointer");
-    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "pw_count_stream_draws: CSR graphs only");
     if (set_device(g)) return PW_ERR_HIP;
     if (g->counters.ensure(8)) return PW_ERR_NOMEM;
     uint32_t *d_starts = nullptr;
@@ -270,12 +318,21 @@ PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_
     return rc;
 }
 
+typedef void (*walk_kernel_fn)(pw::WalkArgs);
+
+static walk_kernel_fn pick_kernel(const pw_graph *g, bool extend) {
+    if (g->kind == 0) {
+        if (g->unit) return pw::walk_kernel<float, false, true, false>;
+        return extend ? pw::walk_kernel<float, false, false, true> : pw::walk_kernel<float, false, false, false>;
+    }
+    if (g->unit) return pw::walk_kernel<double, true, true, false>;
+    return extend ? pw::walk_kernel<double, true, false, true> : pw::walk_kernel<double, true, false, false>;
+}
+
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     int occ = 0;
-    const void *fn = g->unit ? (const void *)pw::walk_sparse_kernel<true, false>
-                             : (extend ? (const void *)pw::walk_sparse_kernel<false, true>
-                                       : (const void *)pw::walk_sparse_kernel<false, false>);
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    walk_kernel_fn fn = pick_kernel(g, extend);
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     uint64_t want = (n_work + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
@@ -283,13 +340,7 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
-    const dim3 blk(pw::WAVES_PER_BLOCK * pw::WAVE);
-    if (g->unit)
-        hipLaunchKernelGGL((pw::walk_sparse_kernel<true, false>), dim3((unsigned)grid), blk, 0, g->stream, wa);
-    else if (extend)
-        hipLaunchKernelGGL((pw::walk_sparse_kernel<false, true>), dim3((unsigned)grid), blk, 0, g->stream, wa);
-    else
-        hipLaunchKernelGGL((pw::walk_sparse_kernel<false, false>), dim3((unsigned)grid), blk, 0, g->stream, wa);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -299,8 +350,10 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
                                  int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
                                  pw_stats *stats) {
     if (!g || (n_jobs && (!d_starts || !d_out))) return fail(PW_ERR_INVALID, "null pointer");
-    if (mode != PW_MODE_SPARSE_OTF) return fail(PW_ERR_UNSUPPORTED, "mode not implemented on the device yet");
-    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph");
+    if (mode != PW_MODE_SPARSE_OTF && mode != PW_MODE_DENSE_OTF)
+        return fail(PW_ERR_UNSUPPORTED, "mode not implemented on the device yet");
+    if (mode == PW_MODE_SPARSE_OTF && g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph handle");
+    if (mode == PW_MODE_DENSE_OTF && g->kind != 1) return fail(PW_ERR_UNSUPPORTED, "DenseOTF needs a dense graph handle");
     if (extend && !g->unit && !g->d_thr)
         return fail(PW_ERR_INVALID, "extend: call pw_graph_set_thresholds() first");
     if (!(p > 0) || !(q > 0)) return fail(PW_ERR_INVALID, "p and q must be positive");
@@ -375,6 +428,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.g.indices = g->d_indices;
     wa.g.data = g->d_data;
     wa.g.thr = g->d_thr;
+    wa.g.adjbits = g->d_adjbits;
+    wa.g.words_per_row = g->words_per_row;
     wa.g.n_nodes = g->n_nodes;
     wa.g.nnz = g->nnz;
     wa.p = p;

@@ -29,10 +29,34 @@ namespace pw {
 struct CsrDev {
     const uint32_t *__restrict__ indptr;
     const uint32_t *__restrict__ indices;
-    const float *__restrict__ data;  // nullptr: every weight is 1.0f
+    const void *__restrict__ data;   // float32 (SparseOTF) / float64 (DenseOTF); nullptr: all 1.0
     const float *__restrict__ thr;   // node2vec+ thresholds or nullptr
+    // DenseOTF only: bit-packed adjacency, row u = words [u * words_per_row, ...), bit x of the
+    // row set <=> nonzero[u, x].  Membership of x in N(prev) is one bit test instead of a search.
+    const uint64_t *__restrict__ adjbits;
+    uint32_t words_per_row;
     uint32_t n_nodes;
     uint32_t nnz;
+};
+
+// Arithmetic flavour of the two reference paths:
+//   float  (SparseOTF): float32 storage, biases applied through float64 (sparse_rw.py:84-87,
+//                       Numba dd->d loop), node2vec+ ratio t in float32 (sparse_rw.py:262-264)
+//   double (DenseOTF) : everything float64 (dense_rw.py:34-118)
+template <typename T> struct Arith;
+template <> struct Arith<float> {
+    static __device__ __forceinline__ float bias_div(float w, double d) { return (float)((double)w / d); }
+    static __device__ __forceinline__ float bias_mul(float w, double a) { return (float)((double)w * a); }
+    static __device__ __forceinline__ double t_ratio(float u, float thr) { return (double)(u / thr); }
+    static __device__ __forceinline__ bool in_edge(float u, float thr) { return u >= thr; }
+    static __device__ __forceinline__ bool noisy(float w, float thr_cur) { return w < thr_cur; }
+};
+template <> struct Arith<double> {
+    static __device__ __forceinline__ double bias_div(double w, double d) { return w / d; }
+    static __device__ __forceinline__ double bias_mul(double w, double a) { return w * a; }
+    static __device__ __forceinline__ double t_ratio(double u, float thr) { return u / (double)thr; }
+    static __device__ __forceinline__ bool in_edge(double u, float thr) { return !(u < (double)thr); }
+    static __device__ __forceinline__ bool noisy(double w, float thr_cur) { return w < (double)thr_cur; }
 };
 
 struct WalkArgs {
@@ -121,10 +145,11 @@ __device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict_
 // position of `prev` itself inside the segment, or NOT_FOUND.
 // node2vec+ (in_mask != nullptr): a second bitmask marks the common neighbours x whose edge
 // prev->x is not "noisy", w(prev, x) >= thr[x] (in-edges, isnotin_extended, sparse_rw.py:233-295).
+template <typename T>
 __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indices, uint32_t *mask,
                                                uint32_t s0, uint32_t a, uint32_t len, uint32_t t0,
                                                uint32_t dp, uint32_t prev, uint32_t *in_mask = nullptr,
-                                               const float *__restrict__ data = nullptr,
+                                               const T *__restrict__ data = nullptr,
                                                const float *__restrict__ thr = nullptr) {
     const int lane = lane_id();
     const uint32_t *__restrict__ crow = indices + s0 + a;
@@ -154,7 +179,7 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
                     bool found = i <= dp && pos[j] < len && crow[pos[j] < len ? pos[j] : 0] == key[j];
                     if (found && i < dp) {
                         atomicOr(&mask[pos[j] >> 5], 1u << (pos[j] & 31));
-                        if (in_mask && data[t0 + i] >= thr[key[j]]) atomicOr(&in_mask[pos[j] >> 5], 1u << (pos[j] & 31));
+                        if (in_mask && Arith<T>::in_edge(data[t0 + i], thr[key[j]])) atomicOr(&in_mask[pos[j] >> 5], 1u << (pos[j] & 31));
                     }
                     uint64_t pb = ballot(found && i == dp);
                     if (pb) prev_pos = a + readlane_u32(pos[j], __builtin_ctzll(pb));
@@ -183,7 +208,7 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
                     if (lane == 0) mask[kb >> 5] = (uint32_t)fb;
                     if (lane == 32) mask[(kb >> 5) + 1] = (uint32_t)(fb >> 32);
                     if (in_mask) {
-                        bool is_in = found && data[t0 + pos[j]] >= thr[key[j]];
+                        bool is_in = found && Arith<T>::in_edge(data[t0 + pos[j]], thr[key[j]]);
                         uint64_t ib = ballot(is_in);
                         if (lane == 0) in_mask[kb >> 5] = (uint32_t)ib;
                         if (lane == 32) in_mask[(kb >> 5) + 1] = (uint32_t)(ib >> 32);
@@ -198,12 +223,49 @@ __device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indi
     return prev_pos;
 }
 
+// DenseOTF membership: the bit-packed row of prev answers "x in N(prev)" directly, so every
+// neighbour of cur in the segment tests its own bit (coalesced read of cur's row + one word of
+// prev's 12.5 KB/100k-column row per lane).
+template <typename T>
+__device__ __forceinline__ uint32_t build_mask_bits(const CsrDev &g, uint32_t *mask, uint32_t s0, uint32_t a,
+                                                    uint32_t len, uint32_t t0, uint32_t dp, uint32_t prev,
+                                                    uint32_t *in_mask, const T *__restrict__ data) {
+    const int lane = lane_id();
+    const uint32_t *__restrict__ crow = g.indices + s0 + a;
+    const uint64_t *__restrict__ pbits = g.adjbits + (uint64_t)prev * g.words_per_row;
+    uint32_t prev_pos = NOT_FOUND;
+    for (uint32_t kb = 0; kb < len; kb += WAVE) {
+        const uint32_t k = kb + lane;
+        const bool valid = k < len;
+        const uint32_t x = valid ? crow[k] : 0u;
+        const bool found = valid && ((pbits[x >> 6] >> (x & 63)) & 1ull);
+        const uint64_t fb = ballot(found);
+        if (lane == 0) mask[kb >> 5] = (uint32_t)fb;
+        if (lane == 32) mask[(kb >> 5) + 1] = (uint32_t)(fb >> 32);
+        if (in_mask) {
+            // w(prev, x): position of x in prev's row by search (only for common neighbours)
+            bool is_in = false;
+            if (fb) {
+                const uint32_t jpos = lower_bound_u32(g.indices + t0, dp, x);
+                is_in = found && Arith<T>::in_edge(data[t0 + jpos], g.thr[x]);
+            }
+            const uint64_t ib = ballot(is_in);
+            if (lane == 0) in_mask[kb >> 5] = (uint32_t)ib;
+            if (lane == 32) in_mask[(kb >> 5) + 1] = (uint32_t)(ib >> 32);
+        }
+        const uint64_t pb = ballot(valid && x == prev);
+        if (pb) prev_pos = a + kb + __builtin_ctzll(pb);
+    }
+    wave_lds_fence();
+    return prev_pos;
+}
+
 // ---- per-neighbour biased weight / probability ------------------------------------------------------
 // Values of one segment of cur's row as the reference computes them:
 //   w_k = data[k]; out edges: fl32(f64(w)/q); return edge: fl32(f64(w)/p)  (sparse_rw.py:84-87)
 //   normalised: fl32(w_k / tot)                                             (sparse_rw.py:89)
-template <bool UNIT> struct RowVals {
-    const float *__restrict__ drow;  // data + s0 (unused when UNIT)
+template <typename T, bool UNIT> struct RowVals {
+    const T *__restrict__ drow;      // data + s0 (unused when UNIT)
     const uint32_t *mask;            // LDS bitmask of the current segment
     uint32_t seg_a;                  // first neighbour index covered by mask
     uint32_t prev_pos;               // NOT_FOUND when prev is not a neighbour of cur
@@ -211,34 +273,28 @@ template <bool UNIT> struct RowVals {
     bool has_prev;
     bool normalize;
     double p, q;
-    float tot;
-    float u_in, u_out, u_prev;  // UNIT: the three possible values (already normalised if asked)
-    // node2vec+ (extend): get_extended_normalized_probs, sparse_rw.py:93-130
+    T tot;
+    T u_in, u_out, u_prev;      // UNIT: the three possible values (already normalised if asked)
+    // node2vec+ (extend): get_extended_normalized_probs, sparse_rw.py:93-130 / dense_rw.py:74-118
     bool extend = false;
     const uint32_t *in_mask = nullptr;           // LDS: common neighbour that is an in-edge
     const uint32_t *__restrict__ crow = nullptr; // indices + s0
     const uint32_t *__restrict__ prow = nullptr; // indices + t0
-    const float *__restrict__ pdata = nullptr;   // data + t0
+    const T *__restrict__ pdata = nullptr;       // data + t0
     const float *__restrict__ thr = nullptr;
     uint32_t dp = 0;
     float thr_cur = 0.0f;
 
-    __device__ __forceinline__ void setup_unit() {
-        float w_in = 1.0f, w_out = (float)(1.0 / q), w_prev = (float)(1.0 / p);
-        if (normalize) { u_in = w_in / tot; u_out = w_out / tot; u_prev = w_prev / tot; }
-        else { u_in = w_in; u_out = w_out; u_prev = w_prev; }
-    }
-
-    __device__ __forceinline__ float value(uint32_t k, uint32_t bit) const {
+    __device__ __forceinline__ T value(uint32_t k, uint32_t bit) const {
         if (UNIT) {
-            const float vi = u_in, vo = u_out, vp = u_prev;
-            float v = bit ? vi : vo;
+            const T vi = u_in, vo = u_out, vp = u_prev;
+            T v = bit ? vi : vo;
             return (has_prev && k == prev_pos) ? vp : v;
         } else {
-            float w = drow[k];
+            T w = drow[k];
             if (has_prev && !extend) {
-                if (k == prev_pos) w = (float)((double)w / p);
-                else if (!bit) w = (float)((double)w / q);
+                if (k == prev_pos) w = Arith<T>::bias_div(w, p);
+                else if (!bit) w = Arith<T>::bias_div(w, q);
             }
             return normalize ? w / tot : w;
         }
@@ -246,26 +302,26 @@ template <bool UNIT> struct RowVals {
 
     // node2vec+ value of element k (valid: k < kend).  Every lane runs the (uniform trip count)
     // row search; only common neighbours that are out-edges need its result (t = w(prev,x)/thr[x]).
-    __device__ __forceinline__ float value_ext(uint32_t k, bool valid) const {
-        float w = valid ? drow[k] : 0.0f;
+    __device__ __forceinline__ T value_ext(uint32_t k, bool valid) const {
+        T w = valid ? drow[k] : (T)0;
         if (!has_prev) return (valid && normalize) ? w / tot : w;
         uint32_t r = valid ? k - seg_a : 0u;
         const bool common = valid && ((mask[r >> 5] >> (r & 31)) & 1u);
         const bool is_in = valid && ((in_mask[r >> 5] >> (r & 31)) & 1u);
         const bool need_t = common && !is_in && k != prev_pos;
-        float t = 0.0f;
+        double t = 0.0;
         if (ballot(need_t)) {
             const uint32_t x = need_t ? crow[k] : 0u;
             const uint32_t jpos = lower_bound_u32(prow, dp, x);
-            if (need_t) t = pdata[jpos] / thr[x];
+            if (need_t) t = Arith<T>::t_ratio(pdata[jpos], thr[x]);
         }
         if (valid) {
-            if (k == prev_pos) w = (float)((double)w / p);
+            if (k == prev_pos) w = Arith<T>::bias_div(w, p);
             else if (!(common && is_in)) {
                 const double inv_q = 1.0 / q;
-                double alpha = inv_q + (1.0 - inv_q) * (double)t;
-                if (w < thr_cur) alpha = inv_q < 1.0 ? inv_q : 1.0;
-                w = (float)((double)w * alpha);
+                double alpha = inv_q + (1.0 - inv_q) * t;
+                if (Arith<T>::noisy(w, thr_cur)) alpha = inv_q < 1.0 ? inv_q : 1.0;
+                w = Arith<T>::bias_mul(w, alpha);
             }
             if (normalize) w = w / tot;
         }
@@ -273,7 +329,7 @@ template <bool UNIT> struct RowVals {
     }
 
     // one element (k < kend required)
-    __device__ __forceinline__ float one(uint32_t k) const {
+    __device__ __forceinline__ T one(uint32_t k) const {
         if (!UNIT && extend) return value_ext(k, k < kend);
         uint32_t bit = 0;
         if (has_prev) { uint32_t r = k - seg_a; bit = (mask[r >> 5] >> (r & 31)) & 1u; }
@@ -281,7 +337,7 @@ template <bool UNIT> struct RowVals {
     }
 
     // EPL consecutive elements starting at kb (kb multiple of EPL); 0 beyond kend
-    __device__ __forceinline__ void vec(uint32_t kb, float (&xs)[EPL]) const {
+    __device__ __forceinline__ void vec(uint32_t kb, T (&xs)[EPL]) const {
         if (!UNIT && extend) {
 #pragma unroll
             for (int e = 0; e < EPL; e++) xs[e] = value_ext(kb + e, kb + e < kend);
@@ -292,7 +348,7 @@ template <bool UNIT> struct RowVals {
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
             uint32_t k = kb + e;
-            xs[e] = (k < kend) ? value(k, (bits >> e) & 1u) : 0.0f;
+            xs[e] = (k < kend) ? value(k, (bits >> e) & 1u) : (T)0;
         }
     }
 };
@@ -473,25 +529,38 @@ __device__ __forceinline__ void build_rank(const uint32_t *mask, uint16_t *rank,
     wave_lds_fence();
 }
 
-template <bool HAS_TARGET>
-__device__ __forceinline__ int unit_chain(float &c, uint32_t &k, uint32_t kend, double r,
-                                          const UnitRow &ur, const RowVals<true> &rv, float x_in,
-                                          float x_out, float x_prev, uint32_t &found) {
-    using B = Binade<float>;
+// cnt * inc without wrap-around (float64 increments reach 2^54; anything >= 2^61 only ever needs to
+// compare as "beyond the binade top").
+template <typename U> __device__ __forceinline__ uint64_t chain_term(uint32_t cnt, U inc);
+template <> __device__ __forceinline__ uint64_t chain_term<uint32_t>(uint32_t cnt, uint32_t inc) {
+    return (uint64_t)cnt * inc;
+}
+template <> __device__ __forceinline__ uint64_t chain_term<uint64_t>(uint32_t cnt, uint64_t inc) {
+    const uint64_t lo = (uint64_t)cnt * inc;
+    const uint64_t hi = __umul64hi((uint64_t)cnt, inc);
+    return (hi || (lo >> 61)) ? (1ull << 61) : lo;
+}
+
+template <typename T, bool HAS_TARGET>
+__device__ __forceinline__ int unit_chain(T &c, uint32_t &k, uint32_t kend, double r, const UnitRow &ur,
+                                          const RowVals<T, true> &rv, T x_in, T x_out, T x_prev,
+                                          uint32_t &found) {
+    using B = Binade<T>;
+    using U = typename B::UInt;
     const int lane = lane_id();
     while (k < kend) {
         const int eb = B::eb_of(c);
-        const uint32_t C = B::sig_of(c);
-        const uint32_t Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
-        const Inc<float> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb), qp = B::quantize(x_prev, eb);
+        const U C = B::sig_of(c);
+        const U Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
+        const Inc<T> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb), qp = B::quantize(x_prev, eb);
         const bool prev_in = ur.has_prev && ur.prev_pos != NOT_FOUND && ur.prev_pos >= k && ur.prev_pos < kend;
         // ties are parity dependent: hand this binade to the generic element scan (rare)
         if (qi.a0 != qi.a1 || qo.a0 != qo.a1 || (prev_in && qp.a0 != qp.a1)) {
-            int rc = seq_scan_binade<float, HAS_TARGET>(c, k, kend, r, rv, found);
+            int rc = seq_scan_binade<T, HAS_TARGET>(c, k, kend, r, rv, found);
             if (rc == SCAN_FOUND) return SCAN_FOUND;
             continue;
         }
-        const uint64_t ii = qi.a0, io = qo.a0, ipv = qp.a0;
+        const U ii = qi.a0, io = qo.a0, ipv = qp.a0;
         const uint32_t rk0 = ur.rank_at(k);
         uint32_t lo = k, hi = kend - 1, kf = 0;
         uint64_t Cf = 0;
@@ -504,8 +573,8 @@ __device__ __forceinline__ int unit_chain(float &c, uint32_t &k, uint32_t kend, 
             const uint32_t cin = ur.rank_at(kp + 1) - rk0;
             const uint32_t cpv = (prev_in && ur.prev_pos <= kp) ? 1u : 0u;
             const uint32_t cout = (kp + 1 - k) - cin - cpv;
-            const uint64_t G = (uint64_t)C + cin * ii + cout * io + cpv * ipv;
-            const uint64_t hitm = ballot(G >= Tt);
+            const uint64_t G = (uint64_t)C + chain_term<U>(cin, ii) + chain_term<U>(cout, io) + chain_term<U>(cpv, ipv);
+            const uint64_t hitm = ballot(G >= (uint64_t)Tt);
             if (!hitm) {  // only possible in the first round: the whole range stays below Tt
                 Cf = readlane_u64(G, WAVE - 1);
                 crossed = false;
@@ -518,32 +587,49 @@ __device__ __forceinline__ int unit_chain(float &c, uint32_t &k, uint32_t kend, 
             if (nhi < hi) hi = (uint32_t)nhi;
         }
         if (!crossed) {
-            c = B::make((uint32_t)Cf, eb);
+            c = B::make((U)Cf, eb);
             k = kend;
             break;
         }
         const bool f_prev = prev_in && kf == ur.prev_pos;
         const bool f_in = !f_prev && ur.bit_at(kf);
-        const uint64_t incf = f_prev ? ipv : (f_in ? ii : io);
-        const float xf = f_prev ? x_prev : (f_in ? x_in : x_out);
-        const uint32_t Cprev = (uint32_t)(Cf - incf);
-        if (Cf < B::TOP) { c = B::make((uint32_t)Cf, eb); found = kf; return SCAN_FOUND; }
-        c = B::make(Cprev, eb) + xf;
+        const T xf = f_prev ? x_prev : (f_in ? x_in : x_out);
+        // value just before element kf (exact: every element before kf kept the sum below Tt)
+        const uint32_t cin0 = ur.rank_at(kf) - rk0;
+        const uint32_t cpv0 = (prev_in && ur.prev_pos < kf) ? 1u : 0u;
+        const uint32_t cout0 = (kf - k) - cin0 - cpv0;
+        const uint64_t Cprev = (uint64_t)C + chain_term<U>(cin0, ii) + chain_term<U>(cout0, io) + chain_term<U>(cpv0, ipv);
+        if (Cf < (uint64_t)B::TOP) { c = B::make((U)Cf, eb); found = kf; return SCAN_FOUND; }
+        c = B::make((U)Cprev, eb) + xf;
         k = kf + 1;
         if (HAS_TARGET && (double)c >= r) { found = kf; return SCAN_FOUND; }
     }
     return SCAN_END;
 }
 
-__device__ __forceinline__ bool is_pow2_f32(float x) { return (__float_as_uint(x) & 0x7fffffu) == 0u; }
+template <typename T> __device__ __forceinline__ bool is_pow2_fp(T x) {
+    using U = typename FloatTraits<T>::UInt;
+    return (FloatTraits<T>::bits(x) & (((U)1 << FloatTraits<T>::MANT) - 1)) == 0;
+}
+
+// Membership mask of one segment: search-based (sparse) or bit-test based (dense adjacency bits).
+template <typename T, bool DENSE>
+__device__ __forceinline__ uint32_t segment_mask(const CsrDev &g, uint32_t *mask, uint32_t *in_mask, uint32_t s0,
+                                                 uint32_t sa, uint32_t len, uint32_t t0, uint32_t dp,
+                                                 uint32_t prev) {
+    const T *__restrict__ data = (const T *)g.data;
+    if (DENSE) return build_mask_bits<T>(g, mask, s0, sa, len, t0, dp, prev, in_mask, data);
+    return build_mask<T>(g.indices, mask, s0, sa, len, t0, dp, prev, in_mask, data, g.thr);
+}
 
 // Membership structures (mask + rank) of one segment; returns prev's position (global) or
 // NOT_FOUND.  known_prev_pos: position found by the caller for segmented rows (else NOT_FOUND).
-__device__ __forceinline__ uint32_t prepare_unit_segment(const uint32_t *__restrict__ indices, uint32_t *mask,
-                                                         uint16_t *rank, uint32_t s0, uint32_t sa,
-                                                         uint32_t len, uint32_t t0, uint32_t dp,
-                                                         uint32_t prev, bool multi, uint32_t known_prev_pos) {
-    uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev);
+template <typename T, bool DENSE>
+__device__ __forceinline__ uint32_t prepare_unit_segment(const CsrDev &g, uint32_t *mask, uint16_t *rank,
+                                                         uint32_t s0, uint32_t sa, uint32_t len, uint32_t t0,
+                                                         uint32_t dp, uint32_t prev, bool multi,
+                                                         uint32_t known_prev_pos) {
+    uint32_t pp = segment_mask<T, DENSE>(g, mask, nullptr, s0, sa, len, t0, dp, prev);
     if (multi) pp = known_prev_pos;
     if (pp != NOT_FOUND && pp >= sa && pp < sa + len) {
         uint32_t rr = pp - sa;  // keep the three classes disjoint
@@ -556,10 +642,11 @@ __device__ __forceinline__ uint32_t prepare_unit_segment(const uint32_t *__restr
 
 // Value view of one segment for the head / tie fallback.  Built fresh (never mutated) so that it
 // stays in registers: a struct that lives in scratch turns every value() into a scratch load.
-__device__ __forceinline__ RowVals<true> make_unit_vals(const uint32_t *mask, uint32_t sa, uint32_t kend,
-                                                         uint32_t prev_pos, bool has_prev, float v_in,
-                                                         float v_out, float v_prev) {
-    RowVals<true> rv;
+template <typename T>
+__device__ __forceinline__ RowVals<T, true> make_unit_vals(const uint32_t *mask, uint32_t sa, uint32_t kend,
+                                                            uint32_t prev_pos, bool has_prev, T v_in, T v_out,
+                                                            T v_prev) {
+    RowVals<T, true> rv;
     rv.drow = nullptr;
     rv.mask = mask;
     rv.seg_a = sa;
@@ -569,7 +656,7 @@ __device__ __forceinline__ RowVals<true> make_unit_vals(const uint32_t *mask, ui
     rv.normalize = false;
     rv.p = 1.0;
     rv.q = 1.0;
-    rv.tot = 1.0f;
+    rv.tot = (T)1;
     rv.u_in = v_in;
     rv.u_out = has_prev ? v_out : v_in;
     rv.u_prev = v_prev;
@@ -578,11 +665,13 @@ __device__ __forceinline__ RowVals<true> make_unit_vals(const uint32_t *mask, ui
 
 // Unit-weight transition: same result as the generic path, closed-form chain.
 // (t0, dp) = CSR row of prev, carried over from the previous step by the caller.
+template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t *mask, uint16_t *rank,
                                                      bool has_prev, uint32_t prev, uint32_t t0,
                                                      uint32_t dp, double r, uint32_t s0, uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
-    const float w_in = 1.0f, w_out = has_prev ? (float)(1.0 / a.q) : 1.0f, w_prev = (float)(1.0 / a.p);
+    const T w_in = (T)1, w_out = has_prev ? Arith<T>::bias_div((T)1, a.q) : (T)1,
+            w_prev = Arith<T>::bias_div((T)1, a.p);
 
     const bool multi = has_prev && d > SEG;
     uint32_t prev_pos = NOT_FOUND;
@@ -591,79 +680,81 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
         if (pos < d && uni(indices[s0 + pos]) == prev) prev_pos = pos;
     }
 
-    // ---- tot = sequential float32 sum of the biased weights ------------------------------------
-    float tot = 0.0f;
+    // ---- tot = sequential sum of the biased weights ------------------------------------------------
+    T tot = (T)0;
     bool have_tot = false;
     if (!multi) {
-        if (has_prev) prev_pos = prepare_unit_segment(indices, mask, rank, s0, 0, d, t0, dp, prev, false, NOT_FOUND);
+        if (has_prev) prev_pos = prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, 0, d, t0, dp, prev, false, NOT_FOUND);
         const UnitRow ur{mask, rank, 0u, d, prev_pos, has_prev};
-        // all partial sums are exact when the weights are dyadic and the total fits 24 bits of
-        // the smallest weight: then the left-to-right float32 sum equals the exact sum.
+        // all partial sums are exact when the weights are dyadic and the total fits the mantissa of
+        // the smallest weight: then the left-to-right sum equals the exact sum.
         const uint32_t n_in = has_prev ? ur.rank_at(d) : 0u;
         const uint32_t n_pv = (has_prev && prev_pos != NOT_FOUND) ? 1u : 0u;
         const uint32_t n_out = d - n_in - n_pv;
-        if ((n_out == 0 || is_pow2_f32(w_out)) && (n_pv == 0 || is_pow2_f32(w_prev))) {
-            float u = 1.0f;
+        if ((n_out == 0 || is_pow2_fp<T>(w_out)) && (n_pv == 0 || is_pow2_fp<T>(w_prev))) {
+            T u = (T)1;
             if (n_out && w_out < u) u = w_out;
             if (n_pv && w_prev < u) u = w_prev;
             double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
-            if (td / (double)u <= 16777216.0) { tot = (float)td; have_tot = true; }
+            if (td / (double)u <= (double)Binade<T>::TOP) { tot = (T)td; have_tot = true; }
         }
     }
     if (!have_tot) {
         for (uint32_t sa = 0; sa < d; sa += SEG) {
             const uint32_t len = d - sa < SEG ? d - sa : SEG;
-            if (multi) (void)prepare_unit_segment(indices, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+            if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
             const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
-            const RowVals<true> rv = make_unit_vals(mask, sa, sa + len, prev_pos, has_prev, w_in, w_out, w_prev);
+            const RowVals<T, true> rv = make_unit_vals<T>(mask, sa, sa + len, prev_pos, has_prev, w_in, w_out, w_prev);
             uint32_t k = sa, found = NOT_FOUND;
-            if (sa == 0) (void)seq_head<float, false>(tot, k, sa + len, 0.0, rv, WAVE, found);
-            (void)unit_chain<false>(tot, k, sa + len, 0.0, ur, rv, w_in, w_out, w_prev, found);
+            if (sa == 0) (void)seq_head<T, false>(tot, k, sa + len, 0.0, rv, WAVE, found);
+            (void)unit_chain<T, false>(tot, k, sa + len, 0.0, ur, rv, w_in, w_out, w_prev, found);
         }
     }
 
     // ---- cdf search ----------------------------------------------------------------------------------
-    const float x_in = w_in / tot, x_out = w_out / tot, x_prev = w_prev / tot;
-    float c = 0.0f;
+    const T x_in = w_in / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    T c = (T)0;
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         const uint32_t len = d - sa < SEG ? d - sa : SEG;
         // single segment: mask and rank from the tot phase are still valid
-        if (multi) (void)prepare_unit_segment(indices, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+        if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
         const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
-        const RowVals<true> rv = make_unit_vals(mask, sa, sa + len, prev_pos, has_prev, x_in, x_out, x_prev);
+        const RowVals<T, true> rv = make_unit_vals<T>(mask, sa, sa + len, prev_pos, has_prev, x_in, x_out, x_prev);
         uint32_t k = sa, found = NOT_FOUND;
-        if (sa == 0 && seq_head<float, true>(c, k, sa + len, r, rv, WAVE, found)) return found;
-        if (unit_chain<true>(c, k, sa + len, r, ur, rv, x_in, x_out, x_prev, found) == SCAN_FOUND) return found;
+        if (sa == 0 && seq_head<T, true>(c, k, sa + len, r, rv, WAVE, found)) return found;
+        if (unit_chain<T, true>(c, k, sa + len, r, ur, rv, x_in, x_out, x_prev, found) == SCAN_FOUND) return found;
     }
     return d;
 }
 
 // ---- general (weighted) transition -------------------------------------------------------------------
 // Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
+template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, uint32_t *in_mask,
                                                          uint32_t cur, bool has_prev, uint32_t prev,
                                                          uint32_t t0, uint32_t dp, double r, uint32_t s0,
                                                          uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
+    const T *__restrict__ data = (const T *)a.g.data;
     const bool extend = in_mask != nullptr;
-    RowVals<false> rv;
+    RowVals<T, false> rv;
+    rv.drow = data + s0;
+    rv.mask = mask;
+    rv.has_prev = has_prev;
+    rv.p = a.p;
+    rv.q = a.q;
+    rv.tot = (T)1;
+    rv.prev_pos = NOT_FOUND;
     rv.extend = extend;
     if (extend) {
         rv.in_mask = in_mask;
         rv.crow = indices + s0;
         rv.prow = indices + t0;
-        rv.pdata = a.g.data + t0;
+        rv.pdata = data + t0;
         rv.thr = a.g.thr;
         rv.dp = dp;
-        rv.thr_cur = uni(a.g.thr[cur]);
+        rv.thr_cur = __uint_as_float(uni(__float_as_uint(a.g.thr[cur])));
     }
-    rv.drow = a.g.data + s0;
-    rv.mask = mask;
-    rv.has_prev = has_prev;
-    rv.p = a.p;
-    rv.q = a.q;
-    rv.tot = 1.0f;
-    rv.prev_pos = NOT_FOUND;
 
     const bool multi = has_prev && d > SEG;
     // prev's position is needed by every segment: find it once when the row is segmented
@@ -673,30 +764,30 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     }
 
     // pass 1: tot
-    float tot = 0.0f;
+    T tot = (T)0;
     rv.normalize = false;
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
         if (has_prev) {
-            uint32_t pp = build_mask(indices, mask, s0, sa, len, t0, dp, prev, in_mask, a.g.data, a.g.thr);
+            uint32_t pp = segment_mask<T, DENSE>(a.g, mask, in_mask, s0, sa, len, t0, dp, prev);
             if (!multi) rv.prev_pos = pp;
         }
         rv.seg_a = sa;
         rv.kend = sa + len;
-        seq_scan<float, false>(tot, sa, sa + len, 0.0, rv, sa == 0 ? WAVE : 0);
+        seq_scan<T, false>(tot, sa, sa + len, 0.0, rv, sa == 0 ? WAVE : 0);
     }
 
     // pass 2: cdf search
     rv.normalize = true;
     rv.tot = tot;
-    float c = 0.0f;
+    T c = (T)0;
     uint32_t choice = NOT_FOUND;
     for (uint32_t sa = 0; sa < d && choice == NOT_FOUND; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (multi) (void)build_mask(indices, mask, s0, sa, len, t0, dp, prev, in_mask, a.g.data, a.g.thr);  // single segment: still valid
+        if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, s0, sa, len, t0, dp, prev);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
-        choice = seq_scan<float, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
+        choice = seq_scan<T, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
     }
     return choice == NOT_FOUND ? d : choice;
 }
@@ -705,11 +796,13 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
 #define PW_MIN_WAVES 8
 #endif
 
+// T = float : SparseOTF (reference float32 path).  T = double, DENSE: DenseOTF (float64 path, membership by
+// adjacency bits, "choice == degree" clamped to the last neighbour -- App. D quirk 1, dense row).
 // UNIT: every edge weight is 1.0 (closed-form chain); EXTEND: node2vec+ (weighted graphs only --
 // on unit weights node2vec+ degenerates to node2vec bit for bit, so the host routes it to UNIT).
-template <bool UNIT, bool EXTEND>
+template <typename T, bool DENSE, bool UNIT, bool EXTEND>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
-walk_sparse_kernel(WalkArgs a) {
+walk_kernel(WalkArgs a) {
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
     __shared__ uint16_t s_rank[UNIT ? WAVES_PER_BLOCK : 1][UNIT ? MASK_WORDS + 2 : 2];
     __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
@@ -752,13 +845,15 @@ walk_sparse_kernel(WalkArgs a) {
             }
             const double r = readlane_f64(rbuf, (int)jr);
             uint32_t choice;
-            if (UNIT) choice = sample_step_unit(a, mask, rank, j >= 2, prev, t0, dp, r, s0, d);
-            else choice = sample_step_weighted(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, cur, j >= 2, prev, t0, dp, r, s0, d);
-            uint64_t pos = (uint64_t)s0 + choice;
+            if (UNIT) choice = sample_step_unit<T, DENSE>(a, mask, rank, j >= 2, prev, t0, dp, r, s0, d);
+            else choice = sample_step_weighted<T, DENSE>(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, cur,
+                                                          j >= 2, prev, t0, dp, r, s0, d);
             if (choice >= d) {
                 st_over++;
-                if (pos >= nnz) { pos = nnz - 1; st_clamp++; }
+                if (DENSE) { choice = d - 1; st_clamp++; }  // reference reads past a temporary: clamp
             }
+            uint64_t pos = (uint64_t)s0 + choice;
+            if (pos >= nnz) { pos = nnz - 1; st_clamp++; }
             const uint32_t nxt = uni(indices[pos]);
             if (lane == 0) row[j] = nxt;
             prev = cur;

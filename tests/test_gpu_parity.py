@@ -193,9 +193,81 @@ def test_long_walks_and_large_offsets():
     assert np.array_equal(got, want), _diff_report(got, want)
 
 
+def _dense_fixtures():
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "_DenseOTF_" in os.path.basename(f))
+
+
+def _dense_from_csr(indptr, indices, data):
+    n = indptr.size - 1
+    mat = np.zeros((n, n), dtype=np.float64)
+    for i in range(n):
+        sl = slice(indptr[i], indptr[i + 1])
+        mat[i, indices[sl]] = data[sl]
+    return mat
+
+
+@pytest.mark.parametrize("path", _dense_fixtures(), ids=lambda f: os.path.basename(f)[:-4])
+def test_golden_dense_otf(path):
+    z = np.load(path)
+    eng = WalkEngine.from_dense(_dense_from_csr(z["indptr"], z["indices"], z["data"]))
+    extend = bool(z["extend"])
+    if extend:
+        eng.set_thresholds(z["thr"])
+    got = eng.simulate("DenseOTF", float(z["p"]), float(z["q"]), extend, z["starts"],
+                       int(z["walk_length"]), seed=int(z["seed"]))
+    assert np.array_equal(got, z["walks"]), _diff_report(got, z["walks"])
+
+
+@pytest.mark.parametrize("weighted,extend,p,q", [(False, False, 0.5, 2), (False, False, 0.3, 1.7),
+                                                  (True, False, 0.5, 2), (True, True, 0.5, 2),
+                                                  (True, True, 1.5, 0.3)])
+def test_dense_er_vs_oracle(weighted, extend, p, q):
+    from pecanpy_amd.synth import er_dense_mask
+
+    n = 700
+    rng = np.random.default_rng(3)
+    adj = er_dense_mask(n, 0.25, seed=2)
+    adj[5, :] = False  # one isolated vertex
+    adj[:, 5] = False
+    mat = adj.astype(np.float64)
+    if weighted:
+        w = np.triu(rng.random((n, n)) + 0.1, 1)
+        mat = mat * (w + w.T)
+    thr = None
+    if extend:
+        thr = np.zeros(n, dtype=np.float32)
+        for i in range(n):
+            row = mat[i, adj[i]]
+            thr[i] = row.mean() + 0.5 * row.std() if row.size else 0.0
+    starts = orc.shuffled_starts(n, 2, 7)
+    want, ost = orc.walks_dense_otf(mat, p, q, starts, 25, 7, thr=thr, return_stats=True)
+    eng = WalkEngine.from_dense(mat)
+    if extend:
+        eng.set_thresholds(thr)
+    got = eng.simulate("DenseOTF", p, q, extend, starts, 25, seed=7)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    assert eng.last_stats["total_steps"] == ost.total_steps
+
+
+def test_dense_and_sparse_agree_on_unweighted_graph():
+    """reference test/test_walk.py:58-81: identical tables for SparseOTF and DenseOTF."""
+    indptr, indices, data = rmat_csr(9, seed=11)
+    starts = orc.shuffled_starts(indptr.size - 1, 2, 2)
+    a = WalkEngine.from_csr(indptr, indices, data).simulate("SparseOTF", 0.5, 2, False, starts, 20, seed=2)
+    b = WalkEngine.from_dense(_dense_from_csr(indptr, indices, data)).simulate("DenseOTF", 0.5, 2, False, starts, 20, seed=2)
+    # float32 vs float64 chains can differ only through rounding at the sampled boundary: on this
+    # graph the reference's two paths agree walk for walk, and so must ours
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 20, 2)
+    assert np.array_equal(a, want)
+    wantd = orc.walks_dense_otf(_dense_from_csr(indptr, indices, data), 0.5, 2, starts, 20, 2)
+    assert np.array_equal(b, wantd)
+
+
 def test_mode_classes_drop_in():
     from pecanpy import pecanpy  # the alias package
     from ref_test_walk import IDS, MAT, WALKS
 
     g = pecanpy.SparseOTF.from_mat(MAT, IDS, p=1, q=1, random_state=0)
     assert g.simulate_walks(2, 3) == WALKS["SparseOTF"]
+    g = pecanpy.DenseOTF.from_mat(MAT, IDS, p=1, q=1, random_state=0)
+    assert g.simulate_walks(2, 3) == WALKS["DenseOTF"]
