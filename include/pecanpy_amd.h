@@ -107,6 +107,17 @@ int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
                        int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
                        pw_stats *stats);
 
+/* Alias tables of the PreComp modes, built on the device and kept in the handle.
+ *   first_order = 0: PreComp.preprocess_transition_probs (pecanpy.py:442-507): sum(deg^2) entries,
+ *                    table of (v, k-th neighbour as prev) at alias_indptr[v] + deg(v) * k
+ *   first_order = 1: PreCompFirstOrder.preprocess_transition_probs (pecanpy.py:336-361): nnz entries
+ * pw_simulate* with PW_MODE_PRECOMP / PW_MODE_PRECOMP_FIRST_ORDER builds them on demand.
+ * pw_precomp_export copies them to host arrays (alias_indptr uint64[n_nodes+1] may be NULL for
+ * first_order); *n_entries receives the table length (call with NULL arrays to query it). */
+int pw_precomp_build(pw_graph *g, double p, double q, int extend, int first_order);
+int pw_precomp_export(pw_graph *g, uint64_t *alias_indptr, uint32_t *alias_j, float *alias_q,
+                      uint64_t *n_entries);
+
 /* Number of stream doubles the jobs starts[0..n_jobs) consume when no walk dead-ends mid-way
  * (= walk_length x number of starts with at least one neighbour).  Lets a multi-GPU driver
  * compute each shard's stream_skip without running the walks. */

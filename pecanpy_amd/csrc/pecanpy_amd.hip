@@ -16,6 +16,7 @@
 #include "aux_kernels.hip.h"
 #include "mtjump.hpp"
 #include "seqscan.h"
+#include "walk_seq.hip.h"
 #include "walk_sparse.hip.h"
 
 #define PW_EXPORT extern "C" __attribute__((visibility("default")))
@@ -79,6 +80,14 @@ struct pw_graph {
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
     bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
+    // alias tables (PreComp modes)
+    DevBuf<uint64_t> alias_indptr;
+    DevBuf<uint32_t> alias_j, alias_s, alias_l, edge_row;
+    DevBuf<float> alias_q, probs_scratch;
+    uint64_t n_alias = 0;
+    int alias_kind = -1;  // -1 none, 0 second order, 1 first order
+    double alias_p = 0, alias_q_param = 0;
+    int alias_extend = 0;
 };
 
 namespace {
@@ -160,6 +169,13 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->jump_table.release();
     g->changed.release();
     g->counters.release();
+    g->alias_indptr.release();
+    g->alias_j.release();
+    g->alias_s.release();
+    g->alias_l.release();
+    g->edge_row.release();
+    g->alias_q.release();
+    g->probs_scratch.release();
     for (auto &e : g->ev)
         if (e) (void)hipEventDestroy(e);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -318,6 +334,118 @@ PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_
     return rc;
 }
 
+static pw::CsrDev csr_dev(const pw_graph *g) {
+    pw::CsrDev c;
+    c.indptr = g->d_indptr;
+    c.indices = g->d_indices;
+    c.data = g->d_data;
+    c.thr = g->d_thr;
+    c.adjbits = g->d_adjbits;
+    c.words_per_row = g->words_per_row;
+    c.n_nodes = g->n_nodes;
+    c.nnz = g->nnz;
+    return c;
+}
+
+PW_EXPORT int pw_precomp_build(pw_graph *g, double p, double q, int extend, int first_order) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "alias tables need a CSR graph handle");
+    if (!(p > 0) || !(q > 0)) return fail(PW_ERR_INVALID, "p and q must be positive");
+    if (extend && !g->d_thr) return fail(PW_ERR_INVALID, "extend: call pw_graph_set_thresholds() first");
+    if (set_device(g)) return PW_ERR_HIP;
+    first_order = first_order ? 1 : 0;
+    if (g->alias_kind == first_order && (first_order || (g->alias_p == p && g->alias_q_param == q && g->alias_extend == extend)))
+        return PW_OK;
+    const uint32_t n = g->n_nodes;
+    std::vector<uint32_t> indptr((size_t)n + 1);
+    HIP_TRY(hipMemcpy(indptr.data(), g->d_indptr, sizeof(uint32_t) * indptr.size(), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> aptr((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t d = indptr[i + 1] - indptr[i];
+        aptr[i + 1] = aptr[i] + (first_order ? d : d * d);
+    }
+    const uint64_t n_alias = aptr[n];
+    const size_t cap = n_alias ? n_alias : 1;
+    if (g->alias_indptr.ensure((size_t)n + 1) || g->alias_j.ensure(cap) || g->alias_q.ensure(cap) ||
+        g->alias_s.ensure(cap) || g->alias_l.ensure(cap) || g->edge_row.ensure(g->nnz ? g->nnz : 1))
+        return PW_ERR_NOMEM;
+    HIP_TRY(hipMemcpy(g->alias_indptr.p, aptr.data(), sizeof(uint64_t) * aptr.size(), hipMemcpyHostToDevice));
+    pw::CsrDev c = csr_dev(g);
+    if (n) hipLaunchKernelGGL(pw::edge_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->d_indptr, n, g->edge_row.p);
+    const uint64_t work = first_order ? (uint64_t)n : (uint64_t)g->nnz;
+    if (work)
+        hipLaunchKernelGGL(pw::alias_tables_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, g->stream, c, p, q,
+                           extend, first_order, g->edge_row.p, g->alias_indptr.p, g->alias_j.p, g->alias_q.p,
+                           g->alias_s.p, g->alias_l.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->n_alias = n_alias;
+    g->alias_kind = first_order;
+    g->alias_p = p;
+    g->alias_q_param = q;
+    g->alias_extend = extend;
+    return PW_OK;
+}
+
+PW_EXPORT int pw_precomp_export(pw_graph *g, uint64_t *alias_indptr, uint32_t *alias_j, float *alias_q,
+                                uint64_t *n_entries) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (g->alias_kind < 0) return fail(PW_ERR_INVALID, "no alias tables built");
+    if (set_device(g)) return PW_ERR_HIP;
+    if (n_entries) *n_entries = g->n_alias;
+    if (alias_indptr)
+        HIP_TRY(hipMemcpy(alias_indptr, g->alias_indptr.p, sizeof(uint64_t) * ((size_t)g->n_nodes + 1), hipMemcpyDeviceToHost));
+    if (alias_j && g->n_alias) HIP_TRY(hipMemcpy(alias_j, g->alias_j.p, sizeof(uint32_t) * g->n_alias, hipMemcpyDeviceToHost));
+    if (alias_q && g->n_alias) HIP_TRY(hipMemcpy(alias_q, g->alias_q.p, sizeof(float) * g->n_alias, hipMemcpyDeviceToHost));
+    return PW_OK;
+}
+
+// Sequential-stream modes (variable word consumption): one lane walks every job in order.
+static int simulate_sequential(pw_graph *g, int mode, double p, double q, int extend, const uint32_t *d_starts,
+                               uint64_t n_jobs, uint32_t L, uint32_t seed, uint32_t *d_out, pw_stats *st) {
+    if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "this mode needs a CSR graph handle");
+    if (mode == PW_MODE_PRECOMP) { int rc = pw_precomp_build(g, p, q, extend, 0); if (rc) return rc; }
+    if (mode == PW_MODE_PRECOMP_FIRST_ORDER) { int rc = pw_precomp_build(g, 1.0, 1.0, 0, 1); if (rc) return rc; }
+    if (g->mt_state.ensure(pw::MT_N)) return PW_ERR_NOMEM;
+    if (g->probs_scratch.ensure((size_t)g->max_degree + 1)) return PW_ERR_NOMEM;
+    uint32_t st0[pw::MT_N];
+    pw::mt_seed_state(st0, seed);
+    HIP_TRY(hipMemcpy(g->mt_state.p, st0, sizeof(st0), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, 8 * sizeof(unsigned long long), g->stream));
+    pw::SeqArgs a;
+    a.g = csr_dev(g);
+    a.p = p;
+    a.q = q;
+    a.mode = mode;
+    a.L = L;
+    a.n_jobs = n_jobs;
+    a.starts = d_starts;
+    a.mt_seed_state = g->mt_state.p;
+    a.alias_indptr = g->alias_indptr.p;
+    a.alias_j = g->alias_j.p;
+    a.alias_q = g->alias_q.p;
+    a.n_alias = g->n_alias;
+    a.probs_scratch = g->probs_scratch.p;
+    a.out = d_out;
+    a.stats = g->counters.p + 1;
+    HIP_TRY(hipEventRecord(g->ev[2], g->stream));
+    hipLaunchKernelGGL(pw::walk_seq_kernel, dim3(1), dim3(64), 0, g->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[3], g->stream));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
+    st->walk_kernel_ms = ms;
+    st->walk_kernel_launches = 1;
+    st->total_steps = h[1];
+    st->overflow_reads = h[2];
+    st->clamped_reads = h[3];
+    st->dead_end_walks = h[4];
+    return PW_OK;
+}
+
 typedef void (*walk_kernel_fn)(pw::WalkArgs);
 
 static walk_kernel_fn pick_kernel(const pw_graph *g, bool extend) {
@@ -350,8 +478,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
                                  int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
                                  pw_stats *stats) {
     if (!g || (n_jobs && (!d_starts || !d_out))) return fail(PW_ERR_INVALID, "null pointer");
-    if (mode != PW_MODE_SPARSE_OTF && mode != PW_MODE_DENSE_OTF)
-        return fail(PW_ERR_UNSUPPORTED, "mode not implemented on the device yet");
+    if (mode < PW_MODE_SPARSE_OTF || mode > PW_MODE_PRECOMP_FIRST_ORDER) return fail(PW_ERR_INVALID, "unknown mode");
     if (mode == PW_MODE_SPARSE_OTF && g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph handle");
     if (mode == PW_MODE_DENSE_OTF && g->kind != 1) return fail(PW_ERR_UNSUPPORTED, "DenseOTF needs a dense graph handle");
     if (extend && !g->unit && !g->d_thr)
@@ -365,6 +492,13 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (n_jobs == 0) { if (stats) *stats = st; return PW_OK; }
     if (!has_seed) seed = os_seed();
     if (g->counters.ensure(8)) return PW_ERR_NOMEM;
+    if (mode >= PW_MODE_PRECOMP) {
+        if (stream_skip) return fail(PW_ERR_UNSUPPORTED, "alias / first-order modes consume a variable number of "
+                                                         "words per step: the stream cannot be sharded");
+        int rcs = simulate_sequential(g, mode, p, q, extend, d_starts, n_jobs, walk_length, seed, d_out, &st);
+        if (!rcs && stats) *stats = st;
+        return rcs;
+    }
 
     // 1. stream offsets (nominal: every walk from a start with neighbours runs L steps)
     uint64_t total = 0;
@@ -424,14 +558,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     // 3. walks
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, 8 * sizeof(unsigned long long), g->stream));
     pw::WalkArgs wa;
-    wa.g.indptr = g->d_indptr;
-    wa.g.indices = g->d_indices;
-    wa.g.data = g->d_data;
-    wa.g.thr = g->d_thr;
-    wa.g.adjbits = g->d_adjbits;
-    wa.g.words_per_row = g->words_per_row;
-    wa.g.n_nodes = g->n_nodes;
-    wa.g.nnz = g->nnz;
+    wa.g = csr_dev(g);
     wa.p = p;
     wa.q = q;
     wa.L = walk_length;

@@ -107,6 +107,22 @@ class WalkEngine:
         self.last_stats = st.as_dict()
         return out
 
+    def precomp_build(self, p, q, extend, first_order):
+        """Alias tables on the device (PreComp / PreCompFirstOrder preprocessing)."""
+        _lib.check(self._lib.pw_precomp_build(self._h, float(p), float(q), int(bool(extend)),
+                                              int(bool(first_order))))
+
+    def precomp_export(self, first_order):
+        """Host copies ``(alias_indptr, alias_j, alias_q)`` of the tables built last."""
+        n = C.c_uint64(0)
+        _lib.check(self._lib.pw_precomp_export(self._h, None, None, None, C.byref(n)))
+        alias_indptr = np.zeros(self.n_nodes + 1, dtype=np.uint64)
+        alias_j = np.zeros(int(n.value), dtype=np.uint32)
+        alias_q = np.zeros(int(n.value), dtype=np.float32)
+        _lib.check(self._lib.pw_precomp_export(self._h, _np_ptr(alias_indptr), _np_ptr(alias_j),
+                                               _np_ptr(alias_q), C.byref(n)))
+        return alias_indptr, alias_j, alias_q
+
     def count_stream_draws(self, starts, walk_length):
         starts = np.ascontiguousarray(starts, dtype=np.uint32)
         n = C.c_uint64(0)

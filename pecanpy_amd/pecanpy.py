@@ -100,6 +100,10 @@ class Base(BaseGraph):
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self._mode not in ("SparseOTF", "DenseOTF"):
+                raise NotImplementedError(
+                    f"{self._mode} draws a variable number of random words per step; its seeded "
+                    "stream cannot be sharded across GPUs -- run it in a single process")
             return self._random_walks_sharded(eng, starts, walk_length)
         mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length,
                            seed=self.random_state)
@@ -215,6 +219,12 @@ class PreCompFirstOrder(_SparseBase):
         super().__init__(*args, **kwargs)
         self.alias_j = self.alias_q = None
 
+    def preprocess_transition_probs(self):
+        """Build the per-node alias tables on the GPU (reference pecanpy.py:336-361)."""
+        eng = self._get_engine()
+        eng.precomp_build(1, 1, False, True)
+        _, self.alias_j, self.alias_q = eng.precomp_export(True)
+
 
 class PreComp(_SparseBase):
     """Second-order alias tables (reference pecanpy.py:364-507)."""
@@ -227,6 +237,14 @@ class PreComp(_SparseBase):
         self.alias_j = None
         self.alias_q = None
         self.alias_indptr = None
+
+    def preprocess_transition_probs(self):
+        """Build the sum(deg^2) second-order alias tables on the GPU (reference pecanpy.py:442-507)
+        and mirror them into ``alias_dim / alias_indptr / alias_j / alias_q``."""
+        eng = self._get_engine()
+        eng.precomp_build(self.p, self.q, self.extend, False)
+        self.alias_indptr, self.alias_j, self.alias_q = eng.precomp_export(False)
+        self.alias_dim = self.indptr[1:] - self.indptr[:-1]
 
 
 class DenseOTF(Base, DenseGraph):

@@ -263,6 +263,42 @@ def test_dense_and_sparse_agree_on_unweighted_graph():
     assert np.array_equal(b, wantd)
 
 
+def _alias_fixtures():
+    names = ("_PreComp_", "_FirstOrderUnweighted_", "_PreCompFirstOrder_")
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if any(n in os.path.basename(f) for n in names))
+
+
+@pytest.mark.parametrize("path", _alias_fixtures(), ids=lambda f: os.path.basename(f)[:-4])
+def test_golden_alias_and_first_order_modes(path):
+    z = np.load(path)
+    mode = str(z["mode"])
+    eng = WalkEngine.from_csr(z["indptr"], z["indices"], z["data"])
+    extend = bool(z["extend"])
+    if extend:
+        eng.set_thresholds(z["thr"])
+    got = eng.simulate(mode, float(z["p"]), float(z["q"]), extend, z["starts"], int(z["walk_length"]),
+                       seed=int(z["seed"]))
+    assert np.array_equal(got, z["walks"]), _diff_report(got, z["walks"])
+
+
+def test_precomp_tables_match_oracle_bitwise():
+    indptr, indices, data = rmat_csr(8, seed=3, weighted=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    eng.precomp_build(0.5, 2, False, False)
+    aip, aj, aq = eng.precomp_export(False)
+    oip, oj, oq = orc.precomp_tables(indptr, indices, data, 0.5, 2)
+    assert np.array_equal(aip, oip) and np.array_equal(aj, oj)
+    assert np.array_equal(aq.view(np.uint32), oq.view(np.uint32))
+    starts = orc.shuffled_starts(indptr.size - 1, 3, 4)
+    want = orc.walks_precomp(indptr, indices, data, 0.5, 2, starts, 30, 4)
+    got = eng.simulate("PreComp", 0.5, 2, False, starts, 30, seed=4)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    for precomp in (False, True):
+        want = orc.walks_first_order(indptr, indices, data, starts, 30, 4, precomp=precomp)
+        got = eng.simulate("PreCompFirstOrder" if precomp else "FirstOrderUnweighted", 1, 1, False, starts, 30, seed=4)
+        assert np.array_equal(got, want), _diff_report(got, want)
+
+
 def test_mode_classes_drop_in():
     from pecanpy import pecanpy  # the alias package
     from ref_test_walk import IDS, MAT, WALKS
@@ -271,3 +307,9 @@ def test_mode_classes_drop_in():
     assert g.simulate_walks(2, 3) == WALKS["SparseOTF"]
     g = pecanpy.DenseOTF.from_mat(MAT, IDS, p=1, q=1, random_state=0)
     assert g.simulate_walks(2, 3) == WALKS["DenseOTF"]
+    for label, cls in [("PreComp", pecanpy.PreComp), ("FirstOrderUnweighted", pecanpy.FirstOrderUnweighted)]:
+        g = cls.from_mat(MAT, IDS, p=1, q=1, random_state=0)
+        assert g.simulate_walks(2, 3) == WALKS[label]
+    g = pecanpy.PreComp.from_mat(MAT, IDS, p=1, q=1, random_state=0)
+    g.preprocess_transition_probs()
+    assert g.alias_j.size == int((np.diff(g.indptr.astype(np.int64)) ** 2).sum())
