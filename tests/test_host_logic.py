@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference API: graph containers, start array, thresholds, CLI."""
+import os
+
+import numpy as np
+import pytest
+
+from pecanpy_amd import cli, graph
+from pecanpy_amd import pecanpy as node2vec
+from pecanpy_amd.synth import csr_from_edges, rmat_csr
+from pecanpy_amd.wrappers import Timer
+
+
+def write_edg(tmp_path, lines):
+    p = tmp_path / "g.edg"
+    p.write_text("\n".join(lines) + "\n")
+    return str(p)
+
+
+def test_edge_list_reader_builds_sorted_csr(tmp_path):
+    path = write_edg(tmp_path, ["b\ta\t2.0", "a\tc\t0.5", "d\tb\t1.5", "c\tb\t4"])
+    g = graph.SparseGraph()
+    g.read_edg(path, weighted=True, directed=False)
+    assert g.nodes == ["b", "a", "c", "d"]          # first-appearance order
+    assert g.indptr.dtype == np.uint32 and g.indices.dtype == np.uint32 and g.data.dtype == np.float32
+    for i in range(g.num_nodes):
+        row = g.indices[g.indptr[i]:g.indptr[i + 1]]
+        assert np.all(np.diff(row.astype(np.int64)) > 0)   # ascending, duplicate free
+    assert g.num_edges == 8
+    dense = graph.DenseGraph()
+    dense.read_edg(path, weighted=True, directed=False)
+    assert dense.data.dtype == np.float64 and dense.nonzero.dtype == bool
+    assert dense.data[0, 1] == 2.0 and dense.data[1, 0] == 2.0 and dense.num_edges == 8
+
+
+def test_directed_unweighted_and_nonpositive_weights(tmp_path):
+    path = write_edg(tmp_path, ["a\tb", "b\tc", "c\ta"])
+    g = graph.SparseGraph()
+    g.read_edg(path, weighted=False, directed=True)
+    assert g.num_edges == 3 and np.all(g.data == 1.0)
+    path = write_edg(tmp_path, ["a\tb\t0", "a\tc\t-1", "b\tc\t1"])
+    with pytest.warns(RuntimeWarning):
+        g.read_edg(path, weighted=True, directed=False)
+    assert g.num_edges == 2
+    with pytest.raises(ValueError):
+        graph.AdjlstGraph._read_edge_line("a\tb", True, "\t")
+
+
+def test_from_mat_npz_roundtrip_and_implicit_ids(tmp_path):
+    mat = np.array([[0, 1, 0, 0], [1, 0, 0, 1], [0, 0, 0, 0], [0, 1, 1, 0]], dtype=float)
+    g = graph.SparseGraph.from_mat(mat, list("abcd"))
+    assert g.indptr.tolist() == [0, 1, 3, 3, 5] and g.indices.tolist() == [1, 0, 3, 1, 2]
+    p = str(tmp_path / "g.csr.npz")
+    g.save(p)
+    h = graph.SparseGraph()
+    h.read_npz(p, weighted=True)
+    assert h.nodes == g.nodes and np.array_equal(h.indices, g.indices)
+    np.savez(str(tmp_path / "raw.npz"), indptr=g.indptr, indices=g.indices, data=g.data)
+    k = graph.SparseGraph()
+    with pytest.warns(UserWarning):
+        k.read_npz(str(tmp_path / "raw.npz"), weighted=False)
+    assert k.nodes == ["0", "1", "2", "3"]
+    k.read_npz(str(tmp_path / "raw.npz"), weighted=False, implicit_ids=True)
+    d = graph.DenseGraph.from_mat(mat, list("abcd"))
+    d.save(str(tmp_path / "d.npz"))
+    e = graph.DenseGraph()
+    e.read_npz(str(tmp_path / "d.npz"), weighted=False)
+    assert np.array_equal(e.nonzero, mat != 0)
+    with pytest.raises(NotImplementedError):
+        graph.BaseGraph().num_edges
+
+
+def test_start_array_is_the_reference_shuffle():
+    g = node2vec.SparseOTF(random_state=5)
+    g.set_node_ids(None, implicit_ids=True, num_nodes=11)
+    starts = g._start_array(3)
+    nodes = np.arange(11, dtype=np.uint32)
+    want = np.concatenate([nodes] * 3)
+    np.random.seed(5)
+    np.random.shuffle(want)
+    assert starts.dtype == np.uint32 and np.array_equal(starts, want)
+
+
+def test_constructor_signature_and_mode_classes():
+    for cls in (node2vec.SparseOTF, node2vec.DenseOTF, node2vec.PreComp, node2vec.PreCompFirstOrder,
+                node2vec.FirstOrderUnweighted):
+        g = cls(0.5, 2, 3, True, True, 0.25, 9)     # the positional order the CLI relies on
+        assert (g.p, g.q, g.workers, g.verbose, g.extend, g.gamma, g.random_state) == (0.5, 2, 3, True, True, 0.25, 9)
+        assert isinstance(g, node2vec.Base)
+    assert hasattr(node2vec.PreComp(), "alias_indptr")
+
+
+def test_noise_thresholds_follow_the_reference_expression():
+    indptr, indices, data = rmat_csr(7, seed=2, weighted=True)
+    keep = np.diff(indptr.astype(np.int64)) > 0
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, gamma=0.5, extend=True)
+    with np.errstate(all="ignore"):
+        thr = g.get_noise_thresholds()
+    for i in np.nonzero(keep)[0][:20]:
+        row = data[indptr[i]:indptr[i + 1]]
+        assert thr[i] == np.float32(max(row.mean() + 0.5 * row.std(), 0))
+
+
+def test_map_walk_uses_length_cell():
+    g = node2vec.SparseOTF()
+    g.set_node_ids(list("abcde"))
+    assert g._map_walk(np.array([2, 3, 0, 0, 2], dtype=np.uint32)) == ["c", "d"]
+
+
+def test_cli_flags_defaults_and_mode_checks():
+    a = cli.parse_args(["--input", "g.edg", "--output", "o.emb"])
+    assert (a.mode, a.p, a.q, a.num_walks, a.walk_length, a.dimensions, a.window_size, a.epochs) == \
+        ("SparseOTF", 1, 1, 10, 80, 128, 10, 1)
+    assert a.workers == 0 and a.random_state is None and a.delimiter == "\t" and not a.extend
+    g = node2vec.SparseOTF()
+    bad = cli.parse_args(["--input", "g", "--output", "o", "--mode", "FirstOrderUnweighted", "--p", "2"])
+    with pytest.raises(ValueError):
+        cli.check_mode(g, bad)
+    bad = cli.parse_args(["--input", "g", "--output", "o", "--mode", "PreCompFirstOrder", "--q", "2", "--weighted"])
+    with pytest.raises(ValueError):
+        cli.check_mode(g, bad)
+    both = cli.parse_args(["--input", "g", "--output", "o", "--directed", "--extend"])
+    with pytest.raises(NotImplementedError):
+        cli.read_graph.__wrapped__(both) if hasattr(cli.read_graph, "__wrapped__") else cli.read_graph(both)
+
+
+def test_cli_conversion_tasks(tmp_path):
+    path = write_edg(tmp_path, ["a\tb", "b\tc"])
+    out = str(tmp_path / "o.csr.npz")
+    args = cli.parse_args(["--input", path, "--output", out, "--task", "tocsr"])
+    with pytest.raises(SystemExit):
+        cli.read_graph(args)
+    assert set(np.load(out).files) == {"IDs", "data", "indptr", "indices"}
+
+
+def test_timer_prints_stage(capsys):
+    assert Timer("do thing")(lambda x: x + 1)(1) == 2
+    assert "to do thing" in capsys.readouterr().out
+    assert Timer("quiet", verbose=False)(len) is len
+
+
+def test_synth_generators():
+    indptr, indices, data = rmat_csr(8, seed=1)
+    assert indptr[-1] == indices.size and np.all(data == 1)
+    rows = np.repeat(np.arange(256), np.diff(indptr.astype(np.int64)))
+    assert np.all(rows != indices)                                   # no self loops
+    fwd = set(zip(rows.tolist(), indices.tolist()))
+    assert all((b, a) in fwd for a, b in list(fwd)[:500])            # symmetric
+    ip, ix, da = csr_from_edges([0, 0, 2, 0], [1, 2, 0, 1], 3)
+    assert ip.tolist() == [0, 2, 2, 3] and ix.tolist() == [1, 2, 0]

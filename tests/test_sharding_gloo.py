@@ -1,0 +1,92 @@
+"""Multi-GPU sharding logic on CPU: world_size 2, gloo backend.
+
+The per-rank walk operator is replaced by the CPU oracle (allowed here: tests may use the oracle
+as the engine-under-test's stand-in); what is checked is the product's sharding code -- shard
+bounds, stream addressing of each shard (stream_skip from an all-gather of draw counts), the
+re-run when a shard consumed fewer draws than announced (dead ends), and the final gather.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyoracle as orc
+from pecanpy_amd.sharding import shard_bounds, sharded_walk_matrix, to_uint32_numpy
+from pecanpy_amd.synth import rmat_csr
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _graph(kind):
+    if kind == "undirected":
+        return rmat_csr(9, seed=5)
+    # directed graph with sinks: dead ends shift the stream address of later shards
+    rng = np.random.default_rng(1)
+    n = 60
+    adj = rng.random((n, n)) < 0.06
+    np.fill_diagonal(adj, False)
+    adj[rng.choice(n, 8, replace=False), :] = False
+    indptr = np.zeros(n + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(adj.sum(1))
+    indices = np.nonzero(adj)[1].astype(np.uint32)
+    return indptr, indices, np.ones(indices.size, dtype=np.float32)
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    indptr, indices, data = _graph(kind)
+    L, seed = 12, 3
+    starts = orc.shuffled_starts(indptr.size - 1, 3, seed)
+    has = indptr[1:] != indptr[:-1]
+    calls = []
+
+    def run_shard(sl, skip):
+        calls.append(len(sl))
+        mat = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, sl, L, seed, stream_skip=skip)
+        actual = int((mat[:, -1].astype(np.int64) - 1).sum())
+        return torch.from_numpy(mat.view(np.int32).copy()), actual
+
+    def count_draws(sl):
+        return int(has[sl].sum()) * L
+
+    full = sharded_walk_matrix(run_shard, count_draws, starts, L)
+    if rank == 0:
+        ret["full"] = to_uint32_numpy(full)
+        ret["runs_rank0"] = sum(1 for c in calls if c)
+    only0 = sharded_walk_matrix(run_shard, count_draws, starts, L, dst=0)
+    assert (only0 is None) == (rank != 0)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["undirected", "directed_with_sinks"])
+def test_two_rank_shards_reassemble_the_single_stream(kind):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, kind, ret), nprocs=2, join=True)
+        indptr, indices, data = _graph(kind)
+        starts = orc.shuffled_starts(indptr.size - 1, 3, 3)
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 12, 3)
+        assert np.array_equal(ret["full"], want)
+        if kind == "directed_with_sinks":
+            assert (want[:, -1] < 13).any()          # the case really has mid-walk dead ends
+
+
+def test_shard_bounds_cover_the_job_array():
+    for n, w in [(10, 3), (7, 8), (41943040, 8), (1, 2)]:
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
