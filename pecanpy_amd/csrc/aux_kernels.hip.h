@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "walk_sparse.hip.h"
+
 namespace pw {
 
 // ---------------------------------------------------------------------------------------------
@@ -111,6 +113,54 @@ mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly,
             }
         }
         states[(src + dst_offset) * 624 + t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-row membership filters (walk_sparse.hip.h: filter_hash / filter_word / filter_bits): one
+// thread per CSR entry sets the two bits of its neighbour id in the owning row's filter.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+filter_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                    const uint32_t *__restrict__ foff, unsigned long long *fbits, uint32_t n_nodes) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t u = wave; u < n_nodes; u += n_waves) {
+        const uint32_t s0 = indptr[u], d = indptr[u + 1] - s0;
+        if (d == 0) continue;
+        const uint32_t f0 = foff[u];
+        const uint32_t nw_mask = foff[u + 1] - f0 - 1u;
+        for (uint32_t k = lane; k < d; k += 64) {
+            const uint32_t h = filter_hash(indices[s0 + k]);
+            atomicOr(&fbits[f0 + filter_word(h, nw_mask)], (unsigned long long)filter_bits(h));
+        }
+    }
+}
+
+// adjacency index (walk_sparse.hip.h: adj_hash / adj_lookup): one wavefront per row inserts the
+// row's (neighbour, position) pairs into its open-addressing table.
+__global__ void __launch_bounds__(256)
+adj_index_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                       const uint64_t *__restrict__ tab_off, unsigned long long *slots, uint32_t n_nodes) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t u = wave; u < n_nodes; u += n_waves) {
+        const uint32_t s0 = indptr[u], d = indptr[u + 1] - s0;
+        if (d == 0) continue;
+        const uint64_t off = tab_off[u];
+        const uint32_t smask = (uint32_t)(tab_off[u + 1] - off) - 1u;
+        for (uint32_t k = lane; k < d; k += 64) {
+            const uint32_t v = indices[s0 + k];
+            const unsigned long long entry = ((unsigned long long)k << 32) | v;
+            uint32_t idx = adj_hash(v, smask);
+            for (;;) {
+                unsigned long long old = atomicCAS(&slots[off + idx], (unsigned long long)SLOT_EMPTY, entry);
+                if (old == (unsigned long long)SLOT_EMPTY) break;
+                idx = (idx + 1) & smask;
+            }
+        }
     }
 }
 

@@ -69,6 +69,9 @@ struct pw_graph {
     void *d_data = nullptr;          // float32 (CSR graphs) or float64 (dense graphs); null when unit
     float *d_thr = nullptr;
     uint64_t *d_adjbits = nullptr;   // dense graphs: bit-packed adjacency rows
+    uint32_t *d_foff = nullptr;      // CSR graphs: per-row membership filters (offsets, bits)
+    uint64_t *d_fbits = nullptr;
+    uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -162,6 +165,10 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_data) (void)hipFree(g->d_data);
     if (g->d_thr) (void)hipFree(g->d_thr);
     if (g->d_adjbits) (void)hipFree(g->d_adjbits);
+    if (g->d_foff) (void)hipFree(g->d_foff);
+    if (g->d_fbits) (void)hipFree(g->d_fbits);
+    if (g->d_tab_off) (void)hipFree(g->d_tab_off);
+    if (g->d_slots) (void)hipFree(g->d_slots);
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -228,6 +235,56 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
     if (!rc && !unit) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
     if (rc) { pw_graph_destroy(g); return rc; }
+    {   // per-row membership filters
+        std::vector<uint32_t> foff((size_t)n_nodes + 1);
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            foff[i] = (uint32_t)run;
+            run += pw::filter_words_for_degree(indptr[i + 1] - indptr[i]);
+        }
+        if (run >= 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit filter offsets"); }
+        foff[n_nodes] = (uint32_t)run;
+        rc = up((void **)&g->d_foff, foff.data(), sizeof(uint32_t) * foff.size());
+        if (!rc) {
+            hipError_t e = hipMalloc((void **)&g->d_fbits, sizeof(uint64_t) * (run ? run : 1));
+            if (e == hipSuccess) e = hipMemsetAsync(g->d_fbits, 0, sizeof(uint64_t) * (run ? run : 1), g->stream);
+            if (e == hipSuccess && n_nodes) {
+                hipLaunchKernelGGL(pw::filter_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
+                                   g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, n_nodes);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+            if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("membership filter build: ") + hipGetErrorString(e));
+        }
+        if (rc) { pw_graph_destroy(g); return rc; }
+    }
+    {   // adjacency index: per-row open-addressing table of next_pow2(2 * degree) slots
+        std::vector<uint64_t> off((size_t)n_nodes + 1);
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            off[i] = run;
+            uint32_t d = indptr[i + 1] - indptr[i];
+            if (d) {
+                uint64_t sz = 2;
+                while (sz < 2ull * d) sz <<= 1;
+                run += sz;
+            }
+        }
+        off[n_nodes] = run;
+        rc = up((void **)&g->d_tab_off, off.data(), sizeof(uint64_t) * off.size());
+        if (!rc) {
+            hipError_t e = hipMalloc((void **)&g->d_slots, sizeof(uint64_t) * (run ? run : 1));
+            if (e == hipSuccess) e = hipMemsetAsync(g->d_slots, 0xff, sizeof(uint64_t) * (run ? run : 1), g->stream);
+            if (e == hipSuccess && n_nodes) {
+                hipLaunchKernelGGL(pw::adj_index_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
+                                   g->d_indices, g->d_tab_off, (unsigned long long *)g->d_slots, n_nodes);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+            if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("adjacency index build: ") + hipGetErrorString(e));
+        }
+        if (rc) { pw_graph_destroy(g); return rc; }
+    }
     *out = g;
     return PW_OK;
 }
@@ -341,6 +398,10 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.data = g->d_data;
     c.thr = g->d_thr;
     c.adjbits = g->d_adjbits;
+    c.foff = g->d_foff;
+    c.fbits = g->d_fbits;
+    c.tab_off = g->d_tab_off;
+    c.slots = g->d_slots;
     c.words_per_row = g->words_per_row;
     c.n_nodes = g->n_nodes;
     c.nnz = g->nnz;

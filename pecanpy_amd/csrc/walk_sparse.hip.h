@@ -35,6 +35,18 @@ struct CsrDev {
     // row set <=> nonzero[u, x].  Membership of x in N(prev) is one bit test instead of a search.
     const uint64_t *__restrict__ adjbits;
     uint32_t words_per_row;
+    // per-row membership filter (blocked Bloom, 2 bits per neighbour inside one 64-bit word, 4-8
+    // filter bits per neighbour): row u owns words [foff[u], foff[u+1]) of fbits (a power of two).
+    // "x is a neighbour of u" is answered negatively with ONE cache-line access for ~90 % of the
+    // non-neighbours; only the survivors pay the log2(d) probes of the exact search.
+    const uint32_t *__restrict__ foff;
+    const uint64_t *__restrict__ fbits;
+    // exact adjacency index for the filter survivors: row u owns slots [tab_off[u], tab_off[u+1]) of an
+    // open-addressing table (size next_pow2(2*degree)); slot = (position in row u) << 32 | neighbour id,
+    // all ones = empty.  One probe (rarely two) replaces the ~log2(d) dependent probes of a binary
+    // search -- the per-step critical path is a chain of memory latencies, not bandwidth.
+    const uint64_t *__restrict__ tab_off;
+    const uint64_t *__restrict__ slots;
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -75,6 +87,45 @@ struct WalkArgs {
     unsigned long long *stats;  // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
 };
 
+__device__ __forceinline__ uint32_t filter_hash(uint32_t v) {
+    uint32_t h = v * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h;
+}
+// word index inside the row's filter and the two-bit pattern of v
+__device__ __forceinline__ uint32_t filter_word(uint32_t h, uint32_t nw_mask) { return (h >> 12) & nw_mask; }
+__device__ __forceinline__ uint64_t filter_bits(uint32_t h) { return (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)); }
+__host__ __device__ inline uint32_t filter_words_for_degree(uint32_t d) {
+    if (d == 0) return 0;
+    uint32_t p = 1;
+    while (p < d) p <<= 1;      // next power of two >= d
+    return p >= 8 ? p / 8 : 1;  // 8 filter bits per (rounded) neighbour, at least one word
+}
+
+constexpr uint64_t SLOT_EMPTY = ~0ull;
+__device__ __forceinline__ uint32_t adj_hash(uint32_t v, uint32_t size_mask) {
+    uint32_t h = v * 0x85EBCA6Bu;  // independent of filter_hash
+    h ^= h >> 16;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 15;
+    return h & size_mask;
+}
+// position of v in the row that owns `tab`, or 0xffffffff
+__device__ __forceinline__ uint32_t adj_lookup(const uint64_t *__restrict__ tab, uint32_t size_mask, uint32_t v,
+                                               bool active) {
+    uint32_t idx = adj_hash(v, size_mask);
+    uint32_t res = 0xffffffffu;
+    while (active) {
+        const uint64_t e = tab[idx];
+        if (e == SLOT_EMPTY) active = false;
+        else if ((uint32_t)e == v) { res = (uint32_t)(e >> 32); active = false; }
+        else idx = (idx + 1) & size_mask;
+    }
+    return res;
+}
+
 constexpr int WAVES_PER_BLOCK = 4;
 #ifndef PW_MASK_WORDS
 #define PW_MASK_WORDS 512
@@ -92,6 +143,9 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
 __device__ __forceinline__ double uni(double v) {
     return __longlong_as_double((long long)readfirst_u64((uint64_t)__double_as_longlong(v)));
 }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(readfirst_u32(__float_as_uint(v))); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) { return readfirst_u64(v); }
+__device__ __forceinline__ bool uni(bool v) { return readfirst_u32(v ? 1u : 0u) != 0u; }
 
 // ---- lower_bound over a sorted global row; every lane searches its own key --------------------
 // Branch-free form with a wave-uniform trip count (n only depends on the row length).
@@ -145,80 +199,103 @@ __device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict_
 // position of `prev` itself inside the segment, or NOT_FOUND.
 // node2vec+ (in_mask != nullptr): a second bitmask marks the common neighbours x whose edge
 // prev->x is not "noisy", w(prev, x) >= thr[x] (in-edges, isnotin_extended, sparse_rw.py:233-295).
+//
+// The entries of the shorter row are the keys, the longer row is searched.  Keys first pass the
+// searched row's Bloom filter (one cache-line access each); the survivors (true members + a few
+// false positives, typically < 20 % of the keys) are compacted into an LDS queue and only they
+// pay the log2(d) probes of the exact binary search.
+constexpr uint32_t QCAP = 128;  // survivor queue entries per wave (key, tag)
+constexpr uint32_t TAG_PREV = 0xffffffffu;
+
 template <typename T>
-__device__ __forceinline__ uint32_t build_mask(const uint32_t *__restrict__ indices, uint32_t *mask,
-                                               uint32_t s0, uint32_t a, uint32_t len, uint32_t t0,
-                                               uint32_t dp, uint32_t prev, uint32_t *in_mask = nullptr,
-                                               const T *__restrict__ data = nullptr,
-                                               const float *__restrict__ thr = nullptr) {
+__device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, uint32_t *queue, uint32_t cur,
+                                               uint32_t prev, uint32_t s0, uint32_t a, uint32_t len,
+                                               uint32_t t0, uint32_t dp, uint32_t *in_mask,
+                                               const T *__restrict__ data) {
     const int lane = lane_id();
-    const uint32_t *__restrict__ crow = indices + s0 + a;
-    const uint32_t *__restrict__ prow = indices + t0;
+    const uint32_t *__restrict__ crow = g.indices + s0 + a;
+    const uint32_t *__restrict__ prow = g.indices + t0;
+    const float *__restrict__ thr = g.thr;
     uint32_t prev_pos = NOT_FOUND;
     const uint32_t nwords = (len + 31) >> 5;
-    if (dp <= len) {
-        // scatter: every neighbour of prev (plus prev itself) looks itself up in cur's segment
-        for (uint32_t w = lane; w < nwords; w += WAVE) {
-            mask[w] = 0;
-            if (in_mask) in_mask[w] = 0;
+    for (uint32_t w = lane; w < nwords; w += WAVE) {
+        mask[w] = 0;
+        if (in_mask) in_mask[w] = 0;
+    }
+    const bool scatter = dp <= len;                       // keys = row(prev), searched = cur's segment
+    const uint32_t *__restrict__ krow = scatter ? prow : crow;
+    const uint32_t kn = scatter ? dp : len;
+    const uint32_t *__restrict__ srow = scatter ? crow : prow;
+    const uint32_t sn = scatter ? len : dp;
+    const uint32_t sv = scatter ? cur : prev;
+    const uint32_t f0 = uni(g.foff[sv]);
+    const uint32_t nw_mask = uni(g.foff[sv + 1]) - f0 - 1u;
+    const uint64_t *__restrict__ fb = g.fbits + f0;
+    uint32_t *qkey = queue, *qtag = queue + QCAP;
+    uint32_t qn = 0;
+    wave_lds_fence();
+
+    // exact lookup of the queued survivors in the searched row's adjacency index
+    const uint64_t tb0 = readfirst_u64(g.tab_off[sv]);
+    const uint32_t tmask = (uint32_t)(readfirst_u64(g.tab_off[sv + 1]) - tb0) - 1u;
+    const uint64_t *__restrict__ tab = g.slots + tb0;
+    const uint32_t seg_lo = scatter ? a : 0u;                 // positions returned are row-global
+    auto flush = [&](uint32_t count) {
+        wave_lds_fence();
+        for (uint32_t base = 0; base < count; base += WAVE) {
+            const uint32_t e = base + lane;
+            const bool valid = e < count;
+            const uint32_t key = valid ? qkey[e] : 0u;
+            const uint32_t tag = valid ? qtag[e] : 0u;
+            const uint32_t gpos = adj_lookup(tab, tmask, key, valid);
+            if (scatter) {
+                // tag = index of the key in row(prev); gpos = position in cur's row
+                const bool found = gpos != 0xffffffffu && gpos >= seg_lo && gpos < seg_lo + len;
+                const uint32_t rel = gpos - seg_lo;
+                if (found && tag != TAG_PREV) {
+                    atomicOr(&mask[rel >> 5], 1u << (rel & 31));
+                    if (in_mask && Arith<T>::in_edge(data[t0 + tag], thr[key])) atomicOr(&in_mask[rel >> 5], 1u << (rel & 31));
+                }
+                const uint64_t pb = ballot(found && tag == TAG_PREV);
+                if (pb) prev_pos = readlane_u32(gpos, __builtin_ctzll(pb));
+            } else if (gpos != 0xffffffffu) {
+                // tag = position of the key in cur's segment; gpos = index in row(prev)
+                atomicOr(&mask[tag >> 5], 1u << (tag & 31));
+                if (in_mask && Arith<T>::in_edge(data[t0 + gpos], thr[key])) atomicOr(&in_mask[tag >> 5], 1u << (tag & 31));
+            }
         }
         wave_lds_fence();
-        for (uint32_t base = 0; base <= dp; base += WAVE * MLP) {
-            const uint32_t nj = (dp + 1 - base + WAVE - 1) / WAVE;  // live chains (uniform)
-            uint32_t key[MLP], pos[MLP];
-#pragma unroll
-            for (int j = 0; j < MLP; j++) {
-                uint32_t i = base + (uint32_t)j * WAVE + lane;
-                key[j] = ((uint32_t)j < nj && i < dp) ? prow[i] : prev;
-            }
-            lower_bound_dispatch(crow, len, key, pos, nj);
-#pragma unroll
-            for (int j = 0; j < MLP; j++) {
-                if ((uint32_t)j < nj) {
-                    uint32_t i = base + (uint32_t)j * WAVE + lane;
-                    bool found = i <= dp && pos[j] < len && crow[pos[j] < len ? pos[j] : 0] == key[j];
-                    if (found && i < dp) {
-                        atomicOr(&mask[pos[j] >> 5], 1u << (pos[j] & 31));
-                        if (in_mask && Arith<T>::in_edge(data[t0 + i], thr[key[j]])) atomicOr(&in_mask[pos[j] >> 5], 1u << (pos[j] & 31));
-                    }
-                    uint64_t pb = ballot(found && i == dp);
-                    if (pb) prev_pos = a + readlane_u32(pos[j], __builtin_ctzll(pb));
-                }
-            }
+    };
+
+    if (scatter) {  // prev itself is looked up in cur's row (no filter: it is almost always there)
+        if (lane == 0) { qkey[0] = prev; qtag[0] = TAG_PREV; }
+        qn = 1;
+    }
+    for (uint32_t base = 0; base < kn; base += WAVE) {
+        const uint32_t i = base + lane;
+        const bool valid = i < kn;
+        const uint32_t key = valid ? krow[i] : 0u;
+        const uint32_t h = filter_hash(key);
+        const uint64_t bits = filter_bits(h);
+        const uint64_t word = valid ? fb[filter_word(h, nw_mask)] : 0ull;
+        const bool pass = valid && (word & bits) == bits;
+        if (!scatter) {
+            const uint64_t pb = ballot(valid && key == prev);
+            if (pb) prev_pos = a + base + (uint32_t)__builtin_ctzll(pb);
         }
-    } else {
-        // gather: every neighbour of cur in the segment looks itself up in prev's row
-        for (uint32_t base = 0; base < len; base += WAVE * MLP) {
-            const uint32_t nj = (len - base + WAVE - 1) / WAVE;
-            uint32_t key[MLP], pos[MLP];
-#pragma unroll
-            for (int j = 0; j < MLP; j++) {
-                uint32_t k = base + (uint32_t)j * WAVE + lane;
-                key[j] = ((uint32_t)j < nj && k < len) ? crow[k] : 0u;
-            }
-            lower_bound_dispatch(prow, dp, key, pos, nj);
-#pragma unroll
-            for (int j = 0; j < MLP; j++) {
-                if ((uint32_t)j < nj) {
-                    uint32_t kb = base + (uint32_t)j * WAVE;
-                    uint32_t k = kb + lane;
-                    bool valid = k < len;
-                    bool found = valid && pos[j] < dp && prow[pos[j] < dp ? pos[j] : 0] == key[j];
-                    uint64_t fb = ballot(found);
-                    if (lane == 0) mask[kb >> 5] = (uint32_t)fb;
-                    if (lane == 32) mask[(kb >> 5) + 1] = (uint32_t)(fb >> 32);
-                    if (in_mask) {
-                        bool is_in = found && Arith<T>::in_edge(data[t0 + pos[j]], thr[key[j]]);
-                        uint64_t ib = ballot(is_in);
-                        if (lane == 0) in_mask[kb >> 5] = (uint32_t)ib;
-                        if (lane == 32) in_mask[(kb >> 5) + 1] = (uint32_t)(ib >> 32);
-                    }
-                    uint64_t pb = ballot(valid && key[j] == prev);
-                    if (pb) prev_pos = a + kb + __builtin_ctzll(pb);
-                }
-            }
+        const uint64_t sb = ballot(pass);
+        if (pass) {
+            const uint32_t slot = qn + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull));
+            qkey[slot] = key;
+            qtag[slot] = i;
+        }
+        qn += (uint32_t)__popcll(sb);
+        if (qn > QCAP - WAVE) {
+            flush(qn);
+            qn = 0;
         }
     }
+    if (qn) flush(qn);
     wave_lds_fence();
     return prev_pos;
 }
@@ -445,14 +522,20 @@ __device__ __forceinline__ bool seq_head(T &c, uint32_t &k, uint32_t kend, doubl
     uint32_t n = kend - k < head ? kend - k : head;
     T v = (lane < (int)n) ? (T)vals.one(k + lane) : (T)0;
     T cc = c;
-    for (uint32_t j = 0; j < n; j++) cc = cc + readlane_fp<T>(v, (int)j);
+    if (n == WAVE) {  // full head: straight-line code (no loop control on the scalar unit)
+#pragma unroll
+        for (int j = 0; j < WAVE; j++) cc = cc + readlane_fp<T>(v, j);
+    } else {
+        for (uint32_t j = 0; j < n; j++) cc = cc + readlane_fp<T>(v, (int)j);
+    }
+    cc = uni(cc);
     if (!HAS_TARGET || (double)cc < r) {
         c = cc;
         k += n;
         return false;
     }
     for (uint32_t j = 0; j < n; j++) {
-        c = c + readlane_fp<T>(v, (int)j);
+        c = uni(c + readlane_fp<T>(v, (int)j));
         if ((double)c >= r) { found = k + j; return true; }
     }
     k += n;  // unreachable: cc >= r guarantees a hit above
@@ -548,10 +631,14 @@ __device__ __forceinline__ int unit_chain(T &c, uint32_t &k, uint32_t kend, doub
     using B = Binade<T>;
     using U = typename B::UInt;
     const int lane = lane_id();
+    x_in = uni(x_in);
+    x_out = uni(x_out);
+    x_prev = uni(x_prev);
+    c = uni(c);
     while (k < kend) {
         const int eb = B::eb_of(c);
         const U C = B::sig_of(c);
-        const U Tt = HAS_TARGET ? B::threshold(r, eb) : B::TOP;
+        const U Tt = HAS_TARGET ? uni(B::threshold(r, eb)) : B::TOP;
         const Inc<T> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb), qp = B::quantize(x_prev, eb);
         const bool prev_in = ur.has_prev && ur.prev_pos != NOT_FOUND && ur.prev_pos >= k && ur.prev_pos < kend;
         // ties are parity dependent: hand this binade to the generic element scan (rare)
@@ -561,7 +648,7 @@ __device__ __forceinline__ int unit_chain(T &c, uint32_t &k, uint32_t kend, doub
             continue;
         }
         const U ii = qi.a0, io = qo.a0, ipv = qp.a0;
-        const uint32_t rk0 = ur.rank_at(k);
+        const uint32_t rk0 = uni(ur.rank_at(k));
         uint32_t lo = k, hi = kend - 1, kf = 0;
         uint64_t Cf = 0;
         bool crossed = true;
@@ -592,15 +679,15 @@ __device__ __forceinline__ int unit_chain(T &c, uint32_t &k, uint32_t kend, doub
             break;
         }
         const bool f_prev = prev_in && kf == ur.prev_pos;
-        const bool f_in = !f_prev && ur.bit_at(kf);
+        const bool f_in = !f_prev && uni(ur.bit_at(kf)) != 0u;
         const T xf = f_prev ? x_prev : (f_in ? x_in : x_out);
         // value just before element kf (exact: every element before kf kept the sum below Tt)
-        const uint32_t cin0 = ur.rank_at(kf) - rk0;
+        const uint32_t cin0 = uni(ur.rank_at(kf)) - rk0;
         const uint32_t cpv0 = (prev_in && ur.prev_pos < kf) ? 1u : 0u;
         const uint32_t cout0 = (kf - k) - cin0 - cpv0;
         const uint64_t Cprev = (uint64_t)C + chain_term<U>(cin0, ii) + chain_term<U>(cout0, io) + chain_term<U>(cpv0, ipv);
         if (Cf < (uint64_t)B::TOP) { c = B::make((U)Cf, eb); found = kf; return SCAN_FOUND; }
-        c = B::make((U)Cprev, eb) + xf;
+        c = uni(B::make((U)Cprev, eb) + xf);
         k = kf + 1;
         if (HAS_TARGET && (double)c >= r) { found = kf; return SCAN_FOUND; }
     }
@@ -614,22 +701,22 @@ template <typename T> __device__ __forceinline__ bool is_pow2_fp(T x) {
 
 // Membership mask of one segment: search-based (sparse) or bit-test based (dense adjacency bits).
 template <typename T, bool DENSE>
-__device__ __forceinline__ uint32_t segment_mask(const CsrDev &g, uint32_t *mask, uint32_t *in_mask, uint32_t s0,
-                                                 uint32_t sa, uint32_t len, uint32_t t0, uint32_t dp,
-                                                 uint32_t prev) {
+__device__ __forceinline__ uint32_t segment_mask(const CsrDev &g, uint32_t *mask, uint32_t *in_mask,
+                                                 uint32_t *queue, uint32_t cur, uint32_t s0, uint32_t sa,
+                                                 uint32_t len, uint32_t t0, uint32_t dp, uint32_t prev) {
     const T *__restrict__ data = (const T *)g.data;
     if (DENSE) return build_mask_bits<T>(g, mask, s0, sa, len, t0, dp, prev, in_mask, data);
-    return build_mask<T>(g.indices, mask, s0, sa, len, t0, dp, prev, in_mask, data, g.thr);
+    return build_mask<T>(g, mask, queue, cur, prev, s0, sa, len, t0, dp, in_mask, data);
 }
 
 // Membership structures (mask + rank) of one segment; returns prev's position (global) or
 // NOT_FOUND.  known_prev_pos: position found by the caller for segmented rows (else NOT_FOUND).
 template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t prepare_unit_segment(const CsrDev &g, uint32_t *mask, uint16_t *rank,
-                                                         uint32_t s0, uint32_t sa, uint32_t len, uint32_t t0,
+                                                         uint32_t *queue, uint32_t cur, uint32_t s0, uint32_t sa, uint32_t len, uint32_t t0,
                                                          uint32_t dp, uint32_t prev, bool multi,
                                                          uint32_t known_prev_pos) {
-    uint32_t pp = segment_mask<T, DENSE>(g, mask, nullptr, s0, sa, len, t0, dp, prev);
+    uint32_t pp = segment_mask<T, DENSE>(g, mask, nullptr, queue, cur, s0, sa, len, t0, dp, prev);
     if (multi) pp = known_prev_pos;
     if (pp != NOT_FOUND && pp >= sa && pp < sa + len) {
         uint32_t rr = pp - sa;  // keep the three classes disjoint
@@ -667,11 +754,11 @@ __device__ __forceinline__ RowVals<T, true> make_unit_vals(const uint32_t *mask,
 // (t0, dp) = CSR row of prev, carried over from the previous step by the caller.
 template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t *mask, uint16_t *rank,
-                                                     bool has_prev, uint32_t prev, uint32_t t0,
+                                                     uint32_t *queue, uint32_t cur, bool has_prev, uint32_t prev, uint32_t t0,
                                                      uint32_t dp, double r, uint32_t s0, uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
-    const T w_in = (T)1, w_out = has_prev ? Arith<T>::bias_div((T)1, a.q) : (T)1,
-            w_prev = Arith<T>::bias_div((T)1, a.p);
+    const T w_in = (T)1, w_out = has_prev ? uni(Arith<T>::bias_div((T)1, a.q)) : (T)1,
+            w_prev = uni(Arith<T>::bias_div((T)1, a.p));
 
     const bool multi = has_prev && d > SEG;
     uint32_t prev_pos = NOT_FOUND;
@@ -684,11 +771,11 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
     T tot = (T)0;
     bool have_tot = false;
     if (!multi) {
-        if (has_prev) prev_pos = prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, 0, d, t0, dp, prev, false, NOT_FOUND);
+        if (has_prev) prev_pos = prepare_unit_segment<T, DENSE>(a.g, mask, rank, queue, cur, s0, 0, d, t0, dp, prev, false, NOT_FOUND);
         const UnitRow ur{mask, rank, 0u, d, prev_pos, has_prev};
         // all partial sums are exact when the weights are dyadic and the total fits the mantissa of
         // the smallest weight: then the left-to-right sum equals the exact sum.
-        const uint32_t n_in = has_prev ? ur.rank_at(d) : 0u;
+        const uint32_t n_in = has_prev ? uni(ur.rank_at(d)) : 0u;
         const uint32_t n_pv = (has_prev && prev_pos != NOT_FOUND) ? 1u : 0u;
         const uint32_t n_out = d - n_in - n_pv;
         if ((n_out == 0 || is_pow2_fp<T>(w_out)) && (n_pv == 0 || is_pow2_fp<T>(w_prev))) {
@@ -696,13 +783,13 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
             if (n_out && w_out < u) u = w_out;
             if (n_pv && w_prev < u) u = w_prev;
             double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
-            if (td / (double)u <= (double)Binade<T>::TOP) { tot = (T)td; have_tot = true; }
+            if (uni(td / (double)u <= (double)Binade<T>::TOP)) { tot = uni((T)td); have_tot = true; }
         }
     }
     if (!have_tot) {
         for (uint32_t sa = 0; sa < d; sa += SEG) {
             const uint32_t len = d - sa < SEG ? d - sa : SEG;
-            if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+            if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, queue, cur, s0, sa, len, t0, dp, prev, true, prev_pos);
             const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
             const RowVals<T, true> rv = make_unit_vals<T>(mask, sa, sa + len, prev_pos, has_prev, w_in, w_out, w_prev);
             uint32_t k = sa, found = NOT_FOUND;
@@ -712,12 +799,13 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
     }
 
     // ---- cdf search ----------------------------------------------------------------------------------
-    const T x_in = w_in / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    tot = uni(tot);
+    const T x_in = uni(w_in / tot), x_out = uni(w_out / tot), x_prev = uni(w_prev / tot);
     T c = (T)0;
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         const uint32_t len = d - sa < SEG ? d - sa : SEG;
         // single segment: mask and rank from the tot phase are still valid
-        if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, s0, sa, len, t0, dp, prev, true, prev_pos);
+        if (multi) (void)prepare_unit_segment<T, DENSE>(a.g, mask, rank, queue, cur, s0, sa, len, t0, dp, prev, true, prev_pos);
         const UnitRow ur{mask, rank, sa, len, prev_pos, has_prev};
         const RowVals<T, true> rv = make_unit_vals<T>(mask, sa, sa + len, prev_pos, has_prev, x_in, x_out, x_prev);
         uint32_t k = sa, found = NOT_FOUND;
@@ -731,7 +819,7 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
 // Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
 template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, uint32_t *in_mask,
-                                                         uint32_t cur, bool has_prev, uint32_t prev,
+                                                         uint32_t *queue, uint32_t cur, bool has_prev, uint32_t prev,
                                                          uint32_t t0, uint32_t dp, double r, uint32_t s0,
                                                          uint32_t d) {
     const uint32_t *__restrict__ indices = a.g.indices;
@@ -769,7 +857,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     for (uint32_t sa = 0; sa < d; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
         if (has_prev) {
-            uint32_t pp = segment_mask<T, DENSE>(a.g, mask, in_mask, s0, sa, len, t0, dp, prev);
+            uint32_t pp = segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);
             if (!multi) rv.prev_pos = pp;
         }
         rv.seg_a = sa;
@@ -784,7 +872,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     uint32_t choice = NOT_FOUND;
     for (uint32_t sa = 0; sa < d && choice == NOT_FOUND; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, s0, sa, len, t0, dp, prev);  // single segment: still valid
+        if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
         choice = seq_scan<T, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
@@ -806,9 +894,11 @@ walk_kernel(WalkArgs a) {
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
     __shared__ uint16_t s_rank[UNIT ? WAVES_PER_BLOCK : 1][UNIT ? MASK_WORDS + 2 : 2];
     __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue[DENSE ? 1 : WAVES_PER_BLOCK][DENSE ? 2 : 2 * QCAP];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     uint32_t *mask = s_mask[wave];
+    uint32_t *queue = s_queue[DENSE ? 0 : wave];
     uint16_t *rank = s_rank[UNIT ? wave : 0];
     const uint32_t *__restrict__ indptr = a.g.indptr;
     const uint32_t *__restrict__ indices = a.g.indices;
@@ -845,8 +935,8 @@ walk_kernel(WalkArgs a) {
             }
             const double r = readlane_f64(rbuf, (int)jr);
             uint32_t choice;
-            if (UNIT) choice = sample_step_unit<T, DENSE>(a, mask, rank, j >= 2, prev, t0, dp, r, s0, d);
-            else choice = sample_step_weighted<T, DENSE>(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, cur,
+            if (UNIT) choice = sample_step_unit<T, DENSE>(a, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
+            else choice = sample_step_weighted<T, DENSE>(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, queue, cur,
                                                           j >= 2, prev, t0, dp, r, s0, d);
             if (choice >= d) {
                 st_over++;
