@@ -203,7 +203,7 @@ __device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict_
 // The entries of the shorter row are the keys, the longer row is searched.  Keys first pass the
 // searched row's Bloom filter (one cache-line access each); the survivors (true members + a few
 // false positives, typically < 20 % of the keys) are compacted into an LDS queue and only they
-// pay the log2(d) probes of the exact binary search.
+// are looked up exactly, in the searched row's adjacency hash index (one probe, rarely two).
 constexpr uint32_t QCAP = 128;  // survivor queue entries per wave (key, tag)
 constexpr uint32_t TAG_PREV = 0xffffffffu;
 
@@ -225,8 +225,6 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
     const bool scatter = dp <= len;                       // keys = row(prev), searched = cur's segment
     const uint32_t *__restrict__ krow = scatter ? prow : crow;
     const uint32_t kn = scatter ? dp : len;
-    const uint32_t *__restrict__ srow = scatter ? crow : prow;
-    const uint32_t sn = scatter ? len : dp;
     const uint32_t sv = scatter ? cur : prev;
     const uint32_t f0 = uni(g.foff[sv]);
     const uint32_t nw_mask = uni(g.foff[sv + 1]) - f0 - 1u;
