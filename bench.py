@@ -161,14 +161,28 @@ def main():
     alg_bytes = algorithmic_bytes(d_out, deg_t, L)
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE), when this
+    # exact workload was profiled (profiles/r01_traffic.json); PMC cannot be collected in a timed run
+    traffic = None
+    traffic_note = "no PMC pass committed for this workload"
+    key = f"rmat{args.scale}_p{args.p:g}_q{args.q:g}_w{W}_l{L}_seed{args.seed}"
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f)["workloads"].get(key)
+        if tj and world == 1 and not args.weighted:
+            traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
+            traffic_note = ("FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch "
+                            "(profiles/r01_rmat22_pmc_v6.txt), uncorrected (scattered 4-8 B/lane probes)")
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {
-        "bound": "hbm", "kernel": "walk_sparse_kernel", "achieved": round(achieved, 1),
+        "bound": "hbm", "kernel": "walk_kernel<float,false,true,false>", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+        "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": round(k_ms, 3), "rng_expand_ms": round(float(np.mean(rng_ms)), 3),
         "note": "algorithmic bytes = sum over sampled steps of 8*d_cur+4*d_prev+28 (SURVEY 8(d)); "
-                "the kernel probes rows by binary search instead of streaming them, so achieved can "
-                "exceed what HBM counters show",
+                "the kernel never streams rows (Bloom filter + hash index probes, closed-form CDF), "
+                "so the HBM counters show about half of the algorithmic bytes",
     }
 
     cpu = None
@@ -176,12 +190,12 @@ def main():
         from oracle import pyoracle as orc
 
         cores = os.cpu_count() or 1
-        probe = starts[: 2000]
+        probe = starts[: 20000]
         t = time.perf_counter()
         s, _ = orc.cpu_baseline_walks(indptr, indices, data, args.p, args.q, probe, L, args.seed,
                                       n_threads=cores, faithful=True)
         rate = max(s, 1) / (time.perf_counter() - t)
-        n_sample = int(min(n_jobs, max(2000, rate * args.cpu_seconds / max(s / probe.size, 1e-9))))
+        n_sample = int(min(n_jobs, max(20000, rate * args.cpu_seconds / max(s / probe.size, 1e-9))))
         sample = starts[:n_sample]
         t = time.perf_counter()
         s_f, _ = orc.cpu_baseline_walks(indptr, indices, data, args.p, args.q, sample, L, args.seed,

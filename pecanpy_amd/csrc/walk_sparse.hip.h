@@ -6,10 +6,10 @@
 //
 //   1. membership  : which neighbours of `cur` are also neighbours of `prev`
 //                    (reference: two-pointer isnotin, sparse_rw.py:142-230).  Done here by
-//                    binary-searching the *shorter* of the two sorted rows into the longer one
-//                    (min(d_cur,d_prev) * log2(max) probes, several independent probe chains per
-//                    lane) and recording the result as one bit per neighbour of `cur` in an LDS
-//                    bitmask owned by the wave.
+//                    streaming the *shorter* of the two sorted rows and testing each entry
+//                    against the longer row's Bloom filter; survivors are looked up in that
+//                    row's adjacency hash index.  The result is one bit per neighbour of `cur`
+//                    in an LDS bitmask owned by the wave.
 //   2. tot         : sequential float32 sum of the biased weights      (sparse_rw.py:89)
 //   3. cdf search  : first k with cumsum(w/tot)[k] >= r, sequential float32 (pecanpy.py:556-557)
 //   4. next        : indices[indptr[cur] + k], k == degree mirrored     (pecanpy.py:559, App. D)
@@ -134,10 +134,6 @@ constexpr int MASK_WORDS = PW_MASK_WORDS;        // per wave: 32*MASK_WORDS neig
 constexpr uint32_t SEG = MASK_WORDS * 32;
 constexpr int EPL = 4;                           // elements per lane per generic scan pass
 constexpr uint32_t NOT_FOUND = 0xffffffffu;
-#ifndef PW_MLP
-#define PW_MLP 4
-#endif
-constexpr int MLP = PW_MLP;                      // independent probe chains per lane
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
 __device__ __forceinline__ double uni(double v) {
@@ -159,39 +155,6 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__
         len -= half;
     }
     return lo + ((base[lo] < key) ? 1u : 0u);
-}
-
-// NJ independent searches per lane, advanced in lockstep: the probe chain of one search is a
-// string of dependent L2/HBM loads, so several chains per lane are what hides the latency.
-template <int NJ>
-__device__ __forceinline__ void lower_bound_multi(const uint32_t *__restrict__ base, uint32_t n,
-                                                  const uint32_t (&key)[MLP], uint32_t (&lo)[MLP]) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) lo[j] = 0;
-    if (n == 0) return;
-    uint32_t len = n;
-    while (len > 1) {
-        uint32_t half = len >> 1;
-        uint32_t v[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) v[j] = base[lo[j] + half - 1];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) lo[j] = (v[j] < key[j]) ? lo[j] + half : lo[j];
-        len -= half;
-    }
-    uint32_t v[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) v[j] = base[lo[j]];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) lo[j] += (v[j] < key[j]) ? 1u : 0u;
-}
-
-__device__ __forceinline__ void lower_bound_dispatch(const uint32_t *__restrict__ base, uint32_t n,
-                                                     const uint32_t (&key)[MLP], uint32_t (&lo)[MLP],
-                                                     uint32_t nj) {
-    if (MLP >= 4 && nj > 2) lower_bound_multi<MLP>(base, n, key, lo);
-    else if (MLP >= 2 && nj > 1) lower_bound_multi<(MLP >= 2 ? 2 : 1)>(base, n, key, lo);
-    else lower_bound_multi<1>(base, n, key, lo);
 }
 
 // ---- step 1: membership bitmask of one segment [a, a+len) of cur's row ---------------------------
