@@ -122,7 +122,8 @@ mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 filter_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                    const uint32_t *__restrict__ foff, unsigned long long *fbits, uint32_t n_nodes) {
+                    const uint32_t *__restrict__ foff, unsigned long long *fbits, uint32_t *ipos,
+                    uint32_t n_nodes, uint32_t nnz) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
     const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;
     const uint32_t lane = threadIdx.x & 63;
@@ -132,8 +133,10 @@ filter_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restr
         const uint32_t f0 = foff[u];
         const uint32_t nw_mask = foff[u + 1] - f0 - 1u;
         for (uint32_t k = lane; k < d; k += 64) {
-            const uint32_t h = filter_hash(indices[s0 + k]);
-            atomicOr(&fbits[f0 + filter_word(h, nw_mask)], (unsigned long long)filter_bits(h));
+            const uint32_t v = indices[s0 + k];
+            const uint32_t frac = (uint32_t)(((unsigned long long)indptr[v] << 32) / nnz);
+            ipos[s0 + k] = frac;
+            atomicOr(&fbits[f0 + filter_word(frac, nw_mask)], (unsigned long long)filter_bits(filter_hash(v)));
         }
     }
 }

@@ -39,8 +39,14 @@ struct CsrDev {
     // filter bits per neighbour): row u owns words [foff[u], foff[u+1]) of fbits (a power of two).
     // "x is a neighbour of u" is answered negatively with ONE cache-line access for ~90 % of the
     // non-neighbours; only the survivors pay the log2(d) probes of the exact search.
+    // The word a neighbour id maps to is ORDER PRESERVING: word = floor(W * F(v)) with F the degree CDF of
+    // the graph (F(v) = indptr[v] / nnz, stored per CSR entry as a 32-bit fraction in `ipos`, so it
+    // arrives with the coalesced key load).  A row's neighbours are spread roughly uniformly by F
+    // (neighbours are drawn ~ proportionally to degree), and the sorted keys of one wavefront load
+    // hit consecutive filter words: a handful of cache lines per 64 keys instead of 64.
     const uint32_t *__restrict__ foff;
     const uint64_t *__restrict__ fbits;
+    const uint32_t *__restrict__ ipos;   // ipos[e] = floor(2^32 * indptr[indices[e]] / nnz)
     // exact adjacency index for the filter survivors: row u owns slots [tab_off[u], tab_off[u+1]) of an
     // open-addressing table (size next_pow2(2*degree)); slot = (position in row u) << 32 | neighbour id,
     // all ones = empty.  One probe (rarely two) replaces the ~log2(d) dependent probes of a binary
@@ -95,7 +101,10 @@ __device__ __forceinline__ uint32_t filter_hash(uint32_t v) {
     return h;
 }
 // word index inside the row's filter and the two-bit pattern of v
-__device__ __forceinline__ uint32_t filter_word(uint32_t h, uint32_t nw_mask) { return (h >> 12) & nw_mask; }
+// nw = nw_mask + 1 words (power of two): the top log2(nw) bits of the 32-bit CDF fraction
+__device__ __forceinline__ uint32_t filter_word(uint32_t frac, uint32_t nw_mask) {
+    return nw_mask ? (frac >> (32 - __popc(nw_mask))) : 0u;
+}
 __device__ __forceinline__ uint64_t filter_bits(uint32_t h) { return (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)); }
 __host__ __device__ inline uint32_t filter_words_for_degree(uint32_t d) {
     if (d == 0) return 0;
@@ -187,6 +196,7 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
     }
     const bool scatter = dp <= len;                       // keys = row(prev), searched = cur's segment
     const uint32_t *__restrict__ krow = scatter ? prow : crow;
+    const uint32_t *__restrict__ kfrac = g.ipos + (scatter ? t0 : s0 + a);   // CDF fractions of the keys
     const uint32_t kn = scatter ? dp : len;
     const uint32_t sv = scatter ? cur : prev;
     const uint32_t f0 = uni(g.foff[sv]);
@@ -236,9 +246,9 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
         const uint32_t i = base + lane;
         const bool valid = i < kn;
         const uint32_t key = valid ? krow[i] : 0u;
-        const uint32_t h = filter_hash(key);
-        const uint64_t bits = filter_bits(h);
-        const uint64_t word = valid ? fb[filter_word(h, nw_mask)] : 0ull;
+        const uint32_t frac = valid ? kfrac[i] : 0u;
+        const uint64_t bits = filter_bits(filter_hash(key));
+        const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
         const bool pass = valid && (word & bits) == bits;
         if (!scatter) {
             const uint64_t pb = ballot(valid && key == prev);
