@@ -63,7 +63,8 @@ typedef struct {
     double walk_kernel_ms;    /* HIP-event time of the walk kernel launches of this call */
     double rng_kernel_ms;     /* HIP-event time of the MT19937 expansion kernels */
     uint32_t walk_kernel_launches;
-    uint32_t reserved;
+    uint32_t stream_addressing; /* 0: the reference's exact draw assignment; 1: nominal per-walk slots
+                                   (fallback on sink-heavy directed graphs) */
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */

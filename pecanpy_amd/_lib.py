@@ -22,11 +22,11 @@ class PwStats(C.Structure):
         ("walk_kernel_ms", C.c_double),
         ("rng_kernel_ms", C.c_double),
         ("walk_kernel_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("stream_addressing", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 MODE_IDS = {

@@ -654,15 +654,20 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     // 4. dead ends shift the stream addresses of every later walk: re-address and re-run the
     //    affected walks until the addressing is self-consistent (directed graphs only).
     uint64_t dead = h[4];
-    const uint64_t max_rounds = 256;
+    const uint64_t max_rounds = 32;
     while (dead > 0) {
         uint64_t tot2 = 0, n_changed = 0;
-        rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, true, &tot2, &n_changed);
+        const bool give_up = st.repair_rounds >= max_rounds;
+        // Each round makes a longer prefix of the job array final; on sink-heavy directed graphs that
+        // takes O(n_jobs) rounds (the single-stream semantics is inherently sequential there).  After
+        // max_rounds fall back to NOMINAL addressing: every walk owns a fixed slot of walk_length draws
+        // (reproducible under the seed and statistically equivalent, but no longer the reference's exact
+        // draw-for-draw assignment); reported through pw_stats.stream_addressing = 1.
+        rc = compute_offsets(g, d_starts, give_up ? nullptr : d_out, walk_length, n_jobs, stream_skip, true, &tot2,
+                             &n_changed);
         if (rc) return rc;
+        if (give_up) st.stream_addressing = 1;
         if (n_changed == 0) break;
-        if (st.repair_rounds >= max_rounds)
-            return fail(PW_ERR_UNSUPPORTED, "stream re-addressing after dead ends did not converge "
-                                            "(directed graph with many sinks)");
         st.repair_rounds++;
         wa.job_list = g->changed.p;
         wa.n_list = n_changed;
@@ -674,13 +679,22 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
         st.walk_kernel_ms += ms;
         st.walk_kernel_launches++;
+        if (give_up) break;
     }
     if (st.repair_rounds) {
         // statistics of the final, self-consistent matrix
         HIP_TRY(hipMemcpy(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost));
         uint64_t tot2 = 0;
-        rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, false, &tot2, nullptr);
-        if (rc) return rc;
+        if (!st.stream_addressing) {
+            rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, false, &tot2, nullptr);
+            if (rc) return rc;
+        } else {  // offsets stay nominal; count the steps from the lengths without touching them
+            std::vector<uint32_t> lens(n_jobs);
+            HIP_TRY(hipMemcpy2D(lens.data(), sizeof(uint32_t), d_out + walk_length + 1,
+                                sizeof(uint32_t) * ((size_t)walk_length + 2), sizeof(uint32_t), n_jobs,
+                                hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n_jobs; i++) tot2 += lens[i] - 1;
+        }
         st.total_steps = tot2;
     } else {
         st.total_steps = h[1];

@@ -299,6 +299,35 @@ def test_precomp_tables_match_oracle_bitwise():
         assert np.array_equal(got, want), _diff_report(got, want)
 
 
+def test_sink_heavy_directed_graph_falls_back_to_nominal_slots():
+    """Many mid-walk dead ends: exact single-stream addressing would need O(n_jobs) passes, so the engine
+    switches to one fixed slot of walk_length draws per walk (reported in the stats) -- still
+    deterministic, and every walk equals the oracle run of that walk alone at its slot."""
+    rng = np.random.default_rng(5)
+    n = 400
+    adj = rng.random((n, n)) < 0.02
+    np.fill_diagonal(adj, False)
+    adj[rng.choice(n, 160, replace=False), :] = False          # 40 % sinks
+    indptr = np.zeros(n + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(adj.sum(1))
+    indices = np.nonzero(adj)[1].astype(np.uint32)
+    data = np.ones(indices.size, dtype=np.float32)
+    L, seed = 30, 2
+    starts = orc.shuffled_starts(n, 8, seed)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    st = eng.last_stats
+    assert st["stream_addressing"] == 1 and st["dead_end_walks"] > 0
+    assert st["total_steps"] == int((got[:, -1].astype(np.int64) - 1).sum())
+    has = (indptr[1:] != indptr[:-1])[starts]
+    slot = np.concatenate([[0], np.cumsum(has)[:-1]]) * L
+    for i in rng.choice(starts.size, 60, replace=False):
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts[i:i + 1], L, seed, stream_skip=int(slot[i]))
+        assert np.array_equal(got[i], want[0]), i
+    again = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    assert np.array_equal(again, got)
+
+
 def test_mode_classes_drop_in():
     from pecanpy import pecanpy  # the alias package
     from ref_test_walk import IDS, MAT, WALKS
