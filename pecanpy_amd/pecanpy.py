@@ -124,11 +124,16 @@ class Base(BaseGraph):
             dist.broadcast_object_list(box, src=0)
             seed = box[0]
 
+        import torch.distributed as dist
+
+        host_comm = dist.get_backend() == "gloo"  # gloo moves CPU tensors; nccl (= RCCL) device tensors
+
         def run_shard(sl, skip):
             d_starts = torch.from_numpy(np.ascontiguousarray(sl).view(np.int32)).to(dev)
             out = eng.simulate_device(self._mode, self.p, self.q, self.extend, d_starts,
                                       walk_length, seed=seed, stream_skip=skip)
-            return out, eng.last_stats["total_steps"]
+            steps = eng.last_stats["total_steps"] if d_starts.numel() else 0
+            return (out.cpu() if host_comm else out), steps
 
         full = sharded_walk_matrix(run_shard, lambda sl: eng.count_stream_draws(sl, walk_length),
                                    starts, walk_length)

@@ -328,6 +328,43 @@ def test_sink_heavy_directed_graph_falls_back_to_nominal_slots():
     assert np.array_equal(again, got)
 
 
+def _sharded_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"            # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, data = rmat_csr(10, seed=6)
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, p=0.5, q=2, random_state=4)
+    mat = g.simulate_walks_array(3, 25)
+    if rank == 0:
+        ret["mat"] = mat
+    dist.destroy_process_group()
+
+
+def test_sharded_simulate_walks_two_ranks_one_gpu():
+    """End-to-end multi-process path (shard bounds, stream_skip, device kernels, gather) with two ranks
+    on the same GPU; communication over gloo because RCCL refuses two ranks on one device."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
+        indptr, indices, data = rmat_csr(10, seed=6)
+        starts = orc.shuffled_starts(indptr.size - 1, 3, 4)
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 25, 4)
+        assert np.array_equal(ret["mat"], want)
+
+
 def test_mode_classes_drop_in():
     from pecanpy import pecanpy  # the alias package
     from ref_test_walk import IDS, MAT, WALKS
