@@ -14,7 +14,40 @@ from .engine import WalkEngine
 from .graph import BaseGraph, DenseGraph, SparseGraph
 from .wrappers import Timer
 
-__all__ = ["Base", "FirstOrderUnweighted", "PreCompFirstOrder", "PreComp", "SparseOTF", "DenseOTF"]
+__all__ = ["Base", "FirstOrderUnweighted", "PreCompFirstOrder", "PreComp", "SparseOTF", "DenseOTF",
+           "WalkCorpus"]
+
+
+class WalkCorpus:
+    """Re-iterable view of a walk index matrix as sentences of node IDs.
+
+    ``simulate_walks`` has to materialise ``List[List[str]]`` (reference API, pecanpy.py:160); at
+    RMAT-22 scale that is ~3.4 G Python objects.  ``WalkCorpus`` keeps the ``uint32[n_jobs, L+2]``
+    matrix the GPU produced and maps rows to ID lists lazily, chunk by chunk, so gensim's
+    ``Word2Vec(corpus)`` (which iterates the corpus once per epoch) can stream it
+    (SURVEY.md section 8(f) rank 1).
+    """
+
+    def __init__(self, walk_idx_mat, node_ids, chunk=65536):
+        self.matrix = walk_idx_mat
+        self._ids = np.asarray(node_ids, dtype=object)
+        self._chunk = int(chunk)
+
+    def __len__(self):
+        return int(self.matrix.shape[0])
+
+    def __iter__(self):
+        mat, ids = self.matrix, self._ids
+        last = mat.shape[1] - 1
+        for lo in range(0, mat.shape[0], self._chunk):
+            block = mat[lo:lo + self._chunk]
+            names = ids[block[:, :last]]           # vectorised index -> ID for the whole chunk
+            for row, n in zip(names, block[:, last]):
+                yield row[:n].tolist()
+
+    def __getitem__(self, i):
+        row = self.matrix[i]
+        return self._ids[row[: row[-1]]].tolist()
 
 
 class Base(BaseGraph):
@@ -88,6 +121,10 @@ class Base(BaseGraph):
         self._preprocess_transition_probs()
         starts = self._start_array(num_walks)
         return self._random_walks(starts, walk_length)
+
+    def simulate_walks_corpus(self, num_walks, walk_length):
+        """Like ``simulate_walks`` but returns a lazy, re-iterable :class:`WalkCorpus`."""
+        return WalkCorpus(self.simulate_walks_array(num_walks, walk_length), self.nodes)
 
     def simulate_walks(self, num_walks, walk_length):
         """Generate ``num_walks`` walks from every node; returns ``List[List[str]]``."""

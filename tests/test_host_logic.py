@@ -147,3 +147,15 @@ def test_synth_generators():
     assert all((b, a) in fwd for a, b in list(fwd)[:500])            # symmetric
     ip, ix, da = csr_from_edges([0, 0, 2, 0], [1, 2, 0, 1], 3)
     assert ip.tolist() == [0, 2, 2, 3] and ix.tolist() == [1, 2, 0]
+
+
+def test_walk_corpus_is_lazy_and_reiterable():
+    ids = ["n%d" % i for i in range(6)]
+    mat = np.array([[2, 3, 0, 0, 2], [5, 0, 0, 0, 1], [1, 2, 3, 4, 4]], dtype=np.uint32)
+    corpus = node2vec.WalkCorpus(mat, ids, chunk=2)
+    want = [["n2", "n3"], ["n5"], ["n1", "n2", "n3", "n4"]]
+    assert list(corpus) == want and list(corpus) == want and len(corpus) == 3
+    assert corpus[2] == want[2]
+    g = node2vec.SparseOTF()
+    g.set_node_ids(ids)
+    assert [g._map_walk(r) for r in mat] == want
