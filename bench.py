@@ -78,11 +78,20 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torchrun with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+    # PECANPY_BENCH_BACKEND=gloo + PECANPY_BENCH_ONE_GPU=1: dry-run of the multi-rank path on a box
+    # with a single GPU (RCCL refuses two ranks on one device); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("PECANPY_BENCH_BACKEND", "nccl")
+    if os.environ.get("PECANPY_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where collectives exchange tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pecanpy_amd.engine import WalkEngine, shard_bounds
     from pecanpy_amd.synth import rmat_csr
@@ -108,7 +117,7 @@ def main():
     full = None
     if world > 1:
         rows = max(b[1] - b[0] for b in shard_bounds(n_jobs, world))
-        padded = torch.zeros((rows, L + 2), dtype=torch.int32, device=dev)
+        padded = torch.zeros((rows, L + 2), dtype=torch.int32, device=cdev)
         parts = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
 
     kernel_ms, rng_ms = [], []
@@ -119,7 +128,7 @@ def main():
         kernel_ms.append(eng.last_stats["walk_kernel_ms"])
         rng_ms.append(eng.last_stats["rng_kernel_ms"])
         if world > 1:  # one gather of the shards over RCCL/xGMI
-            padded[: hi - lo] = d_out
+            padded[: hi - lo] = d_out.to(cdev)
             dist.gather(padded, parts, dst=0)
 
     def fence():
@@ -139,12 +148,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     st = eng.last_stats
-    shard_steps = torch.tensor([st["total_steps"]], dtype=torch.int64, device=dev)
+    shard_steps = torch.tensor([st["total_steps"]], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(shard_steps)
     total_steps = int(shard_steps.item())           # sampled transitions of the whole job array
