@@ -332,6 +332,8 @@ template <typename T, bool UNIT> struct RowVals {
     const float *__restrict__ thr = nullptr;
     uint32_t dp = 0;
     float thr_cur = 0.0f;
+    const uint64_t *__restrict__ ptab = nullptr; // adjacency index of prev's row (nullptr: search prow)
+    uint32_t ptmask = 0;
 
     __device__ __forceinline__ T value(uint32_t k, uint32_t bit) const {
         if (UNIT) {
@@ -360,7 +362,9 @@ template <typename T, bool UNIT> struct RowVals {
         double t = 0.0;
         if (ballot(need_t)) {
             const uint32_t x = need_t ? crow[k] : 0u;
-            const uint32_t jpos = lower_bound_u32(prow, dp, x);
+            // position of x in prev's row: one probe of the adjacency index (sparse graphs) or a
+            // search of the row (dense handles have no index)
+            const uint32_t jpos = ptab ? adj_lookup(ptab, ptmask, x, need_t) : lower_bound_u32(prow, dp, x);
             if (need_t) t = Arith<T>::t_ratio(pdata[jpos], thr[x]);
         }
         if (valid) {
@@ -812,6 +816,11 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
         rv.pdata = data + t0;
         rv.thr = a.g.thr;
         rv.dp = dp;
+        if (!DENSE) {
+            const uint64_t tb0 = readfirst_u64(a.g.tab_off[prev]);
+            rv.ptmask = (uint32_t)(readfirst_u64(a.g.tab_off[prev + 1]) - tb0) - 1u;
+            rv.ptab = a.g.slots + tb0;
+        }
         rv.thr_cur = __uint_as_float(uni(__float_as_uint(a.g.thr[cur])));
     }
 
