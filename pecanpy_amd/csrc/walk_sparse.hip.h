@@ -334,6 +334,20 @@ template <typename T, bool UNIT> struct RowVals {
     float thr_cur = 0.0f;
     const uint64_t *__restrict__ ptab = nullptr; // adjacency index of prev's row (nullptr: search prow)
     uint32_t ptmask = 0;
+    // p / q that are powers of two: fl32(f64(w) / q) == w * (1/q) exactly (scaling by a power of two
+    // is exact, one rounding either way), which avoids a ~30-instruction float64 division per element
+    bool q_pow2 = false, p_pow2 = false;
+    T inv_q = (T)0, inv_p = (T)0;
+
+    __device__ __forceinline__ void setup_bias() {
+        const uint64_t qb = (uint64_t)__double_as_longlong(q), pb = (uint64_t)__double_as_longlong(p);
+        q_pow2 = (qb & 0xfffffffffffffull) == 0 && q > 0x1p-100 && q < 0x1p100;
+        p_pow2 = (pb & 0xfffffffffffffull) == 0 && p > 0x1p-100 && p < 0x1p100;
+        inv_q = (T)(1.0 / q);
+        inv_p = (T)(1.0 / p);
+    }
+    __device__ __forceinline__ T div_q(T w) const { return q_pow2 ? w * inv_q : Arith<T>::bias_div(w, q); }
+    __device__ __forceinline__ T div_p(T w) const { return p_pow2 ? w * inv_p : Arith<T>::bias_div(w, p); }
 
     __device__ __forceinline__ T value(uint32_t k, uint32_t bit) const {
         if (UNIT) {
@@ -343,8 +357,8 @@ template <typename T, bool UNIT> struct RowVals {
         } else {
             T w = drow[k];
             if (has_prev && !extend) {
-                if (k == prev_pos) w = Arith<T>::bias_div(w, p);
-                else if (!bit) w = Arith<T>::bias_div(w, q);
+                if (k == prev_pos) w = div_p(w);
+                else if (!bit) w = div_q(w);
             }
             return normalize ? w / tot : w;
         }
@@ -368,7 +382,7 @@ template <typename T, bool UNIT> struct RowVals {
             if (need_t) t = Arith<T>::t_ratio(pdata[jpos], thr[x]);
         }
         if (valid) {
-            if (k == prev_pos) w = Arith<T>::bias_div(w, p);
+            if (k == prev_pos) w = div_p(w);
             else if (!(common && is_in)) {
                 const double inv_q = 1.0 / q;
                 double alpha = inv_q + (1.0 - inv_q) * t;
@@ -809,6 +823,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     rv.tot = (T)1;
     rv.prev_pos = NOT_FOUND;
     rv.extend = extend;
+    rv.setup_bias();
     if (extend) {
         rv.in_mask = in_mask;
         rv.crow = indices + s0;
