@@ -460,11 +460,31 @@ __device__ __forceinline__ int seq_scan_binade(T &c, uint32_t &k, uint32_t kend,
             f[e] = B::quantize(xs[e], eb);
             if (kl + e < k) { f[e].a0 = 0; f[e].a1 = 0; }
         }
-        Inc<T> agg = f[0];
+        bool lane_tie = false;
 #pragma unroll
-        for (int e = 1; e < EPL; e++) agg = B::compose(agg, f[e]);
-        Inc<T> incl = wave_scan_inc<T>(agg);
-        U Cincl = B::apply(C, incl);
+        for (int e = 0; e < EPL; e++) lane_tie |= f[e].a0 != f[e].a1;
+        U Cincl;
+        if (!ballot(lane_tie)) {
+            // no exact tie in this pass (the common case): increments are parity independent, the
+            // scan is a plain saturating integer prefix sum
+            U sum = f[0].a0;
+#pragma unroll
+            for (int e = 1; e < EPL; e++) { sum += f[e].a0; sum = sum > B::SAT ? B::SAT : sum; }
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                U t = shfl_up_uint<U>(sum, off);
+                U nsum = sum + t;
+                nsum = nsum > B::SAT ? B::SAT : nsum;
+                if (lane >= off) sum = nsum;
+            }
+            Cincl = C + sum;
+        } else {
+            Inc<T> agg = f[0];
+#pragma unroll
+            for (int e = 1; e < EPL; e++) agg = B::compose(agg, f[e]);
+            Inc<T> incl = wave_scan_inc<T>(agg);
+            Cincl = B::apply(C, incl);
+        }
         uint64_t hit = ballot(Cincl >= Tt);
         if (!hit) {
             c = B::make(readlane_uint<U>(Cincl, WAVE - 1), eb);
