@@ -83,6 +83,13 @@ int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *
  * row-major; nonzero mask = (data != 0). */
 int pw_dense_create(const double *data, uint32_t n_nodes, int device, pw_graph **out);
 
+/* Unweighted dense graph from its bit-packed adjacency: row u = ceil(n/64) uint64 words, bit x of the
+ * row set <=> nonzero[u, x] (the reference's bool mask, graph.py:580, one bit per entry).  The
+ * pointer may be a host pointer (on_device = 0) or a device pointer on `device` (on_device = 1);
+ * lets a 100k-node dense graph be created without materialising the 80 GB float64 matrix. */
+int pw_dense_create_bits(const uint64_t *adjbits, uint32_t n_nodes, int on_device, int device,
+                         pw_graph **out);
+
 /* node2vec+ noise thresholds, float32[n_nodes] (sparse_rw.py:22-35 / dense_rw.py:11-19);
  * required before a call with extend != 0. */
 int pw_graph_set_thresholds(pw_graph *g, const float *thr);

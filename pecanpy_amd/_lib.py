@@ -50,6 +50,7 @@ SYMBOLS = {
     "pw_csr_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "pw_dense_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "pw_dense_create_bits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pw_graph_set_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pw_graph_destroy": (None, [C.c_void_p]),
     "pw_simulate": (C.c_int, _SIM_ARGS),

@@ -1,0 +1,329 @@
+// walk_dense.hip.h -- DenseOTF on a bit-packed adjacency matrix, unweighted graphs (gfx950).
+//
+// The reference keeps a float64[N,N] matrix and a bool[N,N] mask and touches ~1 MB per step at
+// N = 100k (rw/dense_rw.py:34-72, pecanpy.py:597-612).  For an unweighted graph all of that is one
+// bit per pair: row u = WPR 64-bit words.  A step here works in COLUMN space:
+//   in  = row(cur) &  row(prev)          common neighbours           value 1
+//   out = row(cur) & ~row(prev)          other neighbours            value 1/q      (float64)
+//   prev itself (if adjacent to cur)                                 value 1/p
+// are three bitmasks obtained with word-wide AND/ANDN from two coalesced row reads; the exact
+// sequential float64 sum / CDF search of the reference is evaluated with the same closed-form
+// binade chain as the sparse unit path (seqscan.h, walk_sparse.hip.h: unit_chain) over the columns
+// of a 16384-column segment at a time, class counts coming from prefix popcounts (rank arrays) of
+// the two masks in LDS.  The sampled element is directly the next vertex (a column index).
+// HBM per step: 2 rows x N/8 bytes (x2 when the row is re-read for the search) instead of ~10 N bytes.
+#pragma once
+#include "walk_sparse.hip.h"
+
+namespace pw {
+
+constexpr int DW = 512;                  // 32-bit mask words per segment
+constexpr uint32_t DSEG = DW * 32;       // columns per segment
+constexpr int DQW = DW / 2;              // 64-bit adjacency words per segment
+
+struct DenseArgs {
+    const uint64_t *__restrict__ adjbits;  // [n][wpr]
+    const uint32_t *__restrict__ deg;      // [n]
+    uint32_t n, wpr;
+    double p, q;
+    uint32_t L;
+    uint64_t n_jobs;
+    const uint32_t *__restrict__ starts;
+    const uint64_t *__restrict__ stream_off;
+    const uint32_t *__restrict__ job_list;
+    uint64_t n_list;
+    const double *__restrict__ rng;
+    uint64_t rng_base;
+    uint32_t *out;
+    unsigned long long *job_counter;
+    unsigned long long *stats;
+};
+
+struct ColRow {
+    const uint32_t *mi, *mo;   // LDS class masks of the segment (prev's own bit cleared in both)
+    const uint16_t *ri, *ro;   // LDS rank arrays
+    uint32_t seg_lo, seg_len;
+    uint32_t prev_col;         // column of prev if it is a neighbour of cur, else NOT_FOUND
+    __device__ __forceinline__ uint32_t rank(const uint32_t *m, const uint16_t *rk, uint32_t k) const {
+        uint32_t r = k - seg_lo, w = r >> 5, b = r & 31;
+        uint32_t base = rk[w];
+        return b ? base + (uint32_t)__popc(m[w] & ((1u << b) - 1u)) : base;
+    }
+    __device__ __forceinline__ uint32_t rank_in(uint32_t k) const { return rank(mi, ri, k); }
+    __device__ __forceinline__ uint32_t rank_out(uint32_t k) const { return rank(mo, ro, k); }
+    __device__ __forceinline__ uint32_t bit(const uint32_t *m, uint32_t k) const {
+        uint32_t r = k - seg_lo;
+        return (m[r >> 5] >> (r & 31)) & 1u;
+    }
+};
+
+// element view for the generic (tie) fallback: one element per COLUMN, zeros for non-neighbours
+struct ColVals {
+    ColRow cr;
+    uint32_t kend;
+    double x_in, x_out, x_prev;
+    __device__ __forceinline__ double one(uint32_t k) const {
+        if (k >= kend) return 0.0;
+        if (k == cr.prev_col) return x_prev;
+        if (cr.bit(cr.mi, k)) return x_in;
+        return cr.bit(cr.mo, k) ? x_out : 0.0;
+    }
+    __device__ __forceinline__ void vec(uint32_t kb, double (&xs)[EPL]) const {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) xs[e] = one(kb + e);
+    }
+};
+
+template <bool HAS_TARGET>
+__device__ __forceinline__ int dense_chain(double &c, uint32_t &k, uint32_t kend, double r, const ColRow &cr,
+                                           const ColVals &cv, double x_in, double x_out, double x_prev,
+                                           uint32_t &found) {
+    using B = Binade<double>;
+    using U = uint64_t;
+    const int lane = lane_id();
+    c = uni(c);
+    while (k < kend) {
+        const int eb = B::eb_of(c);
+        const U C = B::sig_of(c);
+        const U Tt = HAS_TARGET ? uni(B::threshold(r, eb)) : B::TOP;
+        const Inc<double> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb), qp = B::quantize(x_prev, eb);
+        const bool prev_in = cr.prev_col != NOT_FOUND && cr.prev_col >= k && cr.prev_col < kend;
+        if (qi.a0 != qi.a1 || qo.a0 != qo.a1 || (prev_in && qp.a0 != qp.a1)) {
+            int rc = seq_scan_binade<double, HAS_TARGET>(c, k, kend, r, cv, found);
+            if (rc == SCAN_FOUND) return SCAN_FOUND;
+            c = uni(c);
+            continue;
+        }
+        const U ii = qi.a0, io = qo.a0, ipv = qp.a0;
+        const uint32_t ri0 = uni(cr.rank_in(k)), ro0 = uni(cr.rank_out(k));
+        uint32_t lo = k, hi = kend - 1, kf = 0;
+        uint64_t Cf = 0;
+        bool crossed = true;
+        for (;;) {
+            const uint32_t n = hi - lo + 1;
+            const uint32_t step = (n + WAVE - 1) / WAVE;
+            uint64_t kp64 = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+            const uint32_t kp = kp64 > hi ? hi : (uint32_t)kp64;
+            const uint32_t cin = cr.rank_in(kp + 1) - ri0;
+            const uint32_t cout = cr.rank_out(kp + 1) - ro0;
+            const uint32_t cpv = (prev_in && cr.prev_col <= kp) ? 1u : 0u;
+            const uint64_t G = C + chain_term<U>(cin, ii) + chain_term<U>(cout, io) + chain_term<U>(cpv, ipv);
+            const uint64_t hitm = ballot(G >= Tt);
+            if (!hitm) {
+                Cf = readlane_u64(G, WAVE - 1);
+                crossed = false;
+                break;
+            }
+            const int first = __builtin_ctzll(hitm);
+            if (step == 1) { kf = lo + (uint32_t)first; Cf = readlane_u64(G, first); break; }
+            uint64_t nhi = (uint64_t)lo + (uint64_t)(first + 1) * step - 1;
+            lo = lo + (uint32_t)first * step;
+            if (nhi < hi) hi = (uint32_t)nhi;
+        }
+        if (!crossed) {
+            c = uni(B::make((U)Cf, eb));
+            k = kend;
+            break;
+        }
+        const bool f_prev = prev_in && kf == cr.prev_col;
+        const bool f_in = !f_prev && uni(cr.bit(cr.mi, kf)) != 0u;
+        const double xf = f_prev ? x_prev : (f_in ? x_in : x_out);
+        const uint32_t cin0 = uni(cr.rank_in(kf)) - ri0;
+        const uint32_t cout0 = uni(cr.rank_out(kf)) - ro0;
+        const uint32_t cpv0 = (prev_in && cr.prev_col < kf) ? 1u : 0u;
+        const uint64_t Cprev = C + chain_term<U>(cin0, ii) + chain_term<U>(cout0, io) + chain_term<U>(cpv0, ipv);
+        if (Cf < B::TOP) { c = uni(B::make((U)Cf, eb)); found = kf; return SCAN_FOUND; }
+        c = uni(B::make((U)Cprev, eb) + xf);
+        k = kf + 1;
+        if (HAS_TARGET && (double)c >= r) { found = kf; return SCAN_FOUND; }
+    }
+    return SCAN_END;
+}
+
+// Class masks + ranks of one segment of columns [seg_lo, seg_lo + seg_len).
+__device__ __forceinline__ void prepare_dense_segment(const uint64_t *__restrict__ crow,
+                                                      const uint64_t *__restrict__ prow, bool has_prev,
+                                                      uint32_t wpr, uint32_t n, uint32_t seg, uint32_t prev,
+                                                      uint32_t *mi, uint32_t *mo, uint16_t *ri, uint16_t *ro) {
+    const int lane = lane_id();
+    const uint32_t w0 = seg * DQW;
+#pragma unroll
+    for (int j = 0; j < DQW / WAVE; j++) {
+        const uint32_t wl = (uint32_t)j * WAVE + lane;   // 64-bit word inside the segment
+        const uint32_t w = w0 + wl;
+        uint64_t cw = 0, pw = 0;
+        if (w < wpr) {
+            cw = crow[w];
+            if (has_prev) pw = prow[w];
+            const uint64_t col0 = (uint64_t)w * 64;
+            if (col0 + 64 > n) cw &= (n > col0) ? ((1ull << (n - col0)) - 1ull) : 0ull;   // columns >= n
+            if (has_prev && (prev >> 6) == w) {           // prev forms its own class
+                const uint64_t pb = 1ull << (prev & 63);
+                cw &= ~pb;
+            }
+        }
+        const uint64_t in = cw & pw, out = cw & ~pw;
+        mi[2 * wl] = (uint32_t)in;
+        mi[2 * wl + 1] = (uint32_t)(in >> 32);
+        mo[2 * wl] = (uint32_t)out;
+        mo[2 * wl + 1] = (uint32_t)(out >> 32);
+    }
+    wave_lds_fence();
+    build_rank(mi, ri, DW);
+    build_rank(mo, ro, DW);
+}
+
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
+walk_dense_bits_kernel(DenseArgs a) {
+    __shared__ uint32_t s_mi[WAVES_PER_BLOCK][DW], s_mo[WAVES_PER_BLOCK][DW];
+    __shared__ uint16_t s_ri[WAVES_PER_BLOCK][DW + 2], s_ro[WAVES_PER_BLOCK][DW + 2];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    uint32_t *mi = s_mi[wave], *mo = s_mo[wave];
+    uint16_t *ri = s_ri[wave], *ro = s_ro[wave];
+    const uint32_t L = a.L, n = a.n, wpr = a.wpr;
+    const uint64_t W = (uint64_t)L + 2;
+    const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
+    const uint32_t n_seg = (n + DSEG - 1) / DSEG;
+    const double w_in = 1.0, w_outq = 1.0 / a.q, w_prevp = 1.0 / a.p;
+    unsigned long long st_steps = 0, st_over = 0, st_clamp = 0, st_dead = 0;
+
+    for (;;) {
+        unsigned long long widx = 0;
+        if (lane == 0) widx = atomicAdd(a.job_counter, 1ull);
+        widx = readfirst_u64(widx);
+        if (widx >= n_work) break;
+        const uint64_t job = a.job_list ? (uint64_t)uni(a.job_list[widx]) : (uint64_t)widx;
+        uint32_t *row = a.out + job * W;
+        const uint32_t start = uni(a.starts[job]);
+        const uint64_t soff = readfirst_u64(a.stream_off[job]) - a.rng_base;
+        uint32_t cur = start, prev = 0;
+        uint32_t len_out = L + 1;
+        double rbuf = 0.0;
+        uint32_t j = 1;
+        for (; j <= L; j++) {
+            const uint32_t d = uni(a.deg[cur]);
+            if (d == 0) { len_out = j; if (j > 1) st_dead++; break; }
+            const uint32_t jr = (j - 1) & (WAVE - 1);
+            if (jr == 0) {
+                uint32_t idx = (j - 1) + (uint32_t)lane;
+                rbuf = idx < L ? a.rng[soff + idx] : 0.0;
+            }
+            const double r = readlane_f64(rbuf, (int)jr);
+            const bool has_prev = j >= 2;
+            const uint64_t *__restrict__ crow = a.adjbits + (uint64_t)cur * wpr;
+            const uint64_t *__restrict__ prow = a.adjbits + (uint64_t)prev * wpr;
+
+            // class counts over the whole row (for tot)
+            uint32_t n_in = 0, n_pv = 0;
+            if (has_prev) {
+                uint32_t acc = 0;
+                for (uint32_t w = lane; w < wpr; w += WAVE) {
+                    uint64_t cw = crow[w], pw = prow[w];
+                    if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));
+                    acc += (uint32_t)__popcll(cw & pw);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc += (uint32_t)__shfl_xor((int)acc, off, WAVE);
+                n_in = uni(acc);
+                n_pv = (uint32_t)((uni(crow[prev >> 6]) >> (prev & 63)) & 1ull);
+            }
+            const uint32_t n_out = d - n_in - n_pv;
+            const uint32_t prev_col = n_pv ? prev : NOT_FOUND;
+            const double w_out = has_prev ? w_outq : 1.0;
+
+            double tot = 0.0;
+            bool have_tot = false;
+            if ((n_out == 0 || is_pow2_fp<double>(w_out)) && (n_pv == 0 || is_pow2_fp<double>(w_prevp))) {
+                double u = 1.0;
+                if (n_out && w_out < u) u = w_out;
+                if (n_pv && w_prevp < u) u = w_prevp;
+                double td = (double)n_in + (double)n_out * w_out + (double)n_pv * w_prevp;
+                if (td / u <= 9007199254740992.0) { tot = td; have_tot = true; }
+            }
+            if (!have_tot) {
+                for (uint32_t seg = 0; seg < n_seg; seg++) {
+                    prepare_dense_segment(crow, prow, has_prev, wpr, n, seg, prev, mi, mo, ri, ro);
+                    const uint32_t lo = seg * DSEG, len = n - lo < DSEG ? n - lo : DSEG;
+                    const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
+                    const ColVals cv{cr, lo + len, w_in, w_out, w_prevp};
+                    uint32_t k = lo, found = NOT_FOUND;
+                    (void)dense_chain<false>(tot, k, lo + len, 0.0, cr, cv, w_in, w_out, w_prevp, found);
+                }
+            }
+            tot = uni(tot);
+            const double x_in = uni(w_in / tot), x_out = uni(w_out / tot), x_prev = uni(w_prevp / tot);
+
+            uint32_t nxt = NOT_FOUND;
+            double c = 0.0;
+            if (!(r > 0.0)) {
+                // (double)c_0 >= r holds at the first neighbour: lowest set bit of the row
+                uint32_t best = NOT_FOUND;
+                for (uint32_t w = lane; w < wpr && best == NOT_FOUND; w += WAVE) {
+                    uint64_t cw = crow[w];
+                    if (cw) best = w * 64 + (uint32_t)__builtin_ctzll(cw);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    uint32_t o = (uint32_t)__shfl_xor((int)best, off, WAVE);
+                    best = o < best ? o : best;
+                }
+                nxt = uni(best);
+            } else {
+                for (uint32_t seg = 0; seg < n_seg && nxt == NOT_FOUND; seg++) {
+                    prepare_dense_segment(crow, prow, has_prev, wpr, n, seg, prev, mi, mo, ri, ro);
+                    const uint32_t lo = seg * DSEG, len = n - lo < DSEG ? n - lo : DSEG;
+                    const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
+                    const ColVals cv{cr, lo + len, x_in, x_out, x_prev};
+                    uint32_t k = lo, found = NOT_FOUND;
+                    if (dense_chain<true>(c, k, lo + len, r, cr, cv, x_in, x_out, x_prev, found) == SCAN_FOUND) nxt = found;
+                }
+            }
+            if (nxt == NOT_FOUND) {
+                // CDF never reached r: the reference reads past a temporary; clamp to the last neighbour
+                st_over++;
+                st_clamp++;
+                uint32_t best = 0;
+                for (uint32_t w = lane; w < wpr; w += WAVE) {
+                    uint64_t cw = crow[w];
+                    if (cw) { uint32_t col = w * 64 + 63u - (uint32_t)__builtin_clzll(cw); best = col > best ? col : best; }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    uint32_t o = (uint32_t)__shfl_xor((int)best, off, WAVE);
+                    best = o > best ? o : best;
+                }
+                nxt = uni(best);
+            }
+            if (lane == 0) row[j] = nxt;
+            prev = cur;
+            cur = nxt;
+            st_steps++;
+        }
+        if (lane == 0) { row[0] = start; row[L + 1] = len_out; }
+        for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
+    }
+    if (lane == 0) {
+        if (st_steps) atomicAdd(&a.stats[0], st_steps);
+        if (st_over) atomicAdd(&a.stats[1], st_over);
+        if (st_clamp) atomicAdd(&a.stats[2], st_clamp);
+        if (st_dead) atomicAdd(&a.stats[3], st_dead);
+    }
+}
+
+// degrees from the packed rows (one wavefront per row)
+__global__ void __launch_bounds__(256)
+dense_degree_kernel(const uint64_t *__restrict__ adjbits, uint32_t n, uint32_t wpr, uint32_t *deg) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) / WAVE;
+    const int lane = lane_id();
+    for (uint32_t u = wave; u < n; u += n_waves) {
+        uint32_t acc = 0;
+        for (uint32_t w = lane; w < wpr; w += WAVE) acc += (uint32_t)__popcll(adjbits[(uint64_t)u * wpr + w]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += (uint32_t)__shfl_xor((int)acc, off, WAVE);
+        if (lane == 0) deg[u] = acc;
+    }
+}
+
+}  // namespace pw

@@ -58,6 +58,27 @@ class WalkEngine:
         _lib.check(lib.pw_dense_create(_np_ptr(data), data.shape[0], int(device), C.byref(h)))
         return cls(h, lib, "dense", data.shape[0], int(device))
 
+    @classmethod
+    def from_dense_bits(cls, bits, n_nodes, device=0):
+        """Unweighted dense graph from packed adjacency rows: ``bits`` is ``uint64[n, ceil(n/64)]`` as a
+        NumPy array (host) or an int64 torch CUDA tensor (device, same bit pattern)."""
+        lib = _lib.load()
+        wpr = (int(n_nodes) + 63) // 64
+        h = C.c_void_p()
+        if isinstance(bits, np.ndarray):
+            bits = np.ascontiguousarray(bits, dtype=np.uint64)
+            if bits.size != int(n_nodes) * wpr:
+                raise ValueError("bits must hold n * ceil(n/64) words")
+            _lib.check(lib.pw_dense_create_bits(_np_ptr(bits), int(n_nodes), 0, int(device), C.byref(h)))
+        else:  # torch CUDA tensor
+            if not bits.is_cuda or not bits.is_contiguous() or bits.numel() != int(n_nodes) * wpr:
+                raise ValueError("bits must be a contiguous CUDA tensor of n * ceil(n/64) 64-bit words")
+            import torch
+
+            torch.cuda.current_stream(bits.device).synchronize()
+            _lib.check(lib.pw_dense_create_bits(C.c_void_p(bits.data_ptr()), int(n_nodes), 1, int(device), C.byref(h)))
+        return cls(h, lib, "dense", int(n_nodes), int(device))
+
     def set_thresholds(self, thr):
         thr = np.ascontiguousarray(thr, dtype=np.float32)
         if thr.size != self.n_nodes:

@@ -249,6 +249,36 @@ def test_dense_er_vs_oracle(weighted, extend, p, q):
     assert eng.last_stats["total_steps"] == ost.total_steps
 
 
+def _pack_bits(adj):
+    n = adj.shape[0]
+    wpr = (n + 63) // 64
+    padded = np.zeros((n, wpr * 64), dtype=np.uint8)
+    padded[:, :n] = adj
+    return np.packbits(padded, axis=1, bitorder="little").view(np.uint64).reshape(n, wpr)
+
+
+@pytest.mark.parametrize("n,density,p,q", [(700, 0.25, 0.5, 2), (700, 0.25, 0.3, 1.7), (17000, 0.01, 0.5, 2)])
+def test_dense_bits_kernel_vs_oracle(n, density, p, q):
+    """Column-space DenseOTF kernel on packed adjacency rows (graph created without the float64
+    matrix), incl. a graph wider than one 16384-column segment."""
+    from pecanpy_amd.synth import er_dense_mask
+
+    adj = er_dense_mask(n, density, seed=3)
+    adj[7, :] = False
+    adj[:, 7] = False
+    starts = orc.shuffled_starts(n, 1, 5)[:1500]
+    want, ost = orc.walks_dense_otf(adj.astype(np.float64), p, q, starts, 20, 5, return_stats=True)
+    eng = WalkEngine.from_dense_bits(_pack_bits(adj), n)
+    got = eng.simulate("DenseOTF", p, q, False, starts, 20, seed=5)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    assert eng.last_stats["total_steps"] == ost.total_steps
+    import torch
+
+    dbits = torch.from_numpy(_pack_bits(adj).view(np.int64)).to("cuda:0")
+    eng2 = WalkEngine.from_dense_bits(dbits, n)
+    assert np.array_equal(eng2.simulate("DenseOTF", p, q, False, starts, 20, seed=5), want)
+
+
 def test_dense_and_sparse_agree_on_unweighted_graph():
     """reference test/test_walk.py:58-81: identical tables for SparseOTF and DenseOTF."""
     indptr, indices, data = rmat_csr(9, seed=11)

@@ -31,7 +31,41 @@ def run(tag, eng, mode, p, q, extend, starts, L, seed=0, reps=2):
     print(json.dumps(best), flush=True)
 
 
+def er_bits_gpu(n, density, seed=1):
+    """Packed adjacency (int64 words, little-endian bit order) of an undirected ER graph, built on the GPU."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    wpr = (n + 63) // 64
+    adj = torch.zeros((n, wpr * 64), dtype=torch.bool, device=dev)
+    rows_per = max(1, (1 << 28) // n)
+    cols = torch.arange(n, device=dev)
+    for lo in range(0, n, rows_per):
+        hi = min(n, lo + rows_per)
+        u = torch.rand((hi - lo, n), generator=gen, device=dev) < density
+        u &= cols.unsqueeze(0) > torch.arange(lo, hi, device=dev).unsqueeze(1)   # strict upper triangle
+        adj[lo:hi, :n] = u
+    adj[:, :n] |= adj[:, :n].t().clone()
+    w32 = (adj.view(n, wpr * 2, 32).to(torch.int64) * (1 << torch.arange(32, device=dev, dtype=torch.int64))).sum(-1)
+    bits = w32[:, 0::2] | (w32[:, 1::2] << 32)
+    return bits.contiguous()
+
+
+def dense_bits_config(n, density=0.25):
+    bits = er_bits_gpu(n, density)
+    eng = WalkEngine.from_dense_bits(bits, n)
+    del bits
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 10)
+    np.random.RandomState(0).shuffle(starts)
+    run(f"ER-{n} density {density} DenseOTF p=0.5 q=2 (packed-bits column-space kernel)", eng, "DenseOTF", 0.5, 2,
+        False, starts, 80)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dense":
+        dense_bits_config(int(sys.argv[2]))
+        return
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 18
     n_dense = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
     L, W = 80, 10
