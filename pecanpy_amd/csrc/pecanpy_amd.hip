@@ -366,7 +366,9 @@ PW_EXPORT int pw_dense_create_bits(const uint64_t *adjbits, uint32_t n_nodes, in
     g->words_per_row = wpr;
     const size_t bytes = sizeof(uint64_t) * (size_t)n * wpr;
     hipError_t e = hipMalloc((void **)&g->d_adjbits, bytes);
-    if (e == hipSuccess) e = hipMemcpy(g->d_adjbits, adjbits, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    // the copy must be ordered with the kernels of this handle's (non-blocking) stream
+    if (e == hipSuccess) e = hipMemcpyAsync(g->d_adjbits, adjbits, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&g->d_deg, sizeof(uint32_t) * n);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pw::dense_degree_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_adjbits, n_nodes, wpr, g->d_deg);
