@@ -13,19 +13,15 @@ if GOLDEN not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The native library is git-ignored: build it in-tree when a fresh checkout lacks it (hipcc
+    # cross-compiles gfx950 without a GPU; on the GPU box the prebuilt .so travels with the repo).
+    from pecanpy_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
 
-
-@pytest.fixture(scope="session", autouse=True)
-def native_library():
-    """The native library is git-ignored: build it in-tree when a fresh checkout lacks it (hipcc
-    cross-compiles gfx950 without a GPU; on the GPU box the prebuilt .so travels with the repo)."""
-    from pecanpy_amd import _lib
-
-    if not os.path.exists(_lib.LIB_PATH):
-        _lib.build()
-    return _lib.LIB_PATH
