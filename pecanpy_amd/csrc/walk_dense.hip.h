@@ -140,6 +140,36 @@ __device__ __forceinline__ int dense_chain(double &c, uint32_t &k, uint32_t kend
     return SCAN_END;
 }
 
+// The first neighbours of a row are added one by one (the sum leaves its binade every few elements
+// there); all operands are wave uniform, so this runs mostly on the scalar unit.
+template <bool HAS_TARGET>
+__device__ __forceinline__ bool dense_head(double &c, uint32_t &k, uint32_t kend, double r, const ColRow &cr,
+                                           double x_in, double x_out, double x_prev, uint32_t &found) {
+    uint32_t cnt = 0;
+    uint32_t next_k = k;
+    const uint32_t w_end = (kend - cr.seg_lo + 31) >> 5;
+    for (uint32_t w = (k - cr.seg_lo) >> 5; w < w_end && cnt < WAVE; w++) {
+        const uint32_t bi = uni(cr.mi[w]), bo = uni(cr.mo[w]);
+        uint32_t bp = 0;
+        if (cr.prev_col != NOT_FOUND && cr.prev_col >= cr.seg_lo && ((cr.prev_col - cr.seg_lo) >> 5) == w)
+            bp = 1u << ((cr.prev_col - cr.seg_lo) & 31);
+        uint32_t all = bi | bo | bp;
+        while (all && cnt < WAVE) {
+            const uint32_t b = (uint32_t)__builtin_ctz(all);
+            all &= all - 1u;
+            const uint32_t col = cr.seg_lo + w * 32u + b;
+            const double x = ((bp >> b) & 1u) ? x_prev : (((bi >> b) & 1u) ? x_in : x_out);
+            c = uni(c + x);
+            cnt++;
+            next_k = col + 1;
+            if (HAS_TARGET && c >= r) { found = col; return true; }
+        }
+        if (!all) next_k = cr.seg_lo + (w + 1) * 32u;
+    }
+    k = next_k > kend ? kend : next_k;
+    return false;
+}
+
 // Class masks + ranks of one segment of columns [seg_lo, seg_lo + seg_len).
 __device__ __forceinline__ void prepare_dense_segment(const uint64_t *__restrict__ crow,
                                                       const uint64_t *__restrict__ prow, bool has_prev,
@@ -248,6 +278,7 @@ walk_dense_bits_kernel(DenseArgs a) {
                     const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
                     const ColVals cv{cr, lo + len, w_in, w_out, w_prevp};
                     uint32_t k = lo, found = NOT_FOUND;
+                    if (seg == 0) (void)dense_head<false>(tot, k, lo + len, 0.0, cr, w_in, w_out, w_prevp, found);
                     (void)dense_chain<false>(tot, k, lo + len, 0.0, cr, cv, w_in, w_out, w_prevp, found);
                 }
             }
@@ -276,6 +307,7 @@ walk_dense_bits_kernel(DenseArgs a) {
                     const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
                     const ColVals cv{cr, lo + len, x_in, x_out, x_prev};
                     uint32_t k = lo, found = NOT_FOUND;
+                    if (seg == 0 && dense_head<true>(c, k, lo + len, r, cr, x_in, x_out, x_prev, found)) { nxt = found; break; }
                     if (dense_chain<true>(c, k, lo + len, r, cr, cv, x_in, x_out, x_prev, found) == SCAN_FOUND) nxt = found;
                 }
             }
