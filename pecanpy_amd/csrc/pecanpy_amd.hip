@@ -518,7 +518,8 @@ PW_EXPORT int pw_precomp_export(pw_graph *g, uint64_t *alias_indptr, uint32_t *a
 
 // Sequential-stream modes (variable word consumption): one lane walks every job in order.
 static int simulate_sequential(pw_graph *g, int mode, double p, double q, int extend, const uint32_t *d_starts,
-                               uint64_t n_jobs, uint32_t L, uint32_t seed, uint32_t *d_out, pw_stats *st) {
+                               uint64_t n_jobs, uint32_t L, int has_seed, uint32_t seed, uint32_t *d_out,
+                               pw_stats *st) {
     if (g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "this mode needs a CSR graph handle");
     if (mode == PW_MODE_PRECOMP) { int rc = pw_precomp_build(g, p, q, extend, 0); if (rc) return rc; }
     if (mode == PW_MODE_PRECOMP_FIRST_ORDER) { int rc = pw_precomp_build(g, 1.0, 1.0, 0, 1); if (rc) return rc; }
@@ -545,7 +546,11 @@ static int simulate_sequential(pw_graph *g, int mode, double p, double q, int ex
     a.out = d_out;
     a.stats = g->counters.p + 1;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-    hipLaunchKernelGGL(pw::walk_seq_kernel, dim3(1), dim3(64), 0, g->stream, a);
+    if (has_seed)  // reproducible: the reference's single sequential stream
+        hipLaunchKernelGGL(pw::walk_seq_kernel, dim3(1), dim3(64), 0, g->stream, a);
+    else           // random_state=None: nothing to reproduce, all walks in parallel
+        hipLaunchKernelGGL(pw::walk_alias_parallel_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0,
+                           g->stream, a, (uint64_t)seed);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[3], g->stream));
     unsigned long long h[8];
@@ -649,7 +654,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (mode >= PW_MODE_PRECOMP) {
         if (stream_skip) return fail(PW_ERR_UNSUPPORTED, "alias / first-order modes consume a variable number of "
                                                          "words per step: the stream cannot be sharded");
-        int rcs = simulate_sequential(g, mode, p, q, extend, d_starts, n_jobs, walk_length, seed, d_out, &st);
+        int rcs = simulate_sequential(g, mode, p, q, extend, d_starts, n_jobs, walk_length, has_seed, seed, d_out, &st);
         if (!rcs && stats) *stats = st;
         return rcs;
     }

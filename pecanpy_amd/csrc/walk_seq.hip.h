@@ -223,4 +223,86 @@ walk_seq_kernel(SeqArgs a) {
     a.stats[3] = dead;
 }
 
+// ---- unseeded runs of the alias / first-order modes: one lane per walk, counter-based draws -------------
+// With random_state = None the reference is not reproducible either (NumPy/Numba seed themselves from
+// the OS, pecanpy.py:139-140, 177), so there is no stream to match: every walk draws from its own
+// counter-based generator (splitmix64 of (seed, job, draw index)) and all walks run in parallel.
+// The sampled distribution is the same (same alias tables, same alias_draw / randint semantics).
+struct CounterRng {
+    uint64_t key, ctr;
+    __device__ inline uint64_t next64() {
+        uint64_t z = (key + (++ctr) * 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    __device__ inline uint32_t next32() { return (uint32_t)(next64() >> 32); }
+    __device__ inline double random() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+    __device__ inline uint32_t randint(uint32_t n) {  // unbiased: masked rejection like the reference
+        if (n == 1) return 0;
+        const int nbits = 32 - __clz(n - 1);
+        const uint32_t mask = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
+        for (;;) {
+            const uint32_t r = next32() & mask;
+            if (r < n) return r;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256)
+walk_alias_parallel_kernel(SeqArgs a, uint64_t seed) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_jobs) return;
+    const CsrDev &g = a.g;
+    const float *__restrict__ data = (const float *)g.data;
+    const uint32_t L = a.L;
+    const uint64_t W = (uint64_t)L + 2;
+    CounterRng rng{seed * 0xD6E8FEB86659FD93ull + i * 0xA24BAED4963EE407ull + 0x9FB21C651E98DF25ull, 0};
+    uint32_t *row = a.out + i * W;
+    for (uint32_t z = 0; z < W; z++) row[z] = 0;
+    row[0] = a.starts[i];
+    row[L + 1] = L + 1;
+    uint32_t cur = row[0], prev = 0;
+    unsigned long long steps = 0, dead = 0;
+    for (uint32_t j = 1; j <= L; j++) {
+        const uint32_t s0 = g.indptr[cur], d = g.indptr[cur + 1] - s0;
+        if (d == 0) { row[L + 1] = j; if (j > 1) dead++; break; }
+        uint32_t choice;
+        if (a.mode == 3) {
+            choice = rng.randint(d);
+        } else if (a.mode == 4) {
+            const uint32_t kk = rng.randint(d);
+            choice = (rng.random() < (double)a.alias_q[s0 + kk]) ? kk : a.alias_j[s0 + kk];
+        } else if (j == 1) {
+            // first-order step: sequential float32 sum / cumsum over the row, as the reference
+            float tot = 0.0f;
+            for (uint32_t k = 0; k < d; k++) tot += data ? data[s0 + k] : 1.0f;
+            const double r = rng.random();
+            float c = 0.0f;
+            choice = d - 1;
+            for (uint32_t k = 0; k < d; k++) {
+                c += (data ? data[s0 + k] : 1.0f) / tot;
+                if ((double)c >= r) { choice = k; break; }
+            }
+        } else {
+            uint32_t lo = 0, hi = d;
+            while (hi > lo) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (g.indices[s0 + mid] < prev) lo = mid + 1; else hi = mid;
+            }
+            uint64_t off = a.alias_indptr[cur] + (uint64_t)d * lo;
+            if (off + d > a.n_alias) off = a.n_alias - d;
+            const uint32_t kk = rng.randint(d);
+            choice = (rng.random() < (double)a.alias_q[off + kk]) ? kk : a.alias_j[off + kk];
+        }
+        const uint32_t nxt = g.indices[s0 + (choice < d ? choice : d - 1)];
+        row[j] = nxt;
+        prev = cur;
+        cur = nxt;
+        steps++;
+    }
+    if (steps) atomicAdd(&a.stats[0], steps);
+    if (dead) atomicAdd(&a.stats[3], dead);
+}
+
 }  // namespace pw

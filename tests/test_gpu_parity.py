@@ -395,6 +395,49 @@ def test_sharded_simulate_walks_two_ranks_one_gpu():
         assert np.array_equal(ret["mat"], want)
 
 
+def test_unseeded_alias_modes_sample_the_reference_distribution():
+    """random_state=None: nothing to reproduce bit for bit (the reference seeds itself from the OS),
+    so the alias / first-order modes run all walks in parallel on per-walk counter-based draws.
+    Check the sampled second-order transition frequencies against the oracle's probabilities."""
+    rng = np.random.default_rng(11)
+    n = 12
+    w = np.triu(rng.random((n, n)) + 0.2, 1) * (rng.random((n, n)) < 0.6)
+    w = (w + w.T).astype(np.float32)
+    indptr = np.zeros(n + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum((w != 0).sum(1))
+    indices = np.nonzero(w)[1].astype(np.uint32)
+    data = w[w != 0].astype(np.float32)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    starts = np.tile(np.arange(n, dtype=np.uint32), 20000)
+    L = 6
+    for mode, p, q in [("PreComp", 0.5, 2.0), ("PreCompFirstOrder", 1, 1), ("FirstOrderUnweighted", 1, 1)]:
+        mat = eng.simulate(mode, p, q, False, starts, L, seed=None)
+        assert mat[:, -1].min() == L + 1
+        # transitions (prev=a, cur=b) -> next, for the most frequent (a, b)
+        a, b, c = mat[:, 1], mat[:, 2], mat[:, 3]
+        key = a.astype(np.int64) * n + b
+        top = np.bincount(key).argmax()
+        sel = key == top
+        pa, pb = int(top // n), int(top % n)
+        nb = indices[indptr[pb]:indptr[pb + 1]]
+        counts = np.array([(c[sel] == x).sum() for x in nb], dtype=np.float64)
+        if mode == "PreComp":
+            probs = orc.sparse_probs(indptr, indices, data, p, q, pb, pa).astype(np.float64)
+        elif mode == "PreCompFirstOrder":
+            row = data[indptr[pb]:indptr[pb + 1]].astype(np.float64)
+            probs = row / row.sum()
+        else:
+            probs = np.full(nb.size, 1.0 / nb.size)
+        tot = counts.sum()
+        assert tot > 2000
+        sigma = np.sqrt(tot * probs * (1 - probs)) + 1.0
+        assert np.all(np.abs(counts - tot * probs) < 6 * sigma), (mode, counts / tot, probs)
+    # two unseeded runs differ
+    m1 = eng.simulate("FirstOrderUnweighted", 1, 1, False, starts[:1000], L, seed=None)
+    m2 = eng.simulate("FirstOrderUnweighted", 1, 1, False, starts[:1000], L, seed=None)
+    assert not np.array_equal(m1, m2)
+
+
 def test_mode_classes_drop_in():
     from pecanpy import pecanpy  # the alias package
     from ref_test_walk import IDS, MAT, WALKS
