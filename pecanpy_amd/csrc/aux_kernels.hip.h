@@ -167,6 +167,46 @@ adj_index_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__re
     }
 }
 
+// per-edge common-neighbour counts tri[e] = |N(u) & N(v)| for e = (u -> v): one lane per CSR entry walks
+// the shorter of the two rows through the longer row's filter + adjacency index.
+__global__ void __launch_bounds__(256)
+tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint32_t *tri) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.nnz) return;
+    const uint32_t u = edge_row[e], v = g.indices[e];
+    const uint32_t su = g.indptr[u], du = g.indptr[u + 1] - su;
+    const uint32_t sv = g.indptr[v], dv = g.indptr[v + 1] - sv;
+    const bool u_short = du <= dv;
+    const uint32_t ks = u_short ? su : sv, kn = u_short ? du : dv;   // keys: the shorter row
+    const uint32_t w = u_short ? v : u;                               // searched vertex
+    const uint32_t f0 = g.foff[w], nw_mask = g.foff[w + 1] - f0 - 1u;
+    const uint64_t tb0 = g.tab_off[w];
+    const uint32_t tmask = (uint32_t)(g.tab_off[w + 1] - tb0) - 1u;
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < kn; i++) {
+        const uint32_t key = g.indices[ks + i];
+        const uint64_t bits = filter_bits(filter_hash(key));
+        const uint64_t word = g.fbits[f0 + filter_word(g.ipos[ks + i], nw_mask)];
+        if ((word & bits) == bits && adj_lookup(g.slots + tb0, tmask, key, true) != 0xffffffffu) cnt++;
+    }
+    tri[e] = cnt;
+}
+
+__global__ void __launch_bounds__(256)
+self_loop_kernel(const uint32_t *__restrict__ indices, const uint32_t *__restrict__ edge_row, uint32_t nnz,
+                 unsigned int *flag) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz && indices[e] == edge_row[e]) atomicOr(flag, 1u);
+}
+
+__global__ void csr_edge_rows_kernel(const uint32_t *__restrict__ indptr, uint32_t n_nodes, uint32_t *edge_row) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t v = wave; v < n_nodes; v += n_waves)
+        for (uint32_t e = indptr[v] + lane; e < indptr[v + 1]; e += 64) edge_row[e] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stream offsets.  draws[i] = number of doubles job i consumes.  First pass assumes every walk
 // from a start with neighbours runs its full length (always true on undirected graphs); repair

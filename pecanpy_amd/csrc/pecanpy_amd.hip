@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <random>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,7 @@ struct pw_graph {
     uint64_t *d_fbits = nullptr;
     uint32_t *d_ipos = nullptr;      // CSR graphs: degree-CDF fraction of every CSR entry's neighbour
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
+    uint32_t *d_tri = nullptr;                          // CSR graphs: per-edge common-neighbour counts
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -175,6 +177,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_ipos) (void)hipFree(g->d_ipos);
     if (g->d_tab_off) (void)hipFree(g->d_tab_off);
     if (g->d_slots) (void)hipFree(g->d_slots);
+    if (g->d_tri) (void)hipFree(g->d_tri);
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -208,6 +211,8 @@ static int graph_common_init(pw_graph *g, int device) {
     for (auto &e : g->ev) HIP_TRY(hipEventCreate(&e));
     return 0;
 }
+
+static pw::CsrDev csr_dev(const pw_graph *g);
 
 PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                             uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out) {
@@ -291,6 +296,36 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
             if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("adjacency index build: ") + hipGetErrorString(e));
         }
         if (rc) { pw_graph_destroy(g); return rc; }
+    }
+    if (unit && nnz && !getenv("PECANPY_AMD_NO_LAZY")) {
+        // per-edge common-neighbour counts (lazy membership of the unit-weight kernel); skipped for
+        // graphs with self loops, where "common neighbour" and the reference's prev handling differ
+        uint32_t *d_edge_row = nullptr;
+        unsigned int *d_flag = nullptr;
+        hipError_t e = hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_flag, sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(unsigned int), g->stream);
+        unsigned int has_loop = 1;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, n_nodes, d_edge_row);
+            hipLaunchKernelGGL(pw::self_loop_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                               g->d_indices, d_edge_row, nnz, d_flag);
+            e = hipMemcpyAsync(&has_loop, d_flag, sizeof(has_loop), hipMemcpyDeviceToHost, g->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        }
+        if (e == hipSuccess && !has_loop) {
+            e = hipMalloc((void **)&g->d_tri, sizeof(uint32_t) * (size_t)nnz);
+            if (e == hipSuccess) {
+                pw::CsrDev c = csr_dev(g);
+                hipLaunchKernelGGL(pw::tri_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                                   c, d_edge_row, g->d_tri);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+            }
+        }
+        if (d_edge_row) (void)hipFree(d_edge_row);
+        if (d_flag) (void)hipFree(d_flag);
+        if (e != hipSuccess) { pw_graph_destroy(g); return fail(PW_ERR_HIP, std::string("common-neighbour counts: ") + hipGetErrorString(e)); }
     }
     *out = g;
     return PW_OK;
@@ -457,6 +492,7 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.ipos = g->d_ipos;
     c.tab_off = g->d_tab_off;
     c.slots = g->d_slots;
+    c.tri = g->d_tri;
     c.words_per_row = g->words_per_row;
     c.n_nodes = g->n_nodes;
     c.nnz = g->nnz;
@@ -731,6 +767,16 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.out = d_out;
     wa.job_counter = g->counters.p;
     wa.stats = g->counters.p + 1;
+    {
+        // unit-weight biases exactly as the kernels form them: fl32(f64(1.0f) / q) (sparse_rw.py:59-62)
+        wa.w_out = (float)(1.0 / q);
+        wa.w_prev = (float)(1.0 / p);
+        auto pow2_ok = [](float w) {
+            int e = 0;
+            return std::frexp(w, &e) == 0.5f && e > -60 && e < 60;
+        };
+        wa.lazy_ok = (pow2_ok(wa.w_out) && pow2_ok(wa.w_prev)) ? 1u : 0u;
+    }
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
     rc = launch_walks(g, wa, extend != 0);
     if (rc) return rc;
@@ -738,6 +784,22 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+#ifdef PW_PROF
+    {
+        unsigned long long hp[16], zero[16] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(pw::g_prof), sizeof(hp)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pw::g_prof), zero, sizeof(zero)));
+        static const char *names[16] = {"step pro/epilogue", "lazy setup", "membership chunks", "build_rank", "seq_head",
+                                        "unit_chain", "eager fallback", "-", "#chunks", "#searches", "#eager steps",
+                                        "#chain binades", "#chain tie fallbacks", "#search rounds", "-", "-"};
+        double tot = 0;
+        for (int i = 0; i < 8; i++) tot += (double)hp[i];
+        fprintf(stderr, "[pw_prof] steps=%llu\n", h[1]);
+        for (int i = 0; i < 8; i++)
+            fprintf(stderr, "[pw_prof] %-20s %6.2f%%  %.1f cycles/step\n", names[i], 100.0 * hp[i] / tot, (double)hp[i] / (double)h[1]);
+        for (int i = 8; i < 16; i++) fprintf(stderr, "[pw_prof] %-20s %.3f /step\n", names[i], (double)hp[i] / (double)h[1]);
+    }
+#endif
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
     st.rng_kernel_ms = ms;

@@ -53,6 +53,12 @@ struct CsrDev {
     // search -- the per-step critical path is a chain of memory latencies, not bandwidth.
     const uint64_t *__restrict__ tab_off;
     const uint64_t *__restrict__ slots;
+    // tri[e] = |N(u) & N(v)| for CSR entry e = (u -> v): the number of common neighbours of the two
+    // endpoints (a per-edge triangle count, built once).  With it the normaliser `tot` of a step is
+    // known BEFORE any membership work, so the membership test can stop as soon as the CDF search
+    // has found its element (on average half of the keys are never touched).  nullptr: not built
+    // (graphs with self loops, or PW_NO_LAZY).
+    const uint32_t *__restrict__ tri;
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -91,7 +97,33 @@ struct WalkArgs {
     uint32_t *out;                            // [n_jobs, L + 2]
     unsigned long long *job_counter;
     unsigned long long *stats;  // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
+    float w_out, w_prev;        // fl32(1/q), fl32(1/p): the unit-weight biases (host computed)
+    uint32_t lazy_ok;           // both are powers of two in a safe exponent range (lazy path precondition)
 };
+#define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
+
+// Optional per-section cycle accounting (-DPW_PROF builds only; tools/prof_sections.sh).
+#ifdef PW_PROF
+__device__ unsigned long long g_prof[16];
+struct Prof {
+    unsigned long long *acc;   // LDS, per wave: [0..7] cycles per section, [8..15] event counts
+    unsigned long long last;
+};
+__device__ __forceinline__ void prof_tick(Prof &p, int i) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (__lane_id() == 0) p.acc[i] += now - p.last;
+    p.last = __builtin_readcyclecounter();
+}
+__device__ __forceinline__ void prof_count(Prof &p, int i, unsigned long long n = 1) {
+    if (__lane_id() == 0) p.acc[i] += n;
+}
+#define PROF_TICK(p, i) prof_tick(p, i)
+#define PROF_COUNT(p, i, n) prof_count(p, i, n)
+#else
+struct Prof {};
+#define PROF_TICK(p, i)
+#define PROF_COUNT(p, i, n)
+#endif
 
 __device__ __forceinline__ uint32_t filter_hash(uint32_t v) {
     uint32_t h = v * 0x9E3779B1u;
@@ -824,6 +856,143 @@ __device__ __forceinline__ uint32_t sample_step_unit(const WalkArgs &a, uint32_t
     return d;
 }
 
+// ---- lazy unit-weight transition ------------------------------------------------------------------------
+// Same result as sample_step_unit, but membership is established progressively, in row order, and
+// only as far as the CDF search needs it:
+//   tot     = from the per-edge common-neighbour count tri[e(prev->cur)] (closed form, exact)
+//   keys    = chunks of 64 entries of the shorter row, ascending; after a chunk every position of
+//             cur's row below `known_end` has its final class (gather: the chunk itself; scatter:
+//             everything up to the last common neighbour found so far)
+//   search  = the closed-form chain runs over [k, known_end) whenever the exact-arithmetic mass of
+//             the known prefix reaches r (minus a bound on the float drift), and resumes later if
+//             it ended short.
+// Returns LAZY_FALLBACK when a precondition fails (caller uses the eager path).
+constexpr uint32_t LAZY_FALLBACK = 0xfffffffeu;
+
+__device__ __forceinline__ uint32_t adj_lookup_g(gptr<uint64_t> tab, uint32_t size_mask, uint32_t v, bool active) {
+    uint32_t idx = adj_hash(v, size_mask);
+    uint32_t res = 0xffffffffu;
+    while (active) {
+        const uint64_t e = tab[idx];
+        if (e == SLOT_EMPTY) active = false;
+        else if ((uint32_t)e == v) { res = (uint32_t)(e >> 32); active = false; }
+        else idx = (idx + 1) & size_mask;
+    }
+    return res;
+}
+// the same probe sequence with wave-uniform operands: runs on the scalar unit
+__device__ __forceinline__ uint32_t adj_lookup_s(sptr<uint64_t> tab, uint32_t size_mask, uint32_t v) {
+    uint32_t idx = adj_hash(v, size_mask);
+    for (;;) {
+        const uint64_t e = tab[idx];
+        if (e == SLOT_EMPTY) return 0xffffffffu;
+        if ((uint32_t)e == v) return (uint32_t)(e >> 32);
+        idx = (idx + 1) & size_mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16_t *rank, uint32_t cur,
+                                                          uint32_t prev, uint32_t e_pc, uint32_t t0, uint32_t dp,
+                                                          double r, uint32_t s0, uint32_t d, Prof &pf) {
+    const int lane = lane_id();
+    const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
+    if (p_tri == 0 || e_pc == NOT_FOUND || d > SEG || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
+    const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
+
+    // position of prev in cur's row: scalar probe of cur's adjacency index
+    const sptr<uint64_t> tab_off = as_scalar<uint64_t>(PW_KARG(uint64_t, g.tab_off));
+    const uint64_t ctb0 = tab_off[cur];
+    const uint32_t ctmask = (uint32_t)(tab_off[cur + 1] - ctb0) - 1u;
+    const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
+    const uint32_t prev_pos = adj_lookup_s(as_scalar<uint64_t>(p_slots) + ctb0, ctmask, prev);   // 0xffffffff == NOT_FOUND
+    const uint32_t n_in = as_scalar<uint32_t>(p_tri)[e_pc];
+    const uint32_t n_pv = prev_pos != NOT_FOUND ? 1u : 0u;
+    if (n_in + n_pv > d) return LAZY_FALLBACK;
+    const uint32_t n_out = d - n_in - n_pv;
+    float u = 1.0f;
+    if (n_out && w_out < u) u = w_out;
+    if (n_pv && w_prev < u) u = w_prev;
+    const double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
+    if (!(td <= 16777216.0 * (double)u)) return LAZY_FALLBACK;   // every partial sum exact: tot = exact sum
+    const float tot = uni((float)td);
+    // w_out, w_prev are powers of two: w / tot == w * (1 / tot) exactly (one correctly rounded division)
+    const float x_in = uni(1.0f / tot), x_out = uni(x_in * w_out), x_prev = uni(x_in * w_prev);
+    const double dx_in = (double)x_in, dx_out = (double)x_out, dx_prev = (double)x_prev;   // estimates only
+
+    const uint32_t nwords_all = (d + 31) >> 5;
+    for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
+    wave_lds_fence();
+
+    const bool scatter = dp <= d;
+    const uint32_t k0 = scatter ? t0 : s0;
+    const gptr<uint32_t> krow = as_global<uint32_t>(PW_KARG(uint64_t, g.indices)) + k0;
+    const gptr<uint32_t> kfrac = as_global<uint32_t>(PW_KARG(uint64_t, g.ipos)) + k0;
+    const uint32_t kn = scatter ? dp : d;
+    const uint32_t sv = scatter ? cur : prev;
+    const sptr<uint32_t> foff = as_scalar<uint32_t>(PW_KARG(uint64_t, g.foff));
+    const uint32_t f0 = foff[sv];
+    const uint32_t nw_mask = foff[sv + 1] - f0 - 1u;
+    const gptr<uint64_t> fb = as_global<uint64_t>(PW_KARG(uint64_t, g.fbits)) + f0;
+    uint64_t tb0 = ctb0;
+    uint32_t tmask = ctmask;
+    if (!scatter) {
+        tb0 = tab_off[prev];
+        tmask = (uint32_t)(tab_off[prev + 1] - tb0) - 1u;
+    }
+    const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + tb0;
+
+    PROF_TICK(pf, 1);
+    float c = 0.0f;
+    uint32_t k = 0, known_end = 0, cnt_in = 0, found = NOT_FOUND;
+    for (uint32_t base = 0; base < kn; base += WAVE) {
+        const uint32_t i = base + lane;
+        const bool valid = i < kn;
+        const uint32_t key = valid ? krow[i] : 0u;
+        const uint32_t frac = valid ? kfrac[i] : 0u;
+        const uint64_t bits = filter_bits(filter_hash(key));
+        const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
+        const bool pass = valid && (word & bits) == bits;
+        const uint32_t gpos = adj_lookup_g(tab, tmask, key, pass);
+        const bool hit = pass && gpos != 0xffffffffu;
+        const uint64_t hb = ballot(hit);
+        if (scatter) {
+            if (hit) atomicOr(&mask[gpos >> 5], 1u << (gpos & 31));
+            // keys ascend, so do the found positions: the last hit lane holds the largest
+            if (hb) known_end = readlane_u32(gpos, 63 - __builtin_clzll(hb)) + 1;
+            if (base + WAVE >= kn) known_end = d;   // every neighbour of prev has been looked up
+        } else {
+            if (lane == 0) mask[base >> 5] = (uint32_t)hb;
+            if (lane == 32) mask[(base >> 5) + 1] = (uint32_t)(hb >> 32);
+            known_end = base + WAVE < d ? base + WAVE : d;
+        }
+        cnt_in += (uint32_t)__popcll(hb);
+        PROF_TICK(pf, 2);
+        PROF_COUNT(pf, 8, 1);
+        if (known_end <= k) continue;
+        // exact-arithmetic mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
+        const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
+        const double est = (double)cnt_in * dx_in + (double)(known_end - cnt_in - pv_k) * dx_out + (double)pv_k * dx_prev;
+        if (known_end < d && est + (double)known_end * 2.4e-7 + 1e-9 < r) continue;
+        wave_lds_fence();
+        build_rank(mask, rank, (known_end + 31) >> 5);
+        PROF_TICK(pf, 3);
+        PROF_COUNT(pf, 9, 1);
+        const UnitRow ur{mask, rank, 0u, known_end, prev_pos, true};
+        const RowVals<float, true> rv = make_unit_vals<float>(mask, 0u, known_end, prev_pos, true, x_in, x_out, x_prev);
+        if (k == 0) {
+            const bool hit0 = seq_head<float, true>(c, k, known_end, r, rv, WAVE, found);
+            PROF_TICK(pf, 4);
+            if (hit0) return found;
+        }
+        if (k < known_end) {
+            const int rc = unit_chain<float, true>(c, k, known_end, r, ur, rv, x_in, x_out, x_prev, found);
+            PROF_TICK(pf, 5);
+            if (rc == SCAN_FOUND) return found;
+        }
+    }
+    return d;  // the float CDF never reached r (mirrored overflow read)
+}
+
 // ---- general (weighted) transition -------------------------------------------------------------------
 // Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
 template <typename T, bool DENSE>
@@ -915,70 +1084,103 @@ walk_kernel(WalkArgs a) {
     uint32_t *mask = s_mask[wave];
     uint32_t *queue = s_queue[DENSE ? 0 : wave];
     uint16_t *rank = s_rank[UNIT ? wave : 0];
-    const uint32_t *__restrict__ indptr = a.g.indptr;
-    const uint32_t *__restrict__ indices = a.g.indices;
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
-    const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
-    const uint32_t nnz = a.g.nnz;
+    // per-wave statistics live in LDS: [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
+    __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][4];
+    unsigned long long *stat = s_stat[wave];
+    if (lane < 4) stat[lane] = 0;
+    Prof pf;
+#ifdef PW_PROF
+    __shared__ unsigned long long s_prof[WAVES_PER_BLOCK][16];
+    pf.acc = s_prof[wave];
+    if (lane < 16) pf.acc[lane] = 0;
+    pf.last = __builtin_readcyclecounter();
+#endif
+    wave_lds_fence();
 
-    unsigned long long st_steps = 0, st_over = 0, st_clamp = 0, st_dead = 0;
-
+    // Wave-uniform reads of the read-only arrays go through the scalar unit (wave.h); the pointers are
+    // re-read from the kernarg segment where they are used instead of being kept live.
     for (;;) {
         unsigned long long widx = 0;
-        if (lane == 0) widx = atomicAdd(a.job_counter, 1ull);
+        if (lane == 0) widx = atomicAdd((unsigned long long *)PW_KARG(uint64_t, job_counter), 1ull);
         widx = readfirst_u64(widx);
-        if (widx >= n_work) break;
-        const uint64_t job = a.job_list ? (uint64_t)uni(a.job_list[widx]) : (uint64_t)widx;
-        uint32_t *row = a.out + job * W;
-        const uint32_t start = uni(a.starts[job]);
-        const uint64_t soff = readfirst_u64(a.stream_off[job]) - a.rng_base;
+        const uint64_t p_list = PW_KARG(uint64_t, job_list);
+        if (widx >= (p_list ? PW_KARG(uint64_t, n_list) : PW_KARG(uint64_t, n_jobs))) break;
+        const uint64_t job = p_list ? (uint64_t)as_scalar<uint32_t>(p_list)[widx] : (uint64_t)widx;
+        const uint32_t start = as_scalar<uint32_t>(PW_KARG(uint64_t, starts))[job];
+        const uint64_t soff = as_scalar<uint64_t>(PW_KARG(uint64_t, stream_off))[job] - PW_KARG(uint64_t, rng_base);
 
         uint32_t cur = start, prev = 0;
-        uint32_t s0 = uni(indptr[cur]);
-        uint32_t d = uni(indptr[cur + 1]) - s0;
+        uint32_t s0, d;
+        {
+            const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+            s0 = indptr[cur];
+            d = indptr[cur + 1] - s0;
+        }
         uint32_t t0 = 0, dp = 0;  // row of prev (= row of cur one step earlier)
+        uint32_t e_pc = NOT_FOUND; // CSR index of the edge prev -> cur (NOT_FOUND after an overflow read)
         uint32_t len_out = L + 1;
-        double rbuf = 0.0;        // lane l holds the draw of step (64 * block + l)
         uint32_t j = 1;
         for (; j <= L; j++) {
-            if (d == 0) { len_out = j; if (j > 1) st_dead++; break; }
-            const uint32_t jr = (j - 1) & (WAVE - 1);
-            if (jr == 0) {
-                uint32_t idx = (j - 1) + (uint32_t)lane;
-                rbuf = idx < L ? a.rng[soff + idx] : 0.0;
+            if (d == 0) {
+                len_out = j;
+                if (j > 1 && lane == 0) stat[3]++;
+                break;
             }
-            const double r = readlane_f64(rbuf, (int)jr);
+            const double r = as_scalar<double>(PW_KARG(uint64_t, rng))[soff + (j - 1)];
             uint32_t choice;
-            if (UNIT) choice = sample_step_unit<T, DENSE>(a, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
+            if (UNIT) {
+                choice = LAZY_FALLBACK;
+#ifndef PW_NO_LAZY
+                PROF_TICK(pf, 0);
+                if (!DENSE && j >= 2) choice = sample_step_unit_lazy(mask, rank, cur, prev, e_pc, t0, dp, r, s0, d, pf);
+#endif
+                if (choice == LAZY_FALLBACK) {
+                    PROF_TICK(pf, 1);
+                    choice = sample_step_unit<T, DENSE>(a, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
+                    PROF_TICK(pf, 6);
+                    PROF_COUNT(pf, 10, 1);
+                }
+            }
             else choice = sample_step_weighted<T, DENSE>(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, queue, cur,
                                                           j >= 2, prev, t0, dp, r, s0, d);
+            choice = uni(choice);
+            bool clamped = false;
             if (choice >= d) {
-                st_over++;
-                if (DENSE) { choice = d - 1; st_clamp++; }  // reference reads past a temporary: clamp
+                if (lane == 0) stat[1]++;
+                if (DENSE) { choice = d - 1; clamped = true; }  // reference reads past a temporary: clamp
             }
             uint64_t pos = (uint64_t)s0 + choice;
-            if (pos >= nnz) { pos = nnz - 1; st_clamp++; }
-            const uint32_t nxt = uni(indices[pos]);
-            if (lane == 0) row[j] = nxt;
+            const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
+            if (pos >= nnz) { pos = nnz - 1; clamped = true; }
+            if (clamped && lane == 0) stat[2]++;
+            const uint32_t nxt = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[pos];
+            if (lane == 0) ((gptr_mut<uint32_t>)PW_KARG(uint64_t, out))[job * W + j] = nxt;
+            e_pc = choice < d ? (uint32_t)pos : NOT_FOUND;
             prev = cur;
             t0 = s0;
             dp = d;
             cur = nxt;
-            s0 = uni(indptr[cur]);
-            d = uni(indptr[cur + 1]) - s0;
-            st_steps++;
+            const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+            s0 = indptr[cur];
+            d = indptr[cur + 1] - s0;
         }
         // header, tail zeros and length cell (cells j..L stay 0 after an early stop)
-        if (lane == 0) { row[0] = start; row[L + 1] = len_out; }
+        gptr_mut<uint32_t> row = (gptr_mut<uint32_t>)PW_KARG(uint64_t, out) + job * W;
+        if (lane == 0) {
+            row[0] = start;
+            row[L + 1] = len_out;
+            stat[0] += j - 1;   // transitions sampled by this walk
+        }
         for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
     }
-    if (lane == 0) {
-        if (st_steps) atomicAdd(&a.stats[0], st_steps);
-        if (st_over) atomicAdd(&a.stats[1], st_over);
-        if (st_clamp) atomicAdd(&a.stats[2], st_clamp);
-        if (st_dead) atomicAdd(&a.stats[3], st_dead);
-    }
+    wave_lds_fence();
+#ifdef PW_PROF
+    PROF_TICK(pf, 0);
+    if (lane < 16) atomicAdd(&g_prof[lane], pf.acc[lane]);
+#endif
+    if (lane < 4 && stat[lane]) atomicAdd(&a.stats[lane], stat[lane]);
 }
 
 }  // namespace pw

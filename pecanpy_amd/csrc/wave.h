@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 namespace pw {
 
@@ -56,6 +57,24 @@ __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---- scalar-unit access ------------------------------------------------------------------------------
+// The walk kernel carries far more wave-uniform state than the 102 SGPRs of a wave; what the allocator
+// cannot keep it parks in VGPR lanes, and every v_readlane/v_writelane it then emits takes a VALU issue
+// slot (a quarter of the kernel's VALU instructions before this was introduced).  Two remedies:
+//   kernarg<T>(off)  re-reads a kernel argument from the kernarg segment at the point of use (s_load,
+//                    volatile so that it is neither hoisted nor kept live), and
+//   sptr<T>          constant-address-space view of READ-ONLY device arrays: a load through it with a
+//                    wave-uniform address is an s_load (no VGPR, no readfirstlane, no VALU slot).
+template <typename T> using sptr = const __attribute__((address_space(4))) T *;
+template <typename T> using gptr = const __attribute__((address_space(1))) T *;
+template <typename T> using gptr_mut = __attribute__((address_space(1))) T *;
+template <typename T> __device__ __forceinline__ sptr<T> as_scalar(uint64_t addr) { return (sptr<T>)addr; }
+template <typename T> __device__ __forceinline__ gptr<T> as_global(uint64_t addr) { return (gptr<T>)addr; }
+template <typename T> __device__ __forceinline__ T kernarg(size_t off) {
+    sptr<uint8_t> base = (sptr<uint8_t>)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(volatile const __attribute__((address_space(4))) T *)(base + off);
 }
 
 }  // namespace pw
