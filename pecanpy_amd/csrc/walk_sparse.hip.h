@@ -896,7 +896,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
                                                           double r, uint32_t s0, uint32_t d, Prof &pf) {
     const int lane = lane_id();
     const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
-    if (p_tri == 0 || e_pc == NOT_FOUND || d > SEG || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
+    if (p_tri == 0 || e_pc == NOT_FOUND || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
     const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
 
     // position of prev in cur's row: scalar probe of cur's adjacency index
@@ -919,7 +919,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const float x_in = uni(1.0f / tot), x_out = uni(x_in * w_out), x_prev = uni(x_in * w_prev);
     const double dx_in = (double)x_in, dx_out = (double)x_out, dx_prev = (double)x_prev;   // estimates only
 
-    const uint32_t nwords_all = (d + 31) >> 5;
+    const uint32_t nwords_all = ((d < SEG ? d : SEG) + 31) >> 5;
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
     wave_lds_fence();
 
@@ -942,43 +942,62 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + tb0;
 
     PROF_TICK(pf, 1);
+    // Rows longer than the LDS mask (SEG positions) are served through a sliding window [wb, wb + SEG):
+    // the chain consumes a window completely before the mask is reused for the next one.
     float c = 0.0f;
     uint32_t k = 0, known_end = 0, cnt_in = 0, found = NOT_FOUND;
-    for (uint32_t base = 0; base < kn; base += WAVE) {
-        const uint32_t i = base + lane;
-        const bool valid = i < kn;
-        const uint32_t key = valid ? krow[i] : 0u;
-        const uint32_t frac = valid ? kfrac[i] : 0u;
-        const uint64_t bits = filter_bits(filter_hash(key));
-        const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
-        const bool pass = valid && (word & bits) == bits;
-        const uint32_t gpos = adj_lookup_g(tab, tmask, key, pass);
-        const bool hit = pass && gpos != 0xffffffffu;
-        const uint64_t hb = ballot(hit);
-        if (scatter) {
-            if (hit) atomicOr(&mask[gpos >> 5], 1u << (gpos & 31));
-            // keys ascend, so do the found positions: the last hit lane holds the largest
-            if (hb) known_end = readlane_u32(gpos, 63 - __builtin_clzll(hb)) + 1;
-            if (base + WAVE >= kn) known_end = d;   // every neighbour of prev has been looked up
+    uint32_t wb = 0, base = 0;
+    while (k < d) {
+        const uint32_t wend = d - wb < SEG ? d : wb + SEG;   // end of the current window
+        if (base < kn) {
+            const uint32_t i = base + lane;
+            const bool valid = i < kn;
+            const uint32_t key = valid ? krow[i] : 0u;
+            const uint32_t frac = valid ? kfrac[i] : 0u;
+            const uint64_t bits = filter_bits(filter_hash(key));
+            const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
+            const bool pass = valid && (word & bits) == bits;
+            const uint32_t gpos = adj_lookup_g(tab, tmask, key, pass);
+            const bool hit = pass && gpos != 0xffffffffu;
+            if (scatter) {
+                // keys ascend, so do the found positions
+                const bool inw = hit && gpos >= wb && gpos < wend;
+                const uint64_t hb = ballot(inw);
+                const bool beyond = ballot(hit && gpos >= wend) != 0;
+                if (inw) atomicOr(&mask[(gpos - wb) >> 5], 1u << ((gpos - wb) & 31));
+                if (hb) known_end = readlane_u32(gpos, 63 - __builtin_clzll(hb)) + 1;
+                cnt_in += (uint32_t)__popcll(hb);
+                if (beyond) known_end = wend;             // the rest of this chunk belongs to later windows
+                else {
+                    base += WAVE;
+                    if (base >= kn) known_end = wend;     // every neighbour of prev has been looked up
+                }
+            } else {
+                const uint64_t hb = ballot(hit);
+                if (lane == 0) mask[(base - wb) >> 5] = (uint32_t)hb;
+                if (lane == 32) mask[((base - wb) >> 5) + 1] = (uint32_t)(hb >> 32);
+                cnt_in += (uint32_t)__popcll(hb);
+                base += WAVE;
+                known_end = base < d ? base : d;
+            }
         } else {
-            if (lane == 0) mask[base >> 5] = (uint32_t)hb;
-            if (lane == 32) mask[(base >> 5) + 1] = (uint32_t)(hb >> 32);
-            known_end = base + WAVE < d ? base + WAVE : d;
+            known_end = wend;   // no keys left: everything from here on is "out" (or prev itself)
         }
-        cnt_in += (uint32_t)__popcll(hb);
         PROF_TICK(pf, 2);
         PROF_COUNT(pf, 8, 1);
         if (known_end <= k) continue;
-        // exact-arithmetic mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
-        const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
-        const double est = (double)cnt_in * dx_in + (double)(known_end - cnt_in - pv_k) * dx_out + (double)pv_k * dx_prev;
-        if (known_end < d && est + (double)known_end * 2.4e-7 + 1e-9 < r) continue;
+        if (known_end < wend) {
+            // exact-arithmetic mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
+            const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
+            const double est = (double)cnt_in * dx_in + (double)(known_end - cnt_in - pv_k) * dx_out + (double)pv_k * dx_prev;
+            if (est + (double)known_end * 2.4e-7 + 1e-9 < r) continue;
+        }
         wave_lds_fence();
-        build_rank(mask, rank, (known_end + 31) >> 5);
+        build_rank(mask, rank, (known_end - wb + 31) >> 5);
         PROF_TICK(pf, 3);
         PROF_COUNT(pf, 9, 1);
-        const UnitRow ur{mask, rank, 0u, known_end, prev_pos, true};
-        const RowVals<float, true> rv = make_unit_vals<float>(mask, 0u, known_end, prev_pos, true, x_in, x_out, x_prev);
+        const UnitRow ur{mask, rank, wb, known_end - wb, prev_pos, true};
+        const RowVals<float, true> rv = make_unit_vals<float>(mask, wb, known_end, prev_pos, true, x_in, x_out, x_prev);
         if (k == 0) {
             const bool hit0 = seq_head<float, true>(c, k, known_end, r, rv, WAVE, found);
             PROF_TICK(pf, 4);
@@ -988,6 +1007,12 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
             const int rc = unit_chain<float, true>(c, k, known_end, r, ur, rv, x_in, x_out, x_prev, found);
             PROF_TICK(pf, 5);
             if (rc == SCAN_FOUND) return found;
+        }
+        if (known_end == wend && wend < d) {   // window consumed: slide
+            wb = wend;
+            const uint32_t nw = ((d - wb < SEG ? d - wb : SEG) + 31) >> 5;
+            for (uint32_t w = lane; w < nw; w += WAVE) mask[w] = 0;
+            wave_lds_fence();
         }
     }
     return d;  // the float CDF never reached r (mirrored overflow read)
