@@ -917,7 +917,14 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const float tot = uni((float)td);
     // w_out, w_prev are powers of two: w / tot == w * (1 / tot) exactly (one correctly rounded division)
     const float x_in = uni(1.0f / tot), x_out = uni(x_in * w_out), x_prev = uni(x_in * w_prev);
-    const double dx_in = (double)x_in, dx_out = (double)x_out, dx_prev = (double)x_prev;   // estimates only
+    // Search trigger (a heuristic, exactness not needed): mass of a prefix in units of the smallest
+    // weight u -- integers below 2^24 by the precondition above, so plain scalar arithmetic.
+    const uint32_t sh_u = (__float_as_uint(u) >> 23) & 0xffu;
+    const uint32_t sh_in = 127u - sh_u, sh_out = ((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u,
+                   sh_prev = ((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u;
+    const double units = td * (double)(1u << (sh_in & 31u));       // td / u
+    const uint32_t units_i = uni((uint32_t)units);
+    const uint32_t r_units = uni((uint32_t)(r * units));
 
     const uint32_t nwords_all = ((d < SEG ? d : SEG) + 31) >> 5;
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
@@ -949,7 +956,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     uint32_t wb = 0, base = 0;
     while (k < d) {
         const uint32_t wend = d - wb < SEG ? d : wb + SEG;   // end of the current window
-        if (base < kn) {
+        if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
             const uint32_t i = base + lane;
             const bool valid = i < kn;
             const uint32_t key = valid ? krow[i] : 0u;
@@ -981,16 +988,17 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
                 known_end = base < d ? base : d;
             }
         } else {
-            known_end = wend;   // no keys left: everything from here on is "out" (or prev itself)
+            known_end = wend;   // every remaining position is "out" (or prev itself)
         }
         PROF_TICK(pf, 2);
         PROF_COUNT(pf, 8, 1);
         if (known_end <= k) continue;
         if (known_end < wend) {
-            // exact-arithmetic mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
+            // exact mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
             const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
-            const double est = (double)cnt_in * dx_in + (double)(known_end - cnt_in - pv_k) * dx_out + (double)pv_k * dx_prev;
-            if (est + (double)known_end * 2.4e-7 + 1e-9 < r) continue;
+            const uint32_t est = (cnt_in << (sh_in & 31u)) + ((known_end - cnt_in - pv_k) << (sh_out & 31u)) + (pv_k << (sh_prev & 31u));
+            const uint32_t slack = (uint32_t)(((uint64_t)known_end * units_i) >> 24) + 2u;
+            if (est + slack < r_units) continue;
         }
         wave_lds_fence();
         build_rank(mask, rank, (known_end - wb + 31) >> 5);
