@@ -790,8 +790,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(pw::g_prof), sizeof(hp)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pw::g_prof), zero, sizeof(zero)));
         static const char *names[16] = {"step pro/epilogue", "lazy setup", "membership chunks", "build_rank", "seq_head",
-                                        "unit_chain", "eager fallback", "-", "#chunks", "#searches", "#eager steps",
-                                        "#chain binades", "#chain tie fallbacks", "#search rounds", "-", "-"};
+                                        "unit_chain", "eager fallback", "exact search", "#chunks", "#searches", "#eager steps",
+                                        "#ambiguous", "#chain tie fallbacks", "#search rounds", "-", "-"};
         double tot = 0;
         for (int i = 0; i < 8; i++) tot += (double)hp[i];
         fprintf(stderr, "[pw_prof] steps=%llu\n", h[1]);

@@ -891,6 +891,35 @@ __device__ __forceinline__ uint32_t adj_lookup_s(sptr<uint64_t> tab, uint32_t si
     }
 }
 
+// Exact-arithmetic companion of unit_chain.  E(k) = mass of elements 0..k in units of the smallest
+// weight (integers, see the lazy step).  Returns the first k in [0, kend) with E(k) >= th and E(k)
+// through e_at, or kend when E(kend - 1) < th.  One 64-ary search, no binades.
+__device__ __forceinline__ uint32_t unit_search_units(const UnitRow &ur, uint32_t kend, uint32_t th, uint32_t sh_in,
+                                                      uint32_t sh_out, uint32_t sh_prev, uint32_t &e_at) {
+    const int lane = lane_id();
+    uint32_t lo = 0, hi = kend - 1;
+    for (;;) {
+        const uint32_t n = hi - lo + 1;
+        const uint32_t step = (n + WAVE - 1) / WAVE;
+        const uint64_t kp64 = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+        const uint32_t kp = kp64 > hi ? hi : (uint32_t)kp64;
+        const uint32_t cin = ur.rank_at(kp + 1);
+        const uint32_t cpv = ur.prev_pos <= kp ? 1u : 0u;   // NOT_FOUND compares greater than any position
+        const uint32_t cout = kp + 1 - cin - cpv;
+        const uint32_t G = (cin << sh_in) + (cout << sh_out) + (cpv << sh_prev);
+        const uint64_t hitm = ballot(G >= th);
+        if (!hitm) return kend;   // first round only
+        const int first = __builtin_ctzll(hitm);
+        if (step == 1) {
+            e_at = readlane_u32(G, first);
+            return lo + (uint32_t)first;
+        }
+        const uint64_t nhi = (uint64_t)lo + (uint64_t)(first + 1) * step - 1;
+        lo += (uint32_t)first * step;
+        if (nhi < hi) hi = (uint32_t)nhi;
+    }
+}
+
 __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16_t *rank, uint32_t cur,
                                                           uint32_t prev, uint32_t e_pc, uint32_t t0, uint32_t dp,
                                                           double r, uint32_t s0, uint32_t d, Prof &pf) {
@@ -920,9 +949,9 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     // Search trigger (a heuristic, exactness not needed): mass of a prefix in units of the smallest
     // weight u -- integers below 2^24 by the precondition above, so plain scalar arithmetic.
     const uint32_t sh_u = (__float_as_uint(u) >> 23) & 0xffu;
-    const uint32_t sh_in = 127u - sh_u, sh_out = ((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u,
-                   sh_prev = ((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u;
-    const double units = td * (double)(1u << (sh_in & 31u));       // td / u
+    const uint32_t sh_in = (127u - sh_u) & 31u, sh_out = (((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u) & 31u,
+                   sh_prev = (((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u) & 31u;   // unused classes: count 0
+    const double units = td * (double)(1u << sh_in);               // td / u
     const uint32_t units_i = uni((uint32_t)units);
     const uint32_t r_units = uni((uint32_t)(r * units));
 
@@ -954,6 +983,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     float c = 0.0f;
     uint32_t k = 0, known_end = 0, cnt_in = 0, found = NOT_FOUND;
     uint32_t wb = 0, base = 0;
+    bool exact_ok = true;
     while (k < d) {
         const uint32_t wend = d - wb < SEG ? d : wb + SEG;   // end of the current window
         if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
@@ -993,18 +1023,41 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         PROF_TICK(pf, 2);
         PROF_COUNT(pf, 8, 1);
         if (known_end <= k) continue;
-        if (known_end < wend) {
-            // exact mass of the known prefix vs r (float drift of the chain <= known_end * 2^-24)
-            const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
-            const uint32_t est = (cnt_in << (sh_in & 31u)) + ((known_end - cnt_in - pv_k) << (sh_out & 31u)) + (pv_k << (sh_prev & 31u));
-            const uint32_t slack = (uint32_t)(((uint64_t)known_end * units_i) >> 24) + 2u;
-            if (est + slack < r_units) continue;
-        }
+        // exact mass of the known prefix, in units; the float32 chain is within (k + 4) * 2^-24 of the exact
+        // partial sums (one rounding per addition, 2^-24 relative on the three values): z units
+        const uint32_t pv_k = (n_pv && prev_pos < known_end) ? 1u : 0u;
+        const uint32_t est = (cnt_in << sh_in) + ((known_end - cnt_in - pv_k) << sh_out) + (pv_k << sh_prev);
+        const uint32_t z = (uint32_t)(((uint64_t)(known_end + 4u) * units_i) >> 24) + 1u;
+        if (known_end < wend && est + z + 2u < r_units) continue;   // target not inside the known prefix yet
         wave_lds_fence();
         build_rank(mask, rank, (known_end - wb + 31) >> 5);
         PROF_TICK(pf, 3);
         PROF_COUNT(pf, 9, 1);
         const UnitRow ur{mask, rank, wb, known_end - wb, prev_pos, true};
+        if (exact_ok && k == 0 && wb == 0) {
+            // Decide in exact arithmetic when no partial sum lies next to the target.  With R = r * units
+            // (real) and c_i < r for i < j, the float chain obeys
+            //     |c_j - E(j) / units| <= ((j + 1) * (R + wmax) + R + wmax) * 2^-24 / units   =: zr / units
+            // (one relative rounding 2^-24 per addition of a sum below r + x_max, plus 2^-24 relative on
+            // the three values).  Hence every j below the first k1 with E(k1) >= ceil(R - zr) has c_j < r
+            // (induction on j), and E(k1) >= ceil(R + zr) gives c_k1 >= r: k1 is the chain's answer.
+            const double R = r * units;
+            const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
+            const double zr = ((double)(known_end + 6u) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;
+            const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
+            if (est >= hi_th) {
+                const double lo = R - zr;
+                const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
+                uint32_t e_at = 0;
+                const uint32_t k1 = unit_search_units(ur, known_end, lo_th, sh_in, sh_out, sh_prev, e_at);
+                PROF_TICK(pf, 7);
+                if (e_at >= hi_th) return k1;
+                PROF_COUNT(pf, 11, 1);
+            } else if (known_end < wend) {
+                continue;   // the prefix may still end below the target: keep loading
+            }
+            exact_ok = false;   // a partial sum sits next to the target (or r is near the total): float chain
+        }
         const RowVals<float, true> rv = make_unit_vals<float>(mask, wb, known_end, prev_pos, true, x_in, x_out, x_prev);
         if (k == 0) {
             const bool hit0 = seq_head<float, true>(c, k, known_end, r, rv, WAVE, found);
