@@ -122,7 +122,7 @@ mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 filter_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                    const uint32_t *__restrict__ foff, unsigned long long *fbits, uint32_t *ipos,
+                    const uint32_t *__restrict__ foff, unsigned long long *fbits, uint2 *kf,
                     uint32_t n_nodes, uint32_t nnz) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
     const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;
@@ -135,8 +135,9 @@ filter_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restr
         for (uint32_t k = lane; k < d; k += 64) {
             const uint32_t v = indices[s0 + k];
             const uint32_t frac = (uint32_t)(((unsigned long long)indptr[v] << 32) / nnz);
-            ipos[s0 + k] = frac;
-            atomicOr(&fbits[f0 + filter_word(frac, nw_mask)], (unsigned long long)filter_bits(filter_hash(v)));
+            const uint32_t fw = filter_fw(frac, v);
+            kf[s0 + k] = make_uint2(v, fw);
+            atomicOr(&fbits[f0 + filter_word(fw, nw_mask)], (unsigned long long)filter_bits(fw));
         }
     }
 }
@@ -184,10 +185,9 @@ tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint32_t *tri)
     const uint32_t tmask = (uint32_t)(g.tab_off[w + 1] - tb0) - 1u;
     uint32_t cnt = 0;
     for (uint32_t i = 0; i < kn; i++) {
-        const uint32_t key = g.indices[ks + i];
-        const uint64_t bits = filter_bits(filter_hash(key));
-        const uint64_t word = g.fbits[f0 + filter_word(g.ipos[ks + i], nw_mask)];
-        if ((word & bits) == bits && adj_lookup(g.slots + tb0, tmask, key, true) != 0xffffffffu) cnt++;
+        const uint2 kfw = g.kf[ks + i];
+        const uint64_t word = g.fbits[f0 + filter_word(kfw.y, nw_mask)];
+        if (filter_pass(word, kfw.y) && adj_lookup(g.slots + tb0, tmask, kfw.x, true) != 0xffffffffu) cnt++;
     }
     tri[e] = cnt;
 }

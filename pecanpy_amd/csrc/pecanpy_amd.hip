@@ -75,7 +75,7 @@ struct pw_graph {
     bool bits_only = false;          // dense graph created from packed bits: no compressed rows
     uint32_t *d_foff = nullptr;      // CSR graphs: per-row membership filters (offsets, bits)
     uint64_t *d_fbits = nullptr;
-    uint32_t *d_ipos = nullptr;      // CSR graphs: degree-CDF fraction of every CSR entry's neighbour
+    uint2 *d_kf = nullptr;           // CSR graphs: (neighbour id, filter word) per CSR entry
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
     uint32_t *d_tri = nullptr;                          // CSR graphs: per-edge common-neighbour counts
     uint32_t words_per_row = 0;
@@ -174,7 +174,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_deg) (void)hipFree(g->d_deg);
     if (g->d_foff) (void)hipFree(g->d_foff);
     if (g->d_fbits) (void)hipFree(g->d_fbits);
-    if (g->d_ipos) (void)hipFree(g->d_ipos);
+    if (g->d_kf) (void)hipFree(g->d_kf);
     if (g->d_tab_off) (void)hipFree(g->d_tab_off);
     if (g->d_slots) (void)hipFree(g->d_slots);
     if (g->d_tri) (void)hipFree(g->d_tri);
@@ -258,11 +258,11 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         rc = up((void **)&g->d_foff, foff.data(), sizeof(uint32_t) * foff.size());
         if (!rc) {
             hipError_t e = hipMalloc((void **)&g->d_fbits, sizeof(uint64_t) * (run ? run : 1));
-            if (e == hipSuccess) e = hipMalloc((void **)&g->d_ipos, sizeof(uint32_t) * (nnz ? nnz : 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&g->d_kf, sizeof(uint2) * (size_t)(nnz ? nnz : 1));
             if (e == hipSuccess) e = hipMemsetAsync(g->d_fbits, 0, sizeof(uint64_t) * (run ? run : 1), g->stream);
             if (e == hipSuccess && n_nodes && nnz) {
                 hipLaunchKernelGGL(pw::filter_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
-                                   g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, g->d_ipos, n_nodes, nnz);
+                                   g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, g->d_kf, n_nodes, nnz);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
@@ -489,7 +489,7 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.adjbits = g->d_adjbits;
     c.foff = g->d_foff;
     c.fbits = g->d_fbits;
-    c.ipos = g->d_ipos;
+    c.kf = g->d_kf;
     c.tab_off = g->d_tab_off;
     c.slots = g->d_slots;
     c.tri = g->d_tri;

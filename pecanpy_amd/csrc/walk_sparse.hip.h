@@ -40,13 +40,16 @@ struct CsrDev {
     // "x is a neighbour of u" is answered negatively with ONE cache-line access for ~90 % of the
     // non-neighbours; only the survivors pay the log2(d) probes of the exact search.
     // The word a neighbour id maps to is ORDER PRESERVING: word = floor(W * F(v)) with F the degree CDF of
-    // the graph (F(v) = indptr[v] / nnz, stored per CSR entry as a 32-bit fraction in `ipos`, so it
-    // arrives with the coalesced key load).  A row's neighbours are spread roughly uniformly by F
+    // the graph (F(v) = indptr[v] / nnz, stored next to every CSR entry in `kf`, so it arrives with
+    // the coalesced key load).  A row's neighbours are spread roughly uniformly by F
     // (neighbours are drawn ~ proportionally to degree), and the sorted keys of one wavefront load
     // hit consecutive filter words: a handful of cache lines per 64 keys instead of 64.
     const uint32_t *__restrict__ foff;
     const uint64_t *__restrict__ fbits;
-    const uint32_t *__restrict__ ipos;   // ipos[e] = floor(2^32 * indptr[indices[e]] / nnz)
+    // kf[e] = { indices[e], fw } with fw = the top 22 bits of floor(2^32 * indptr[indices[e]] / nnz) (word
+    // selector) | 10 hash bits of the neighbour id (its two filter bit positions): one 8-byte load per key,
+    // no hashing in the walk kernel.
+    const uint2 *__restrict__ kf;
     // exact adjacency index for the filter survivors: row u owns slots [tab_off[u], tab_off[u+1]) of an
     // open-addressing table (size next_pow2(2*degree)); slot = (position in row u) << 32 | neighbour id,
     // all ones = empty.  One probe (rarely two) replaces the ~log2(d) dependent probes of a binary
@@ -132,17 +135,28 @@ __device__ __forceinline__ uint32_t filter_hash(uint32_t v) {
     h ^= h >> 13;
     return h;
 }
-// word index inside the row's filter and the two-bit pattern of v
-// nw = nw_mask + 1 words (power of two): the top log2(nw) bits of the 32-bit CDF fraction
-__device__ __forceinline__ uint32_t filter_word(uint32_t frac, uint32_t nw_mask) {
-    return nw_mask ? (frac >> (32 - __popc(nw_mask))) : 0u;
+// fw of a neighbour id v with degree-CDF fraction frac (see CsrDev::kf)
+__device__ __forceinline__ uint32_t filter_fw(uint32_t frac, uint32_t v) {
+    return (frac & 0xFFFFFC00u) | (filter_hash(v) & 0x3FFu);
 }
-__device__ __forceinline__ uint64_t filter_bits(uint32_t h) { return (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)); }
+// word index inside the row's filter: nw = nw_mask + 1 words (power of two <= 2^22), the top log2(nw)
+// bits of the CDF fraction
+__device__ __forceinline__ uint32_t filter_word(uint32_t fw, uint32_t nw_mask) {
+    return nw_mask ? (fw >> (32 - __popc(nw_mask))) : 0u;
+}
+// the two filter bits of a key: bit (fw & 31) of the low half, bit ((fw >> 5) & 31) of the high half
+__device__ __forceinline__ uint64_t filter_bits(uint32_t fw) {
+    return (1ull << (fw & 31u)) | (1ull << (32u + ((fw >> 5) & 31u)));
+}
+__device__ __forceinline__ bool filter_pass(uint64_t word, uint32_t fw) {
+    return (__builtin_amdgcn_ubfe((uint32_t)word, fw, 1u) & __builtin_amdgcn_ubfe((uint32_t)(word >> 32), fw >> 5, 1u)) != 0u;
+}
 __host__ __device__ inline uint32_t filter_words_for_degree(uint32_t d) {
     if (d == 0) return 0;
     uint32_t p = 1;
     while (p < d) p <<= 1;      // next power of two >= d
-    return p >= 8 ? p / 8 : 1;  // 8 filter bits per (rounded) neighbour, at least one word
+    p = p >= 8 ? p / 8 : 1;     // 8 filter bits per (rounded) neighbour, at least one word
+    return p > (1u << 22) ? (1u << 22) : p;   // the word selector has 22 bits
 }
 
 constexpr uint64_t SLOT_EMPTY = ~0ull;
@@ -217,8 +231,6 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
                                                uint32_t t0, uint32_t dp, uint32_t *in_mask,
                                                const T *__restrict__ data) {
     const int lane = lane_id();
-    const uint32_t *__restrict__ crow = g.indices + s0 + a;
-    const uint32_t *__restrict__ prow = g.indices + t0;
     const float *__restrict__ thr = g.thr;
     uint32_t prev_pos = NOT_FOUND;
     const uint32_t nwords = (len + 31) >> 5;
@@ -227,8 +239,7 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
         if (in_mask) in_mask[w] = 0;
     }
     const bool scatter = dp <= len;                       // keys = row(prev), searched = cur's segment
-    const uint32_t *__restrict__ krow = scatter ? prow : crow;
-    const uint32_t *__restrict__ kfrac = g.ipos + (scatter ? t0 : s0 + a);   // CDF fractions of the keys
+    const uint2 *__restrict__ krow = g.kf + (scatter ? t0 : s0 + a);   // keys with their filter words
     const uint32_t kn = scatter ? dp : len;
     const uint32_t sv = scatter ? cur : prev;
     const uint32_t f0 = uni(g.foff[sv]);
@@ -277,11 +288,10 @@ __device__ __forceinline__ uint32_t build_mask(const CsrDev &g, uint32_t *mask, 
     for (uint32_t base = 0; base < kn; base += WAVE) {
         const uint32_t i = base + lane;
         const bool valid = i < kn;
-        const uint32_t key = valid ? krow[i] : 0u;
-        const uint32_t frac = valid ? kfrac[i] : 0u;
-        const uint64_t bits = filter_bits(filter_hash(key));
-        const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
-        const bool pass = valid && (word & bits) == bits;
+        const uint2 kfw = valid ? krow[i] : make_uint2(0u, 0u);
+        const uint32_t key = kfw.x;
+        const uint64_t word = valid ? fb[filter_word(kfw.y, nw_mask)] : 0ull;
+        const bool pass = valid && filter_pass(word, kfw.y);
         if (!scatter) {
             const uint64_t pb = ballot(valid && key == prev);
             if (pb) prev_pos = a + base + (uint32_t)__builtin_ctzll(pb);
@@ -961,8 +971,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
 
     const bool scatter = dp <= d;
     const uint32_t k0 = scatter ? t0 : s0;
-    const gptr<uint32_t> krow = as_global<uint32_t>(PW_KARG(uint64_t, g.indices)) + k0;
-    const gptr<uint32_t> kfrac = as_global<uint32_t>(PW_KARG(uint64_t, g.ipos)) + k0;
+    const gptr<uint64_t> krow = as_global<uint64_t>(PW_KARG(uint64_t, g.kf)) + k0;   // fw << 32 | key
     const uint32_t kn = scatter ? dp : d;
     const uint32_t sv = scatter ? cur : prev;
     const sptr<uint32_t> foff = as_scalar<uint32_t>(PW_KARG(uint64_t, g.foff));
@@ -989,11 +998,10 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
             const uint32_t i = base + lane;
             const bool valid = i < kn;
-            const uint32_t key = valid ? krow[i] : 0u;
-            const uint32_t frac = valid ? kfrac[i] : 0u;
-            const uint64_t bits = filter_bits(filter_hash(key));
-            const uint64_t word = valid ? fb[filter_word(frac, nw_mask)] : 0ull;
-            const bool pass = valid && (word & bits) == bits;
+            const uint64_t kfw = valid ? krow[i] : 0ull;
+            const uint32_t key = (uint32_t)kfw, fw = (uint32_t)(kfw >> 32);
+            const uint64_t word = valid ? fb[filter_word(fw, nw_mask)] : 0ull;
+            const bool pass = valid && filter_pass(word, fw);
             const uint32_t gpos = adj_lookup_g(tab, tmask, key, pass);
             const bool hit = pass && gpos != 0xffffffffu;
             if (scatter) {
@@ -1043,7 +1051,9 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
             // (induction on j), and E(k1) >= ceil(R + zr) gives c_k1 >= r: k1 is the chain's answer.
             const double R = r * units;
             const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
-            const double zr = ((double)(known_end + 6u) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;
+            // every element weighs at least one unit, so E(k) >= k + 1 and k1 < R: j + 1 <= min(known_end, R + 1)
+            const double jb = (double)known_end < R + 2.0 ? (double)known_end : R + 2.0;
+            const double zr = ((jb + 6.0) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;
             const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
             if (est >= hi_th) {
                 const double lo = R - zr;
