@@ -936,15 +936,28 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const int lane = lane_id();
     const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
     if (p_tri == 0 || e_pc == NOT_FOUND || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
+    // The step is a chain of memory latencies, so everything that depends only on (cur, prev, e_pc) is
+    // requested up front, in one batch: kernel arguments, the row descriptors of both vertices, the
+    // common-neighbour count and the first 64 keys.  Only then the dependent probe for prev's position.
     const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
+    const sptr<uint64_t> tab_off = as_scalar<uint64_t>(PW_KARG(uint64_t, g.tab_off));
+    const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
+    const sptr<uint32_t> foff = as_scalar<uint32_t>(PW_KARG(uint64_t, g.foff));
+    const uint64_t p_kf = PW_KARG(uint64_t, g.kf), p_fbits = PW_KARG(uint64_t, g.fbits);
+    const bool scatter = dp <= d;
+    const uint32_t k0 = scatter ? t0 : s0;
+    const uint32_t kn = scatter ? dp : d;
+    const uint32_t sv = scatter ? cur : prev;
+    const uint64_t ctb0 = tab_off[cur], ctb1 = tab_off[cur + 1];
+    const uint64_t ptb0 = tab_off[prev], ptb1 = tab_off[prev + 1];
+    const uint32_t n_in = as_scalar<uint32_t>(p_tri)[e_pc];
+    const uint32_t f0 = foff[sv], f1 = foff[sv + 1];
+    const gptr<uint64_t> krow = as_global<uint64_t>(p_kf) + k0;   // fw << 32 | key
+    uint64_t kfw_next = (uint32_t)lane < kn ? krow[lane] : 0ull;
 
     // position of prev in cur's row: scalar probe of cur's adjacency index
-    const sptr<uint64_t> tab_off = as_scalar<uint64_t>(PW_KARG(uint64_t, g.tab_off));
-    const uint64_t ctb0 = tab_off[cur];
-    const uint32_t ctmask = (uint32_t)(tab_off[cur + 1] - ctb0) - 1u;
-    const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
+    const uint32_t ctmask = (uint32_t)(ctb1 - ctb0) - 1u;
     const uint32_t prev_pos = adj_lookup_s(as_scalar<uint64_t>(p_slots) + ctb0, ctmask, prev);   // 0xffffffff == NOT_FOUND
-    const uint32_t n_in = as_scalar<uint32_t>(p_tri)[e_pc];
     const uint32_t n_pv = prev_pos != NOT_FOUND ? 1u : 0u;
     if (n_in + n_pv > d) return LAZY_FALLBACK;
     const uint32_t n_out = d - n_in - n_pv;
@@ -969,21 +982,10 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
     wave_lds_fence();
 
-    const bool scatter = dp <= d;
-    const uint32_t k0 = scatter ? t0 : s0;
-    const gptr<uint64_t> krow = as_global<uint64_t>(PW_KARG(uint64_t, g.kf)) + k0;   // fw << 32 | key
-    const uint32_t kn = scatter ? dp : d;
-    const uint32_t sv = scatter ? cur : prev;
-    const sptr<uint32_t> foff = as_scalar<uint32_t>(PW_KARG(uint64_t, g.foff));
-    const uint32_t f0 = foff[sv];
-    const uint32_t nw_mask = foff[sv + 1] - f0 - 1u;
-    const gptr<uint64_t> fb = as_global<uint64_t>(PW_KARG(uint64_t, g.fbits)) + f0;
-    uint64_t tb0 = ctb0;
-    uint32_t tmask = ctmask;
-    if (!scatter) {
-        tb0 = tab_off[prev];
-        tmask = (uint32_t)(tab_off[prev + 1] - tb0) - 1u;
-    }
+    const uint32_t nw_mask = f1 - f0 - 1u;
+    const gptr<uint64_t> fb = as_global<uint64_t>(p_fbits) + f0;
+    const uint64_t tb0 = scatter ? ctb0 : ptb0;
+    const uint32_t tmask = scatter ? ctmask : (uint32_t)(ptb1 - ptb0) - 1u;
     const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + tb0;
 
     PROF_TICK(pf, 1);
@@ -992,13 +994,18 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     float c = 0.0f;
     uint32_t k = 0, known_end = 0, cnt_in = 0, found = NOT_FOUND;
     uint32_t wb = 0, base = 0;
-    bool exact_ok = true;
+    bool exact_ok = true, advance = true;
+    uint64_t kfw = 0;
     while (k < d) {
         const uint32_t wend = d - wb < SEG ? d : wb + SEG;   // end of the current window
         if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
             const uint32_t i = base + lane;
             const bool valid = i < kn;
-            const uint64_t kfw = valid ? krow[i] : 0ull;
+            if (advance) {   // take the prefetched keys, request the next 64
+                kfw = kfw_next;
+                const uint32_t in = i + WAVE;
+                kfw_next = in < kn ? krow[in] : 0ull;
+            }
             const uint32_t key = (uint32_t)kfw, fw = (uint32_t)(kfw >> 32);
             const uint64_t word = valid ? fb[filter_word(fw, nw_mask)] : 0ull;
             const bool pass = valid && filter_pass(word, fw);
@@ -1012,6 +1019,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
                 if (inw) atomicOr(&mask[(gpos - wb) >> 5], 1u << ((gpos - wb) & 31));
                 if (hb) known_end = readlane_u32(gpos, 63 - __builtin_clzll(hb)) + 1;
                 cnt_in += (uint32_t)__popcll(hb);
+                advance = !beyond;
                 if (beyond) known_end = wend;             // the rest of this chunk belongs to later windows
                 else {
                     base += WAVE;
