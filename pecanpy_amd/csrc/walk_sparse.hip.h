@@ -105,6 +105,43 @@ struct WalkArgs {
 };
 #define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
 
+// Fresh copy of the kernel arguments for the rarely taken paths: read from the kernarg segment at the
+// point of use, so that none of it stays live (or spilled) across the hot path.
+__device__ __forceinline__ WalkArgs reload_walk_args() {
+    WalkArgs a;
+    a.g.indptr = (const uint32_t *)PW_KARG(uint64_t, g.indptr);
+    a.g.indices = (const uint32_t *)PW_KARG(uint64_t, g.indices);
+    a.g.data = (const void *)PW_KARG(uint64_t, g.data);
+    a.g.thr = (const float *)PW_KARG(uint64_t, g.thr);
+    a.g.adjbits = (const uint64_t *)PW_KARG(uint64_t, g.adjbits);
+    a.g.words_per_row = PW_KARG(uint32_t, g.words_per_row);
+    a.g.foff = (const uint32_t *)PW_KARG(uint64_t, g.foff);
+    a.g.fbits = (const uint64_t *)PW_KARG(uint64_t, g.fbits);
+    a.g.kf = (const uint2 *)PW_KARG(uint64_t, g.kf);
+    a.g.tab_off = (const uint64_t *)PW_KARG(uint64_t, g.tab_off);
+    a.g.slots = (const uint64_t *)PW_KARG(uint64_t, g.slots);
+    a.g.tri = (const uint32_t *)PW_KARG(uint64_t, g.tri);
+    a.g.n_nodes = PW_KARG(uint32_t, g.n_nodes);
+    a.g.nnz = PW_KARG(uint32_t, g.nnz);
+    a.p = PW_KARG(double, p);
+    a.q = PW_KARG(double, q);
+    a.L = PW_KARG(uint32_t, L);
+    a.n_jobs = 0;
+    a.starts = nullptr;
+    a.stream_off = nullptr;
+    a.job_list = nullptr;
+    a.n_list = 0;
+    a.rng = nullptr;
+    a.rng_base = 0;
+    a.out = nullptr;
+    a.job_counter = nullptr;
+    a.stats = nullptr;
+    a.w_out = PW_KARG(float, w_out);
+    a.w_prev = PW_KARG(float, w_prev);
+    a.lazy_ok = PW_KARG(uint32_t, lazy_ok);
+    return a;
+}
+
 // Optional per-section cycle accounting (-DPW_PROF builds only; tools/prof_sections.sh).
 #ifdef PW_PROF
 __device__ unsigned long long g_prof[16];
@@ -938,7 +975,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     if (p_tri == 0 || e_pc == NOT_FOUND || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
     // The step is a chain of memory latencies, so everything that depends only on (cur, prev, e_pc) is
     // requested up front, in one batch: kernel arguments, the row descriptors of both vertices, the
-    // common-neighbour count and the first 64 keys.  Only then the dependent probe for prev's position.
+    // common-neighbour count.  Only then the dependent probe for prev's position.
     const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
     const sptr<uint64_t> tab_off = as_scalar<uint64_t>(PW_KARG(uint64_t, g.tab_off));
     const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
@@ -953,7 +990,6 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const uint32_t n_in = as_scalar<uint32_t>(p_tri)[e_pc];
     const uint32_t f0 = foff[sv], f1 = foff[sv + 1];
     const gptr<uint64_t> krow = as_global<uint64_t>(p_kf) + k0;   // fw << 32 | key
-    uint64_t kfw_next = (uint32_t)lane < kn ? krow[lane] : 0ull;
 
     // position of prev in cur's row: scalar probe of cur's adjacency index
     const uint32_t ctmask = (uint32_t)(ctb1 - ctb0) - 1u;
@@ -994,18 +1030,13 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     float c = 0.0f;
     uint32_t k = 0, known_end = 0, cnt_in = 0, found = NOT_FOUND;
     uint32_t wb = 0, base = 0;
-    bool exact_ok = true, advance = true;
-    uint64_t kfw = 0;
+    bool exact_ok = true;
     while (k < d) {
         const uint32_t wend = d - wb < SEG ? d : wb + SEG;   // end of the current window
         if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
             const uint32_t i = base + lane;
             const bool valid = i < kn;
-            if (advance) {   // take the prefetched keys, request the next 64
-                kfw = kfw_next;
-                const uint32_t in = i + WAVE;
-                kfw_next = in < kn ? krow[in] : 0ull;
-            }
+            const uint64_t kfw = valid ? krow[i] : 0ull;
             const uint32_t key = (uint32_t)kfw, fw = (uint32_t)(kfw >> 32);
             const uint64_t word = valid ? fb[filter_word(fw, nw_mask)] : 0ull;
             const bool pass = valid && filter_pass(word, fw);
@@ -1019,7 +1050,6 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
                 if (inw) atomicOr(&mask[(gpos - wb) >> 5], 1u << ((gpos - wb) & 31));
                 if (hb) known_end = readlane_u32(gpos, 63 - __builtin_clzll(hb)) + 1;
                 cnt_in += (uint32_t)__popcll(hb);
-                advance = !beyond;
                 if (beyond) known_end = wend;             // the rest of this chunk belongs to later windows
                 else {
                     base += WAVE;
@@ -1027,8 +1057,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
                 }
             } else {
                 const uint64_t hb = ballot(hit);
-                if (lane == 0) mask[(base - wb) >> 5] = (uint32_t)hb;
-                if (lane == 32) mask[((base - wb) >> 5) + 1] = (uint32_t)(hb >> 32);
+                if (lane < 2) mask[((base - wb) >> 5) + lane] = lane ? (uint32_t)(hb >> 32) : (uint32_t)hb;
                 cnt_in += (uint32_t)__popcll(hb);
                 base += WAVE;
                 known_end = base < d ? base : d;
@@ -1188,7 +1217,7 @@ walk_kernel(WalkArgs a) {
     uint32_t *mask = s_mask[wave];
     uint32_t *queue = s_queue[DENSE ? 0 : wave];
     uint16_t *rank = s_rank[UNIT ? wave : 0];
-    const uint32_t L = a.L;
+    const uint32_t L = PW_KARG(uint32_t, L);
     const uint64_t W = (uint64_t)L + 2;
     // per-wave statistics live in LDS: [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
     __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][4];
@@ -1242,7 +1271,8 @@ walk_kernel(WalkArgs a) {
 #endif
                 if (choice == LAZY_FALLBACK) {
                     PROF_TICK(pf, 1);
-                    choice = sample_step_unit<T, DENSE>(a, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
+                    const WalkArgs la = reload_walk_args();
+                    choice = sample_step_unit<T, DENSE>(la, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
                     PROF_TICK(pf, 6);
                     PROF_COUNT(pf, 10, 1);
                 }
@@ -1284,7 +1314,7 @@ walk_kernel(WalkArgs a) {
     PROF_TICK(pf, 0);
     if (lane < 16) atomicAdd(&g_prof[lane], pf.acc[lane]);
 #endif
-    if (lane < 4 && stat[lane]) atomicAdd(&a.stats[lane], stat[lane]);
+    if (lane < 4 && stat[lane]) atomicAdd((unsigned long long *)PW_KARG(uint64_t, stats) + lane, stat[lane]);
 }
 
 }  // namespace pw
