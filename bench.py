@@ -181,7 +181,7 @@ def main():
         if tj and world == 1 and not args.weighted:
             traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
             traffic_note = ("FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch "
-                            "(profiles/r01_rmat22_pmc_v7.txt), uncorrected (scattered 4-8 B/lane probes)")
+                            "(profiles/r01_rmat22_pmc_v9.txt), uncorrected (scattered 4-8 B/lane probes)")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
@@ -190,8 +190,9 @@ def main():
         "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": round(k_ms, 3), "rng_expand_ms": round(float(np.mean(rng_ms)), 3),
         "note": "algorithmic bytes = sum over sampled steps of 8*d_cur+4*d_prev+28 (SURVEY 8(d)); "
-                "the kernel never streams rows (Bloom filter + hash index probes, closed-form CDF), "
-                "so the HBM counters show about half of the algorithmic bytes",
+                "the kernel never streams whole rows (lazy membership through Bloom filter + hash index "
+                "probes, per-edge common-neighbour counts, closed-form CDF search), so the HBM counters "
+                "show a fraction of the algorithmic bytes and frac exceeds 1",
     }
 
     cpu = None
