@@ -160,6 +160,21 @@ def test_hub_rows_longer_than_mask_segment(weighted):
     assert eng.last_stats["overflow_reads"] == ost.overflow_reads
 
 
+def test_self_loops_take_the_eager_step():
+    """Graphs with self loops get no common-neighbour counts (prev would be its own common neighbour):
+    every step runs the eager path and still matches the oracle."""
+    from pecanpy_amd.synth import csr_from_edges
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    s, d = rng.integers(0, n, 40000), rng.integers(0, n, 40000)
+    loops = rng.choice(n, 300, replace=False)
+    indptr, indices, data = csr_from_edges(np.concatenate([s, d, loops]), np.concatenate([d, s, loops]), n)
+    rows = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+    assert (rows == indices).sum() >= 300
+    _check_vs_oracle(indptr, indices, data, 0.5, 2, 2, 30, seed=8)
+
+
 def test_overflow_reads_are_mirrored():
     """choice == degree (float32 CDF short of 1) must read the next row's first neighbour
     exactly like the reference; RMAT-14 produces a few of those."""

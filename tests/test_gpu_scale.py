@@ -77,3 +77,22 @@ def test_full_size_shard_invariance(run):
     shard = run["eng"].simulate_device("SparseOTF", 0.5, 2, False, run["d_starts"][lo:hi].contiguous(), L,
                                        seed=SEED, stream_skip=skip)
     assert torch.equal(shard, run["out"][lo:hi])
+
+
+def test_full_size_lazy_step_equals_eager_step(run, monkeypatch):
+    """The lazy step (per-edge common-neighbour counts, progressive membership, exact-arithmetic
+    decision of the CDF search) must reproduce the eager float-chain step draw for draw: 4.4e8
+    transitions, far more boundary cases than the oracle-sized parity tests can reach."""
+    import torch
+
+    monkeypatch.setenv("PECANPY_AMD_NO_LAZY", "1")   # read by pw_csr_create: no `tri`, eager step only
+    eager = WalkEngine.from_csr(run["indptr"], run["indices"], None)
+    monkeypatch.delenv("PECANPY_AMD_NO_LAZY")
+    out = eager.simulate_device("SparseOTF", 0.5, 2, False, run["d_starts"], L, seed=SEED)
+    assert eager.last_stats["total_steps"] == run["stats"]["total_steps"]
+    assert eager.last_stats["overflow_reads"] == run["stats"]["overflow_reads"]
+    assert torch.equal(out, run["out"])
+    for p, q in ((0.25, 4.0), (2.0, 0.5), (1.0, 1.0)):
+        a = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
+        b = eager.simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
+        assert torch.equal(a, b), (p, q)
