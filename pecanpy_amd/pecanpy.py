@@ -115,12 +115,14 @@ class Base(BaseGraph):
         np.random.shuffle(starts)
         return starts
 
-    def simulate_walks_array(self, num_walks, walk_length):
+    def simulate_walks_array(self, num_walks, walk_length, gather=True):
         """The walk index matrix ``uint32[n_jobs, walk_length + 2]`` (what ``_random_walks``
-        returns in the reference); ``simulate_walks`` maps it to ID lists."""
+        returns in the reference); ``simulate_walks`` maps it to ID lists.  Under
+        ``torch.distributed`` with ``gather=False`` every rank gets ``(rows, (lo, hi))``: its own
+        slice [lo, hi) of that matrix, without the final collective."""
         self._preprocess_transition_probs()
         starts = self._start_array(num_walks)
-        return self._random_walks(starts, walk_length)
+        return self._random_walks(starts, walk_length, gather=gather)
 
     def simulate_walks_corpus(self, num_walks, walk_length):
         """Like ``simulate_walks`` but returns a lazy, re-iterable :class:`WalkCorpus`."""
@@ -131,7 +133,7 @@ class Base(BaseGraph):
         mat = self.simulate_walks_array(num_walks, walk_length)
         return [self._map_walk(row) for row in mat]
 
-    def _random_walks(self, starts, walk_length):
+    def _random_walks(self, starts, walk_length, gather=True):
         """GPU replacement of the reference's njit ``_random_walks`` (pecanpy.py:164-210)."""
         eng = self._get_engine()
         import torch.distributed as dist
@@ -141,13 +143,13 @@ class Base(BaseGraph):
                 raise NotImplementedError(
                     f"{self._mode} draws a variable number of random words per step; its seeded "
                     "stream cannot be sharded across GPUs -- run it in a single process")
-            return self._random_walks_sharded(eng, starts, walk_length)
+            return self._random_walks_sharded(eng, starts, walk_length, gather)
         mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length,
                            seed=self.random_state)
         self.last_stats = eng.last_stats
         return mat
 
-    def _random_walks_sharded(self, eng, starts, walk_length):
+    def _random_walks_sharded(self, eng, starts, walk_length, gather=True):
         import torch
 
         from .sharding import sharded_walk_matrix, to_uint32_numpy
@@ -173,8 +175,11 @@ class Base(BaseGraph):
             return (out.cpu() if host_comm else out), steps
 
         full = sharded_walk_matrix(run_shard, lambda sl: eng.count_stream_draws(sl, walk_length),
-                                   starts, walk_length)
+                                   starts, walk_length, gather=gather)
         self.last_stats = eng.last_stats
+        if not gather:
+            rows, bounds = full
+            return to_uint32_numpy(rows), bounds
         return to_uint32_numpy(full)
 
     def setup_get_normalized_probs(self):

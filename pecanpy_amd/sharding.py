@@ -2,8 +2,8 @@
 
 The (start node x num_walks) job array is embarrassingly parallel: the
 graph is replicated on every GPU, rank r walks the contiguous slice [lo_r, hi_r) of the *shuffled*
-job array, and the walk shards are gathered once at the end (RCCL over xGMI when the backend is
-``nccl``; ``gloo`` on CPU tensors in the unit tests).  The only cross-rank dependency is the stream
+job array, and the walk shards are either left on their GPUs (``gather=False``) or gathered once at
+the end (RCCL over xGMI when the backend is ``nccl``; ``gloo`` on CPU tensors in the unit tests).  The only cross-rank dependency is the stream
 address of each shard: rank r's first draw is double #(draws of all earlier shards) of the single
 MT19937 stream, obtained from an all-gather of per-shard draw counts.
 """
@@ -21,7 +21,7 @@ def _dist():
 
 
 def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None, dst=None,
-                        max_rounds=None):
+                        max_rounds=None, gather=True):
     """Walk ``starts`` cooperatively across the ranks of ``group``.
 
     run_shard(starts_slice, stream_skip) -> (walks, actual_draws)
@@ -30,7 +30,9 @@ def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None,
     count_draws(starts_slice) -> nominal number of draws of the slice (no dead ends assumed)
 
     Returns the full [n_jobs, walk_length + 2] tensor on every rank (``dst=None``) or only on
-    rank ``dst`` (others get ``None``).
+    rank ``dst`` (others get ``None``).  ``gather=False`` skips the collective: every rank gets
+    ``(walks_of_its_shard, (lo, hi))`` -- rows [lo, hi) of the full matrix, left where they were
+    produced (the jobs are independent; nothing downstream of the walks needs them on one device).
     """
     import torch
 
@@ -71,6 +73,8 @@ def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None,
         if after == counts or rounds >= limit:
             break
 
+    if not gather:
+        return walks, (lo, hi)
     # one gather of the shards (row counts differ by at most one: pad to the widest)
     width = walk_length + 2
     rows = max(b[1] - b[0] for b in bounds)

@@ -67,6 +67,10 @@ def _worker(rank, world, port, kind, ret):
         ret["runs_rank0"] = sum(1 for c in calls if c)
     only0 = sharded_walk_matrix(run_shard, count_draws, starts, L, dst=0)
     assert (only0 is None) == (rank != 0)
+    # no collective on the data path: every rank keeps rows [lo, hi) of the same matrix
+    local, (lo, hi) = sharded_walk_matrix(run_shard, count_draws, starts, L, gather=False)
+    assert (lo, hi) == tuple(shard_bounds(starts.size, world)[rank])
+    ret[f"local{rank}"] = (lo, hi, to_uint32_numpy(local))
     dist.destroy_process_group()
 
 
@@ -80,6 +84,9 @@ def test_two_rank_shards_reassemble_the_single_stream(kind):
         starts = orc.shuffled_starts(indptr.size - 1, 3, 3)
         want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 12, 3)
         assert np.array_equal(ret["full"], want)
+        for r in range(2):
+            lo, hi, rows = ret[f"local{r}"]
+            assert np.array_equal(rows, want[lo:hi])
         if kind == "directed_with_sinks":
             assert (want[:, -1] < 13).any()          # the case really has mid-walk dead ends
 
