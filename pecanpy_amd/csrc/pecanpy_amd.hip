@@ -78,6 +78,7 @@ struct pw_graph {
     uint2 *d_kf = nullptr;           // CSR graphs: (neighbour id, filter word) per CSR entry
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
     uint32_t *d_tri = nullptr;                          // CSR graphs: per-edge common-neighbour counts
+    uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -178,6 +179,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_tab_off) (void)hipFree(g->d_tab_off);
     if (g->d_slots) (void)hipFree(g->d_slots);
     if (g->d_tri) (void)hipFree(g->d_tri);
+    if (g->d_vrec) (void)hipFree(g->d_vrec);
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -246,8 +248,9 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
     if (!rc && !unit) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
     if (rc) { pw_graph_destroy(g); return rc; }
+    std::vector<uint32_t> foff((size_t)n_nodes + 1);
+    std::vector<uint64_t> off((size_t)n_nodes + 1);
     {   // per-row membership filters
-        std::vector<uint32_t> foff((size_t)n_nodes + 1);
         uint64_t run = 0;
         for (uint32_t i = 0; i < n_nodes; i++) {
             foff[i] = (uint32_t)run;
@@ -271,7 +274,6 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         if (rc) { pw_graph_destroy(g); return rc; }
     }
     {   // adjacency index: per-row open-addressing table of next_pow2(2 * degree) slots
-        std::vector<uint64_t> off((size_t)n_nodes + 1);
         uint64_t run = 0;
         for (uint32_t i = 0; i < n_nodes; i++) {
             off[i] = run;
@@ -295,6 +297,18 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
             if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
             if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("adjacency index build: ") + hipGetErrorString(e));
         }
+        if (rc) { pw_graph_destroy(g); return rc; }
+    }
+    {   // per-vertex records
+        if ((off[n_nodes] >> 1) > 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit index offsets"); }
+        std::vector<uint32_t> rec(4 * ((size_t)n_nodes + 1));
+        for (uint32_t i = 0; i <= n_nodes; i++) {
+            rec[4 * (size_t)i + 0] = indptr[i];
+            rec[4 * (size_t)i + 1] = i < n_nodes ? indptr[i + 1] - indptr[i] : 0u;
+            rec[4 * (size_t)i + 2] = foff[i];
+            rec[4 * (size_t)i + 3] = (uint32_t)(off[i] >> 1);   // table sizes are powers of two >= 2
+        }
+        rc = up((void **)&g->d_vrec, rec.data(), sizeof(uint32_t) * rec.size());
         if (rc) { pw_graph_destroy(g); return rc; }
     }
     if (unit && nnz && !getenv("PECANPY_AMD_NO_LAZY")) {
@@ -493,6 +507,7 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.tab_off = g->d_tab_off;
     c.slots = g->d_slots;
     c.tri = g->d_tri;
+    c.vrec = g->d_vrec;
     c.words_per_row = g->words_per_row;
     c.n_nodes = g->n_nodes;
     c.nnz = g->nnz;

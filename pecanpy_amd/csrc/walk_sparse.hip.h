@@ -56,6 +56,9 @@ struct CsrDev {
     // search -- the per-step critical path is a chain of memory latencies, not bandwidth.
     const uint64_t *__restrict__ tab_off;
     const uint64_t *__restrict__ slots;
+    // vrec[v] = { indptr[v], degree(v), foff[v], tab_off[v] / 2 }: everything the walk needs to know about
+    // a vertex in ONE 16-byte scalar load (filter and index sizes follow from the degree).
+    const uint4 *__restrict__ vrec;
     // tri[e] = |N(u) & N(v)| for CSR entry e = (u -> v): the number of common neighbours of the two
     // endpoints (a per-edge triangle count, built once).  With it the normaliser `tot` of a step is
     // known BEFORE any membership work, so the membership test can stop as soon as the CDF search
@@ -120,6 +123,7 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.g.kf = (const uint2 *)PW_KARG(uint64_t, g.kf);
     a.g.tab_off = (const uint64_t *)PW_KARG(uint64_t, g.tab_off);
     a.g.slots = (const uint64_t *)PW_KARG(uint64_t, g.slots);
+    a.g.vrec = (const uint4 *)PW_KARG(uint64_t, g.vrec);
     a.g.tri = (const uint32_t *)PW_KARG(uint64_t, g.tri);
     a.g.n_nodes = PW_KARG(uint32_t, g.n_nodes);
     a.g.nnz = PW_KARG(uint32_t, g.nnz);
@@ -195,6 +199,17 @@ __host__ __device__ inline uint32_t filter_words_for_degree(uint32_t d) {
     p = p >= 8 ? p / 8 : 1;     // 8 filter bits per (rounded) neighbour, at least one word
     return p > (1u << 22) ? (1u << 22) : p;   // the word selector has 22 bits
 }
+
+// sizes of a row's filter / adjacency index from its degree d >= 1 (the build code's rules, scalar ALU)
+__device__ __forceinline__ uint32_t next_pow2_u32(uint32_t x) {   // smallest power of two >= x, x >= 1
+    return x <= 1u ? 1u : 1u << (32 - __builtin_clz(x - 1u));
+}
+__device__ __forceinline__ uint32_t filter_mask_for_degree(uint32_t d) {
+    uint32_t p = next_pow2_u32(d);
+    p = p >= 8u ? p >> 3 : 1u;
+    return (p > (1u << 22) ? (1u << 22) : p) - 1u;
+}
+__device__ __forceinline__ uint32_t index_mask_for_degree(uint32_t d) { return next_pow2_u32(2u * d) - 1u; }
 
 constexpr uint64_t SLOT_EMPTY = ~0ull;
 __device__ __forceinline__ uint32_t adj_hash(uint32_t v, uint32_t size_mask) {
@@ -967,32 +982,34 @@ __device__ __forceinline__ uint32_t unit_search_units(const UnitRow &ur, uint32_
     }
 }
 
+// Vertex context carried by the walk loop: row start/degree plus the offsets of the row's filter and
+// adjacency index (one vrec load when the vertex is entered).
+struct VertexCtx {
+    uint32_t s0, d, f0, tb;   // tb = tab_off / 2
+};
+
 __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16_t *rank, uint32_t cur,
-                                                          uint32_t prev, uint32_t e_pc, uint32_t t0, uint32_t dp,
-                                                          double r, uint32_t s0, uint32_t d, Prof &pf) {
+                                                          uint32_t prev, uint32_t n_in, const VertexCtx &vc,
+                                                          const VertexCtx &vp, double r, Prof &pf) {
     const int lane = lane_id();
-    const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
-    if (p_tri == 0 || e_pc == NOT_FOUND || !PW_KARG(uint32_t, lazy_ok)) return LAZY_FALLBACK;
-    // The step is a chain of memory latencies, so everything that depends only on (cur, prev, e_pc) is
-    // requested up front, in one batch: kernel arguments, the row descriptors of both vertices, the
-    // common-neighbour count.  Only then the dependent probe for prev's position.
+    const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
+    // The step is a chain of memory latencies.  The vertex records of cur and prev and the
+    // common-neighbour count of the edge arrived with the previous step; what is left is the probe for
+    // prev's position in cur's row and the keys.
     const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
-    const sptr<uint64_t> tab_off = as_scalar<uint64_t>(PW_KARG(uint64_t, g.tab_off));
     const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
-    const sptr<uint32_t> foff = as_scalar<uint32_t>(PW_KARG(uint64_t, g.foff));
     const uint64_t p_kf = PW_KARG(uint64_t, g.kf), p_fbits = PW_KARG(uint64_t, g.fbits);
     const bool scatter = dp <= d;
     const uint32_t k0 = scatter ? t0 : s0;
     const uint32_t kn = scatter ? dp : d;
-    const uint32_t sv = scatter ? cur : prev;
-    const uint64_t ctb0 = tab_off[cur], ctb1 = tab_off[cur + 1];
-    const uint64_t ptb0 = tab_off[prev], ptb1 = tab_off[prev + 1];
-    const uint32_t n_in = as_scalar<uint32_t>(p_tri)[e_pc];
-    const uint32_t f0 = foff[sv], f1 = foff[sv + 1];
     const gptr<uint64_t> krow = as_global<uint64_t>(p_kf) + k0;   // fw << 32 | key
+    // first 64 keys: requested before the (dependent, scalar) probe below so that the two overlap
+    uint64_t kfw_first = 0;
+    if (n_in && (uint32_t)lane < kn) kfw_first = krow[lane];
 
     // position of prev in cur's row: scalar probe of cur's adjacency index
-    const uint32_t ctmask = (uint32_t)(ctb1 - ctb0) - 1u;
+    const uint32_t ctmask = index_mask_for_degree(d);
+    const uint64_t ctb0 = 2ull * vc.tb;
     const uint32_t prev_pos = adj_lookup_s(as_scalar<uint64_t>(p_slots) + ctb0, ctmask, prev);   // 0xffffffff == NOT_FOUND
     const uint32_t n_pv = prev_pos != NOT_FOUND ? 1u : 0u;
     if (n_in + n_pv > d) return LAZY_FALLBACK;
@@ -1018,11 +1035,11 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
     wave_lds_fence();
 
-    const uint32_t nw_mask = f1 - f0 - 1u;
-    const gptr<uint64_t> fb = as_global<uint64_t>(p_fbits) + f0;
-    const uint64_t tb0 = scatter ? ctb0 : ptb0;
-    const uint32_t tmask = scatter ? ctmask : (uint32_t)(ptb1 - ptb0) - 1u;
-    const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + tb0;
+    const VertexCtx &vs = scatter ? vc : vp;                    // the searched row: cur (scatter) or prev
+    const uint32_t nw_mask = filter_mask_for_degree(vs.d);
+    const gptr<uint64_t> fb = as_global<uint64_t>(p_fbits) + vs.f0;
+    const uint32_t tmask = scatter ? ctmask : index_mask_for_degree(dp);
+    const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + 2ull * vs.tb;
 
     PROF_TICK(pf, 1);
     // Rows longer than the LDS mask (SEG positions) are served through a sliding window [wb, wb + SEG):
@@ -1036,7 +1053,8 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         if (base < kn && cnt_in < n_in) {   // keys left and common neighbours still missing
             const uint32_t i = base + lane;
             const bool valid = i < kn;
-            const uint64_t kfw = valid ? krow[i] : 0ull;
+            uint64_t kfw = kfw_first;
+            if (base != 0) kfw = valid ? krow[i] : 0ull;
             const uint32_t key = (uint32_t)kfw, fw = (uint32_t)(kfw >> 32);
             const uint64_t word = valid ? fb[filter_word(fw, nw_mask)] : 0ull;
             const bool pass = valid && filter_pass(word, fw);
@@ -1245,17 +1263,27 @@ walk_kernel(WalkArgs a) {
         const uint64_t soff = as_scalar<uint64_t>(PW_KARG(uint64_t, stream_off))[job] - PW_KARG(uint64_t, rng_base);
 
         uint32_t cur = start, prev = 0;
-        uint32_t s0, d;
-        {
-            const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
-            s0 = indptr[cur];
-            d = indptr[cur + 1] - s0;
-        }
-        uint32_t t0 = 0, dp = 0;  // row of prev (= row of cur one step earlier)
-        uint32_t e_pc = NOT_FOUND; // CSR index of the edge prev -> cur (NOT_FOUND after an overflow read)
+        // vertex contexts of cur and prev (= cur one step earlier): sparse graphs read the 16-byte vertex
+        // record, dense (compressed-row) graphs only have indptr
+        VertexCtx vc{0, 0, 0, 0}, vp{0, 0, 0, 0};
+        auto enter = [&](uint32_t v) {
+            if (!DENSE) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 rec = as_scalar<u32x4>(PW_KARG(uint64_t, g.vrec))[v];   // one s_load_dwordx4
+                vc = VertexCtx{rec.x, rec.y, rec.z, rec.w};
+            } else {
+                const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+                const uint32_t b = indptr[v];
+                vc = VertexCtx{b, indptr[v + 1] - b, 0, 0};
+            }
+        };
+        enter(cur);
+        bool lazy_next = false;    // the edge prev -> cur is a real CSR entry with a common-neighbour count
+        uint32_t n_in = 0;         // tri[e(prev -> cur)], requested together with the sampled neighbour
         uint32_t len_out = L + 1;
         uint32_t j = 1;
         for (; j <= L; j++) {
+            const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
             if (d == 0) {
                 len_out = j;
                 if (j > 1 && lane == 0) stat[3]++;
@@ -1267,7 +1295,7 @@ walk_kernel(WalkArgs a) {
                 choice = LAZY_FALLBACK;
 #ifndef PW_NO_LAZY
                 PROF_TICK(pf, 0);
-                if (!DENSE && j >= 2) choice = sample_step_unit_lazy(mask, rank, cur, prev, e_pc, t0, dp, r, s0, d, pf);
+                if (!DENSE && lazy_next) choice = sample_step_unit_lazy(mask, rank, cur, prev, n_in, vc, vp, r, pf);
 #endif
                 if (choice == LAZY_FALLBACK) {
                     PROF_TICK(pf, 1);
@@ -1281,7 +1309,8 @@ walk_kernel(WalkArgs a) {
                                                           j >= 2, prev, t0, dp, r, s0, d);
             choice = uni(choice);
             bool clamped = false;
-            if (choice >= d) {
+            const bool real_edge = choice < d;
+            if (!real_edge) {
                 if (lane == 0) stat[1]++;
                 if (DENSE) { choice = d - 1; clamped = true; }  // reference reads past a temporary: clamp
             }
@@ -1289,16 +1318,19 @@ walk_kernel(WalkArgs a) {
             const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
             if (pos >= nnz) { pos = nnz - 1; clamped = true; }
             if (clamped && lane == 0) stat[2]++;
+            // the sampled neighbour and the common-neighbour count of the edge just taken: one round trip
             const uint32_t nxt = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[pos];
+            lazy_next = false;
+            if (UNIT && !DENSE) {
+                const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
+                lazy_next = real_edge && p_tri != 0 && PW_KARG(uint32_t, lazy_ok) != 0;
+                if (lazy_next) n_in = as_scalar<uint32_t>(p_tri)[pos];
+            }
             if (lane == 0) ((gptr_mut<uint32_t>)PW_KARG(uint64_t, out))[job * W + j] = nxt;
-            e_pc = choice < d ? (uint32_t)pos : NOT_FOUND;
             prev = cur;
-            t0 = s0;
-            dp = d;
+            vp = vc;
             cur = nxt;
-            const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
-            s0 = indptr[cur];
-            d = indptr[cur + 1] - s0;
+            enter(cur);
         }
         // header, tail zeros and length cell (cells j..L stay 0 after an early stop)
         gptr_mut<uint32_t> row = (gptr_mut<uint32_t>)PW_KARG(uint64_t, out) + job * W;
