@@ -3,14 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W [--scale S]
 
-One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels) over the
-whole job array of the workload: RMAT-S (default S = 22, the
+One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels + for
+N > 1 the one gather of the walk shards on rank 0) over the whole job array of the workload: RMAT-S (default S = 22, the
 configuration the BASELINE metric is quoted on), SparseOTF p = 0.5 q = 2, 10 walks x 80 steps per
 vertex, seed 0.  Graph, shuffled start array and output buffers are resident in HBM before the
 timed region.  N > 1: one process per GPU (torchrun), graph replicated, job array sharded, strong
-scaling (total work fixed); the walks of a shard stay in the HBM of the GPU that produced them (the
-jobs are independent: no data-path collective), --gather adds the optional collection of all shards
-on rank 0 over RCCL/xGMI to the timed region.  Rank 0 prints ONE JSON line.
+scaling (total work fixed); the walk shards are gathered once on rank 0 over RCCL/xGMI inside the
+timed region (BASELINE's north star); --no-gather leaves every shard in the HBM of the GPU that
+produced it (the jobs are independent: no data-path collective is needed to use them shard-locally).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -40,8 +41,10 @@ def parse():
     ap.add_argument("--weighted", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also gather the walk shards on rank 0 inside the timed region")
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N > 1: chunks per shard whose gathers overlap the next chunk's walk kernel")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: leave the walk shards on their GPUs (skip the gather on rank 0)")
     return ap.parse_args()
 
 
@@ -118,23 +121,42 @@ def main():
     # stream address of this shard (undirected graph: nominal counts are exact)
     has_nbr = (indptr[1:] != indptr[:-1])
     skip = int(has_nbr[starts[:lo]].sum()) * L
-    full = None
-    do_gather = world > 1 and args.gather
+    do_gather = world > 1 and not args.no_gather
+    # N > 1 with gather: the shard is walked in a few chunks and the gather of chunk c (async, on RCCL's
+    # stream) overlaps the walk kernel of chunk c + 1; --gather-chunks 1 = one blocking gather at the end
+    n_chunks = max(1, args.gather_chunks) if do_gather else 1
+    chunk_bounds = shard_bounds(hi - lo, n_chunks)
+    csum = np.concatenate([[0], np.cumsum(has_nbr[starts[lo:hi]], dtype=np.int64)])
+    chunk_skip = [skip + int(csum[a]) * L for a, _ in chunk_bounds]
+    pads, parts = [], []
     if do_gather:
-        rows = max(b[1] - b[0] for b in shard_bounds(n_jobs, world))
-        padded = torch.zeros((rows, L + 2), dtype=torch.int32, device=cdev)
-        parts = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+        widest = max(b[1] - b[0] for b in shard_bounds(n_jobs, world))
+        for c in range(n_chunks):
+            rows = max(b[1] - b[0] for b in shard_bounds(widest, n_chunks))
+            pad = torch.zeros((rows, L + 2), dtype=torch.int32, device=cdev)
+            pads.append(pad)
+            parts.append([torch.empty_like(pad) for _ in range(world)] if rank == 0 else None)
 
-    kernel_ms, rng_ms = [], []
+    kernel_ms, rng_ms, pass_steps = [], [], []
 
     def one_pass():
-        eng.simulate_device("SparseOTF", args.p, args.q, False, d_starts, L, seed=args.seed,
-                            stream_skip=skip, out=d_out)
-        kernel_ms.append(eng.last_stats["walk_kernel_ms"])
-        rng_ms.append(eng.last_stats["rng_kernel_ms"])
-        if do_gather:  # one gather of the shards over RCCL/xGMI
-            padded[: hi - lo] = d_out.to(cdev)
-            dist.gather(padded, parts, dst=0)
+        k_ms = r_ms = 0.0
+        steps = 0
+        works = []
+        for c, (a, b) in enumerate(chunk_bounds):
+            eng.simulate_device("SparseOTF", args.p, args.q, False, d_starts[a:b], L, seed=args.seed,
+                                stream_skip=chunk_skip[c], out=d_out[a:b])
+            k_ms += eng.last_stats["walk_kernel_ms"]
+            r_ms += eng.last_stats["rng_kernel_ms"]
+            steps += eng.last_stats["total_steps"]
+            if do_gather:  # gather of this chunk over RCCL/xGMI while the next chunk is walked
+                pads[c][: b - a] = d_out[a:b].to(cdev)
+                works.append(dist.gather(pads[c], parts[c], dst=0, async_op=True))
+        for w in works:
+            w.wait()
+        kernel_ms.append(k_ms)
+        rng_ms.append(r_ms)
+        pass_steps.append(steps)
 
     def fence():
         torch.cuda.synchronize()
@@ -158,7 +180,7 @@ def main():
         elapsed = float(tmax.item())
 
     st = eng.last_stats
-    shard_steps = torch.tensor([st["total_steps"]], dtype=torch.int64, device=cdev)
+    shard_steps = torch.tensor([pass_steps[-1]], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(shard_steps)
     total_steps = int(shard_steps.item())           # sampled transitions of the whole job array
@@ -169,6 +191,19 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+
+    if os.environ.get("PECANPY_BENCH_VERIFY") and do_gather:
+        # dry-run check of the sharded + chunked addressing: the gathered matrix equals one whole-array run
+        b_all = shard_bounds(n_jobs, world)
+        rows_of = []
+        for r in range(world):
+            cb = shard_bounds(b_all[r][1] - b_all[r][0], n_chunks)
+            rows_of.append(torch.cat([parts[c][r][: cb[c][1] - cb[c][0]] for c in range(n_chunks)], dim=0))
+        gathered = torch.cat(rows_of, dim=0).to(dev)
+        whole = eng.simulate_device("SparseOTF", args.p, args.q, False,
+                                    torch.from_numpy(starts.view(np.int32)).to(dev), L, seed=args.seed)
+        assert torch.equal(gathered, whole), "gathered shards differ from the single-stream matrix"
+        print("bench.py: gathered shards verified against a whole-array run", file=sys.stderr)
 
     # roofline of the dominant kernel (walk_sparse_kernel), rank 0's shard
     deg_t = torch.from_numpy(np.diff(indptr.astype(np.int64))).to(dev)
@@ -258,7 +293,7 @@ def main():
             "effective_steps_per_pass": total_steps, "nominal_steps_per_pass": int(n_jobs) * L,
             "nominal_value": round(int(n_jobs) * L / sec_per_step / 1e6, 3),
             "parallelism": f"jobs sharded over {world} GPU(s), graph replicated",
-            "gather_on_rank0": bool(do_gather),
+            "gather_on_rank0": bool(do_gather), "gather_chunks": n_chunks if do_gather else 0,
             "overflow_reads": st["overflow_reads"], "host_prep_s": round(t_prep, 1),
             "graph_gen_s": round(t_graph, 1),
         },
