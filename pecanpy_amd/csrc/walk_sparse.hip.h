@@ -18,8 +18,17 @@
 // to the reference's left-to-right float32 loops.  Unweighted graphs take a closed-form variant
 // of the same chain (run lengths of equal values, see "unit-weight fast path").
 //
-// Everything a wave decides on is wave-uniform; values loaded from memory are passed through
-// readfirstlane so that the compiler keeps them in SGPRs (scalar address arithmetic, scalar loads).
+// Two implementations of a step:
+//   eager (sample_step_unit / sample_step_weighted): 1-4 as listed, the full mask of the row first.
+//         Weighted graphs, node2vec+, non-dyadic p/q, the first step of a walk, graphs with self loops.
+//   lazy  (sample_step_unit_lazy, the headline case: unit weights, 1/p and 1/q powers of two):
+//         tot from the per-edge common-neighbour count, membership 64 keys at a time and only as far
+//         as the search needs it, the search decided in exact integer arithmetic whenever no partial
+//         sum lies within the float32 drift bound of the target (else by the same binade chain).
+//
+// Everything a wave decides on is wave-uniform and lives in SGPRs; read-only arrays are read with
+// scalar loads and kernel arguments are re-read at the point of use (wave.h) because the 80 SGPRs
+// a wave gets at 8 waves/SIMD are the scarcest resource of this kernel.
 #pragma once
 #include "seqscan.h"
 #include "wave.h"
