@@ -1040,6 +1040,29 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const uint32_t units_i = uni((uint32_t)units);
     const uint32_t r_units = uni((uint32_t)(r * units));
 
+    if (n_in == 0) {
+        // No common neighbour at all (a fifth of the edges of an R-MAT graph): every position is "out"
+        // except prev's, E(k) is a closed form and the exact decision needs neither keys nor the mask.
+        //   E(k) = (k + 1) << sh_out                       k <  prev_pos
+        //        = (k << sh_out) + (1 << sh_prev)          k >= prev_pos
+        const double R = r * units;
+        const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
+        const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
+        const double zr = ((jb + 6.0) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;   // drift bound, see below
+        const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
+        const double lo = R - zr;
+        const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
+        const uint32_t wo_m1 = (1u << sh_out) - 1u, wp = 1u << sh_prev;
+        uint32_t k1 = lo_th ? ((lo_th + wo_m1) >> sh_out) - 1u : 0u;          // first k with (k + 1) << sh_out >= lo_th
+        uint32_t e1 = (k1 + 1u) << sh_out;
+        if (n_pv && k1 >= prev_pos) {                                         // all k < prev_pos stay below lo_th
+            const uint32_t need = lo_th > wp ? lo_th - wp : 0u;
+            k1 = (need + wo_m1) >> sh_out;                                    // first k with (k << sh_out) + wp >= lo_th
+            if (k1 < prev_pos) k1 = prev_pos;
+            e1 = (k1 << sh_out) + wp;
+        }
+        if (k1 < d && e1 >= hi_th) return k1;
+    }
     const uint32_t nwords_all = ((d < SEG ? d : SEG) + 31) >> 5;
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
     wave_lds_fence();
