@@ -1048,7 +1048,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         const double R = r * units;
         const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
         const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
-        const double zr = ((jb + 6.0) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;   // drift bound, see below
+        const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;   // drift bound, see below
         const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
         const double lo = R - zr;
         const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
@@ -1132,15 +1132,17 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         if (exact_ok && k == 0 && wb == 0) {
             // Decide in exact arithmetic when no partial sum lies next to the target.  With R = r * units
             // (real) and c_i < r for i < j, the float chain obeys
-            //     |c_j - E(j) / units| <= ((j + 1) * (R + wmax) + R + wmax) * 2^-24 / units   =: zr / units
-            // (one relative rounding 2^-24 per addition of a sum below r + x_max, plus 2^-24 relative on
-            // the three values).  Hence every j below the first k1 with E(k1) >= ceil(R - zr) has c_j < r
+            //     |c_j - E(j) / units| <= (sum_{i<=j} E(i) + E(j)) * 2^-24 / units
+            //                          <= ((j + 1) * (R + wmax) - j (j + 1) / 2 + R + wmax) * 2^-24 / units =: zr / units
+            // (one relative rounding 2^-24 per addition, applied to the partial sum being rounded, plus
+            // 2^-24 relative on the three values; every element weighs at least one unit).  Hence every j below the first k1 with E(k1) >= ceil(R - zr) has c_j < r
             // (induction on j), and E(k1) >= ceil(R + zr) gives c_k1 >= r: k1 is the chain's answer.
             const double R = r * units;
             const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
             // every element weighs at least one unit, so E(k) >= k + 1 and k1 < R: j + 1 <= min(known_end, R + 1)
             const double jb = (double)known_end < R + 2.0 ? (double)known_end : R + 2.0;
-            const double zr = ((jb + 6.0) * (R + wmax)) * (1.0001 / 16777216.0) + 1e-6;
+            // and E(i) <= E(j) - (j - i): the sum of the partial sums is at most (j+1) E(j) - j (j+1) / 2
+            const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;
             const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
             if (est >= hi_th) {
                 const double lo = R - zr;
