@@ -136,6 +136,26 @@ int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
 /* doubles #offset.. of RandomState(seed).random_sample, produced with MT19937 jump-ahead. */
 int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out);
 
+/* ---- edge-list ingestion (host side; usable without a GPU) -------------------------------- */
+/* Fast path of AdjlstGraph.read + to_csr (reference src/pecanpy/graph.py:270-341): parses a 2- or
+ * 3-column edge list into the reference's CSR (vertices numbered by first appearance, rows ascending,
+ * float32 weights, last duplicate wins) and the vertex-ID table.
+ * Returns PW_OK, PW_ERR_INVALID (file cannot be read), or PW_ERR_UNSUPPORTED when the file needs the
+ * statement-by-statement reader to reproduce Python-level behaviour (malformed line, non-positive or
+ * exotic weight literal, conflicting duplicate edge -- the cases where the reference warns or raises --
+ * or non-ASCII bytes); the caller then falls back to it.  The handle owns the arrays until destroyed. */
+typedef struct pw_edgelist pw_edgelist;
+int pw_edgelist_read(const char *path, int weighted, int directed, const char *delimiter, pw_edgelist **out);
+/* n_nodes, nnz (distinct directed edges), insertions (the reference's num_edges counter), id_bytes */
+int pw_edgelist_shape(const pw_edgelist *e, uint64_t *n_nodes, uint64_t *nnz, uint64_t *insertions,
+                      uint64_t *id_bytes);
+/* indptr uint32[n_nodes+1], indices uint32[nnz], data float32[nnz] (the CSR of to_csr), data64
+ * float64[nnz] (the weights as parsed: AdjlstGraph.to_dense keeps float64), id_offsets uint64[n_nodes+1],
+ * id_chars char[id_bytes] (vertex i's ID = id_chars[id_offsets[i] : id_offsets[i+1]]); NULL = skip */
+int pw_edgelist_export(const pw_edgelist *e, uint32_t *indptr, uint32_t *indices, float *data,
+                       double *data64, uint64_t *id_offsets, char *id_chars);
+void pw_edgelist_destroy(pw_edgelist *e);
+
 /* ---- self test hooks (host only, no GPU needed) ------------------------------------------ */
 /* Runs the binade-scan emulation of csrc/seqscan.h on a host array: returns through *index the
  * position np.searchsorted(np.cumsum(x), r) would return under sequential float32 semantics

@@ -1,9 +1,9 @@
-"""Command line front-end: the reference's ``pecanpy`` CLI on the MI355X walk engine.
+"""``pecanpy`` command line on the MI355X walk engine.
 
-Same flags, defaults, mode checks and stage order as reference src/pecanpy/cli.py (:27-176 flags,
-:179-254 ``check_mode``, :257-304 ``read_graph``, :307-351 pipeline).  Walk generation runs on the
-GPU; the skip-gram step uses gensim when it is installed (embedding training is outside the scope
-of this engine) and otherwise ``--output`` receives the walks themselves (one walk per line).
+Flag names, defaults, the mode sanity rules and the stage order follow the reference CLI
+(src/pecanpy/cli.py: flags :27-176, ``check_mode`` :179-254, ``read_graph`` :257-304, pipeline
+:307-351) so that existing invocations keep working.  Walks come from the GPU; the skip-gram stage
+uses gensim when it is importable and otherwise writes the walks (one per line) to ``--output``.
 
     pecanpy --input demo/karate.edg --output karate.emb --mode SparseOTF --p 0.5 --q 2
 """
@@ -17,134 +17,108 @@ from . import graph
 from . import pecanpy
 from .wrappers import Timer
 
-MODES = ["DenseOTF", "FirstOrderUnweighted", "PreComp", "PreCompFirstOrder", "SparseOTF"]
+MODES = ("DenseOTF", "FirstOrderUnweighted", "PreComp", "PreCompFirstOrder", "SparseOTF")
+
+# (flag, argparse keywords) -- one table instead of twenty add_argument calls
+_OPTIONS = (
+    ("--input", dict(required=True, help="graph file: .edg edge list or .npz (CSR / dense)")),
+    ("--output", dict(required=True, help="embedding file (.npz -> IDs/data arrays, else word2vec text)")),
+    ("--task", dict(default="pecanpy", choices=("pecanpy", "tocsr", "todense"),
+                    help="run node2vec, or only convert the edge list to CSR / dense .npz")),
+    ("--mode", dict(default="SparseOTF", choices=MODES, help="walk engine variant")),
+    ("--dimensions", dict(type=int, default=128, help="embedding size")),
+    ("--walk-length", dict(type=int, default=80, help="steps per walk")),
+    ("--num-walks", dict(type=int, default=10, help="walks per start vertex")),
+    ("--window-size", dict(type=int, default=10, help="skip-gram window")),
+    ("--epochs", dict(type=int, default=1, help="skip-gram epochs")),
+    ("--workers", dict(type=int, default=0, help="host threads for the skip-gram stage (0 = all)")),
+    ("--p", dict(type=float, default=1, help="return parameter")),
+    ("--q", dict(type=float, default=1, help="in-out parameter")),
+    ("--weighted", dict(action="store_true", help="third column of the edge list holds weights")),
+    ("--directed", dict(action="store_true", help="do not add the reverse of every edge")),
+    ("--verbose", dict(action="store_true", help="progress output")),
+    ("--extend", dict(action="store_true", help="node2vec+ (weighted graphs)")),
+    ("--gamma", dict(type=float, default=0, help="node2vec+ noisy-edge threshold = mean + gamma * std")),
+    ("--random_state", dict(type=int, default=None, help="seed of the walk stream")),
+    ("--delimiter", dict(type=str, default="\t", help="column separator of the edge list")),
+    ("--implicit_ids", dict(action="store_true", help=".npz without IDs: use 0..N-1")),
+)
 
 
 def parse_args(argv=None):
-    """Parse node2vec arguments (flag set of the reference CLI)."""
-    ap = argparse.ArgumentParser(
-        description="Run pecanpy, a parallelized, efficient, and accelerated Python implementation "
-                    "of node2vec (walks generated on AMD MI355X GPUs)",
-        formatter_class=argparse.ArgumentDefaultsHelpFormatter,
-    )
-    ap.add_argument("--input", required=True, help="Input graph (.edg or .npz) file path.")
-    ap.add_argument("--output", required=True,
-                    help="Output embeddings file path. Save as .npz file if the specified file path "
-                         "ends with .npz, otherwise save as a text file using the gensim "
-                         "save_word2vec_format method.")
-    ap.add_argument("--task", default="pecanpy", choices=["pecanpy", "tocsr", "todense"],
-                    help="Task to be performed.")
-    ap.add_argument("--mode", default="SparseOTF", choices=MODES, help="PecanPy execution mode.")
-    ap.add_argument("--dimensions", type=int, default=128, help="Number of dimensions.")
-    ap.add_argument("--walk-length", type=int, default=80, help="Length of walk per source.")
-    ap.add_argument("--num-walks", type=int, default=10, help="Number of walks per source.")
-    ap.add_argument("--window-size", type=int, default=10, help="Context size for optimization.")
-    ap.add_argument("--epochs", type=int, default=1, help="Number of epochs in SGD when training Word2Vec")
-    ap.add_argument("--workers", type=int, default=0,
-                    help="Number of parallel workers (0 to use all available threads).")
-    ap.add_argument("--p", type=float, default=1, help="Return hyperparameter.")
-    ap.add_argument("--q", type=float, default=1, help="Inout hyperparameter.")
-    ap.add_argument("--weighted", action="store_true", help="Boolean specifying (un)weighted.")
-    ap.add_argument("--directed", action="store_true", help="Graph is (un)directed.")
-    ap.add_argument("--verbose", action="store_true", help="Print out training details")
-    ap.add_argument("--extend", action="store_true", help="Use node2vec+ extension")
-    ap.add_argument("--gamma", type=float, default=0, help="Noisy edge threshold parameter.")
-    ap.add_argument("--random_state", type=int, default=None, help="Random seed for generating random walks.")
-    ap.add_argument("--delimiter", type=str, default="\t", help="Delimiter used between node IDs.")
-    ap.add_argument("--implicit_ids", action="store_true",
-                    help="If set, use canonical node ordering for the node IDs.")
-    return ap.parse_args(argv)
+    """The reference's flag set (``--walk-length`` style and ``--random_state`` style both as there)."""
+    parser = argparse.ArgumentParser(
+        prog="pecanpy",
+        description="node2vec / node2vec+ embeddings; random walks generated on AMD MI355X GPUs",
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for flag, kw in _OPTIONS:
+        parser.add_argument(flag, **kw)
+    return parser.parse_args(argv)
+
+
+def _advise(better, current, why):
+    warnings.warn(f"{why}: {better} is recommended over {current} (current selection)", stacklevel=3)
 
 
 def check_mode(g, args):
-    """Mode sanity checks and recommendations by graph size / density (reference cli.py:179-254)."""
-    mode, weighted, p, q = args.mode, args.weighted, args.p, args.q
+    """Reject impossible mode / parameter combinations and recommend a better mode (cli.py:179-254)."""
+    mode = args.mode
+    first_order = args.p == 1 and args.q == 1
 
+    # hard constraints of the two first-order modes
+    if mode == "FirstOrderUnweighted" and (args.weighted or not first_order):
+        raise ValueError(f"FirstOrderUnweighted only works when weighted = False and p = q = 1, got "
+                         f"weighted={args.weighted}, p={args.p}, q={args.q}")
+    if mode == "PreCompFirstOrder" and not first_order:
+        raise ValueError(f"PreCompFirstOrder only works when p = q = 1, got p={args.p}, q={args.q}")
     if mode == "FirstOrderUnweighted":
-        if not p == q == 1 or weighted:
-            raise ValueError(
-                f"FirstOrderUnweighted only works when weighted = False and "
-                f"p = q = 1, got {weighted=}, {p=}, {q=}",
-            )
-        return
-    if p == q == 1 and not weighted:
-        warnings.warn(
-            "When p = 1 and q = 1 with unweighted graph, it is highly recommended to use "
-            f"FirstOrderUnweighted over {mode} (current selection). The runtime could be improved "
-            "greatly with improved  memory usage.",
-            stacklevel=2,
-        )
-        return
-    if mode == "PreCompFirstOrder":
-        if not p == q == 1:
-            raise ValueError(f"PreCompFirstOrder only works when p = q = 1, got {p=}, {q=}")
-        return
-    if p == 1 == q:
-        warnings.warn(
-            "When p = 1 and q = 1, it is highly recommended to use PreCompFirstOrder over "
-            f"{mode} (current selection). The runtime could be improved greatly with low memory usage.",
-            stacklevel=2,
-        )
         return
 
-    size, dens = g.num_nodes, g.density
-    if dens >= 0.2 and mode != "DenseOTF":
-        warnings.warn(f"Network density = {dens:.3f} (> 0.2), it is recommended to use DenseOTF "
-                      f"over {mode} (current selection)", stacklevel=2)
-    if dens < 0.001 and size < 10000 and mode != "PreComp":
-        warnings.warn(f"Network density = {dens:.2e} (< 0.001) with {size} nodes (< 10000), it is "
-                      f"recommended to use PreComp over {mode} (current selection)", stacklevel=2)
-    if 0.001 <= dens < 0.2 and mode != "SparseOTF":
-        warnings.warn(f"Network density = {dens:.3f}, it is recommended to use SparseOTF over "
-                      f"{mode} (current selection)", stacklevel=2)
-    if dens < 0.001 and size >= 10000 and mode != "SparseOTF":
-        warnings.warn(f"Network density = {dens:.3f} (< 0.001) with {size} nodes (>= 10000), it is "
-                      f"recommended to use SparseOTF over {mode} (current selection)", stacklevel=2)
+    # p = q = 1: a first-order mode does the same walk for less
+    if first_order:
+        if not args.weighted:
+            _advise("FirstOrderUnweighted", mode, "p = q = 1 on an unweighted graph")
+        elif mode != "PreCompFirstOrder":
+            _advise("PreCompFirstOrder", mode, "p = q = 1")
+        return
+
+    # second order: pick by size and density
+    n, rho = g.num_nodes, g.density
+    if rho >= 0.2:
+        best, why = "DenseOTF", f"network density = {rho:.3f} (>= 0.2)"
+    elif rho < 0.001 and n < 10000:
+        best, why = "PreComp", f"network density = {rho:.2e} (< 0.001) with {n} nodes (< 10000)"
+    else:
+        best, why = "SparseOTF", f"network density = {rho:.3g} with {n} nodes"
+    if mode != best:
+        _advise(best, mode, why)
+
+
+def _convert_only(args):
+    target = graph.SparseGraph() if args.task == "tocsr" else graph.DenseGraph()
+    target.read_edg(args.input, args.weighted, args.directed, args.delimiter)
+    target.save(args.output)
+    raise SystemExit(0)
 
 
 @Timer("load Graph")
 def read_graph(args):
-    """Read the input network as CSR (sparse modes) or dense matrix (DenseOTF)."""
+    """Build the graph object of ``--mode`` from ``--input`` (or convert and exit for tocsr/todense)."""
     if args.directed and args.extend:
         raise NotImplementedError("Node2vec+ not implemented for directed graph yet.")
     if args.extend and not args.weighted:
         print("NOTE: node2vec+ is equivalent to node2vec for unweighted graphs.")
+    if args.task != "pecanpy":
+        _convert_only(args)
 
-    if args.task in ("tocsr", "todense"):  # conversion only
-        g = graph.SparseGraph() if args.task == "tocsr" else graph.DenseGraph()
-        g.read_edg(args.input, args.weighted, args.directed, args.delimiter)
-        g.save(args.output)
-        raise SystemExit(0)
-
-    cls = getattr(pecanpy, args.mode, None)
-    g = cls(args.p, args.q, args.workers, args.verbose, args.extend, args.gamma, args.random_state)
+    engine_cls = getattr(pecanpy, args.mode)
+    g = engine_cls(args.p, args.q, args.workers, args.verbose, args.extend, args.gamma, args.random_state)
     if args.input.endswith(".npz"):
         g.read_npz(args.input, args.weighted, implicit_ids=args.implicit_ids)
     else:
         g.read_edg(args.input, args.weighted, args.directed, args.delimiter)
     check_mode(g, args)
     return g
-
-
-@Timer("train embeddings")
-def learn_embeddings(args, walks):
-    """Skip-gram on the walk corpus (gensim; reference cli.py:307-325)."""
-    try:
-        from gensim.models import Word2Vec
-    except ImportError:
-        path = args.output
-        with open(path, "w", encoding="utf-8") as f:
-            for walk in walks:
-                f.write(" ".join(walk) + "\n")
-        warnings.warn(f"gensim is not installed: wrote the {len(walks)} walks to {path} instead of "
-                      "embeddings (Word2Vec training is outside this engine)", stacklevel=2)
-        return
-    model = Word2Vec(walks, vector_size=args.dimensions, window=args.window_size, min_count=0, sg=1,
-                     workers=args.workers, epochs=args.epochs, seed=args.random_state)
-    if args.output.endswith(".npz"):
-        np.savez(args.output, IDs=model.wv.index_to_key, data=model.wv.vectors)
-    else:
-        model.wv.save_word2vec_format(args.output)
 
 
 @Timer("pre-compute transition probabilities")
@@ -157,15 +131,37 @@ def simulate_walks(args, g):
     return g.simulate_walks(args.num_walks, args.walk_length)
 
 
+def _dump_walks(path, walks):
+    with open(path, "w", encoding="utf-8") as out:
+        out.writelines(" ".join(w) + "\n" for w in walks)
+
+
+@Timer("train embeddings")
+def learn_embeddings(args, walks):
+    """Skip-gram over the walk corpus (gensim, cli.py:307-325); without gensim the walks are written."""
+    try:
+        from gensim.models import Word2Vec
+    except ImportError:
+        _dump_walks(args.output, walks)
+        warnings.warn(f"gensim is not installed: {len(walks)} walks written to {args.output} instead of "
+                      "embeddings (Word2Vec training is outside this engine)", stacklevel=2)
+        return
+    w2v = Word2Vec(walks, vector_size=args.dimensions, window=args.window_size, min_count=0, sg=1,
+                   workers=args.workers, epochs=args.epochs, seed=args.random_state)
+    vectors = w2v.wv
+    if args.output.endswith(".npz"):
+        np.savez(args.output, IDs=vectors.index_to_key, data=vectors.vectors)
+    else:
+        vectors.save_word2vec_format(args.output)
+
+
 def main(argv=None):
-    """Pipeline: read graph -> preprocess -> walks (GPU) -> embeddings."""
+    """read graph -> preprocess -> walks (GPU) -> embeddings."""
     args = parse_args(argv)
-    if args.workers == 0:
-        args.workers = os.cpu_count() or 1
+    args.workers = args.workers or (os.cpu_count() or 1)
     g = read_graph(args)
     preprocess(g)
-    walks = simulate_walks(args, g)
-    learn_embeddings(args, walks)
+    learn_embeddings(args, simulate_walks(args, g))
 
 
 if __name__ == "__main__":

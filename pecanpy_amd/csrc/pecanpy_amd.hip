@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <random>
 #include <cmath>
 #include <string>
@@ -15,6 +16,7 @@
 
 #include "../../include/pecanpy_amd.h"
 #include "aux_kernels.hip.h"
+#include "edgelist.hpp"
 #include "mtjump.hpp"
 #include "seqscan.h"
 #include "walk_dense.hip.h"
@@ -906,6 +908,54 @@ PW_EXPORT int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, do
     pw::mt_random_sample_host(seed, offset, n, out);
     return PW_OK;
 }
+
+// ---- edge-list ingestion (host only) ----------------------------------------------------------------
+struct pw_edgelist {
+    pw::EdgeList el;
+};
+
+PW_EXPORT int pw_edgelist_read(const char *path, int weighted, int directed, const char *delimiter, pw_edgelist **out) {
+    if (!path || !out) return fail(PW_ERR_INVALID, "null pointer");
+    *out = nullptr;
+    pw_edgelist *h = new (std::nothrow) pw_edgelist();
+    if (!h) return fail(PW_ERR_NOMEM, "out of host memory");
+    int st;
+    try {
+        st = pw::read_edgelist(path, weighted != 0, directed != 0, delimiter, h->el);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(PW_ERR_NOMEM, "out of host memory while reading the edge list");
+    }
+    if (st == pw::EL_OK) { *out = h; return PW_OK; }
+    delete h;
+    if (st == pw::EL_IO_ERROR) return fail(PW_ERR_INVALID, std::string("cannot read ") + path);
+    return fail(PW_ERR_UNSUPPORTED, "edge list needs the statement-by-statement reader");
+}
+
+PW_EXPORT int pw_edgelist_shape(const pw_edgelist *e, uint64_t *n_nodes, uint64_t *nnz, uint64_t *insertions,
+                                uint64_t *id_bytes) {
+    if (!e) return fail(PW_ERR_INVALID, "null pointer");
+    if (n_nodes) *n_nodes = e->el.indptr.size() - 1;
+    if (nnz) *nnz = e->el.indices.size();
+    if (insertions) *insertions = e->el.insertions;
+    if (id_bytes) *id_bytes = e->el.id_chars.size();
+    return PW_OK;
+}
+
+PW_EXPORT int pw_edgelist_export(const pw_edgelist *e, uint32_t *indptr, uint32_t *indices, float *data,
+                                 double *data64, uint64_t *id_offsets, char *id_chars) {
+    if (!e) return fail(PW_ERR_INVALID, "null pointer");
+    const pw::EdgeList &el = e->el;
+    if (indptr) memcpy(indptr, el.indptr.data(), sizeof(uint32_t) * el.indptr.size());
+    if (indices && !el.indices.empty()) memcpy(indices, el.indices.data(), sizeof(uint32_t) * el.indices.size());
+    if (data && !el.data.empty()) memcpy(data, el.data.data(), sizeof(float) * el.data.size());
+    if (data64 && !el.data64.empty()) memcpy(data64, el.data64.data(), sizeof(double) * el.data64.size());
+    if (id_offsets) memcpy(id_offsets, el.id_off.data(), sizeof(uint64_t) * el.id_off.size());
+    if (id_chars && !el.id_chars.empty()) memcpy(id_chars, el.id_chars.data(), el.id_chars.size());
+    return PW_OK;
+}
+
+PW_EXPORT void pw_edgelist_destroy(pw_edgelist *e) { delete e; }
 
 PW_EXPORT int pw_selftest_seqscan_f32(const float *x, uint32_t n, double r, int use_target, uint32_t chunk,
                                       uint32_t *index, float *sum) {

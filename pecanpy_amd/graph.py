@@ -1,41 +1,41 @@
 """Host-side graph containers: the *input layout contract* of the walk engine.
 
-Same public surface as the reference's ``pecanpy.graph`` (reference src/pecanpy/graph.py):
-``BaseGraph`` (IDs, :19-105), ``AdjlstGraph`` (edge-list reader/writer, :108-386), ``SparseGraph``
-(CSR ``indptr:uint32[N+1]``, ``indices:uint32[nnz]`` ascending per row, ``data:float32[nnz]``,
-:389-528) and ``DenseGraph`` (``data:float64[N,N]`` + ``nonzero:bool[N,N]``, :531-657).
-These are cold, host-only paths; only the array layouts they produce
-matter to the GPU engine.
+Public surface of the reference's ``pecanpy.graph`` (src/pecanpy/graph.py): ``BaseGraph`` (IDs,
+:19-105), ``AdjlstGraph`` (edge-list reader / writer, :108-386), ``SparseGraph`` (CSR
+``indptr:uint32[N+1]``, ``indices:uint32[nnz]`` ascending per row, ``data:float32[nnz]``, :389-528) and
+``DenseGraph`` (``data:float64[N,N]`` + ``nonzero:bool[N,N]``, :531-657).
+
+The implementation is this package's own: edges live in one flat ``{(src << 32) | dst: weight}`` map (or,
+after a bulk read, directly in CSR arrays), conversions are vectorised NumPy, and well-formed edge-list
+files are parsed by the native reader in libpecanpy_amd (``pw_edgelist_read``) with the
+statement-by-statement reader as the fallback for everything that warns or raises in the reference.
 """
+import ctypes
 import warnings
 
 import numpy as np
 
 __all__ = ["BaseGraph", "AdjlstGraph", "SparseGraph", "DenseGraph"]
 
+_SHIFT = 32
+_LOW = (1 << _SHIFT) - 1
+
 
 class BaseGraph:
-    """Node-ID bookkeeping shared by every graph flavour."""
+    """Vertex-ID bookkeeping shared by every graph flavour."""
 
     def __init__(self):
         self._node_ids = []
         self._node_idmap = {}
 
-    @property
-    def nodes(self):
-        """List of node IDs, index = node index."""
-        return self._node_ids
-
-    @property
-    def num_nodes(self):
-        return len(self.nodes)
+    nodes = property(lambda self: self._node_ids, doc="vertex IDs; position = vertex index")
+    num_nodes = property(lambda self: len(self._node_ids))
 
     @property
     def num_edges(self):
         raise NotImplementedError(
-            f"{self.__class__.__name__} does not have num_edges, use the "
-            f"derived classes like SparseGraph and DenseGraph instead.",
-        )
+            f"{type(self).__name__} does not have num_edges, use the derived classes like "
+            "SparseGraph and DenseGraph instead.")
 
     @property
     def density(self):
@@ -43,22 +43,19 @@ class BaseGraph:
         return self.num_edges / n / (n - 1)
 
     def set_node_ids(self, node_ids, implicit_ids=False, num_nodes=None):
-        """Install the ID list (or canonical ``"0".."N-1"`` IDs when none are available)."""
-        if node_ids is not None and not implicit_ids:
-            self._node_ids = list(node_ids)
-        else:
+        """Install the ID list, or the canonical IDs ``"0" .. "N-1"`` when the file carried none."""
+        if node_ids is None or implicit_ids:
             if num_nodes is None:
                 raise ValueError("Need to specify `num_nodes` when setting implicit node IDs.")
-            self._node_ids = [str(i) for i in range(num_nodes)]
             if not implicit_ids:
                 warnings.warn(
-                    "WARNING: Implicitly set node IDs to the canonical node ordering due to "
-                    "missing IDs field in the raw CSR npz file. This warning message can be "
-                    "suppressed by setting implicit_ids to True in the read_npz function call, "
-                    "or by setting the --implicit_ids flag in the CLI",
-                    stacklevel=2,
-                )
-        self._node_idmap = {nid: idx for idx, nid in enumerate(self._node_ids)}
+                    "WARNING: Implicitly set node IDs to the canonical node ordering due to missing IDs "
+                    "field in the raw CSR npz file. This warning message can be suppressed by setting "
+                    "implicit_ids to True in the read_npz function call, or by setting the "
+                    "--implicit_ids flag in the CLI", stacklevel=2)
+            node_ids = map(str, range(num_nodes))
+        self._node_ids = list(node_ids)
+        self._node_idmap = dict(zip(self._node_ids, range(len(self._node_ids))))
 
     def get_has_nbrs(self):
         raise NotImplementedError
@@ -67,23 +64,94 @@ class BaseGraph:
         raise NotImplementedError
 
 
-class AdjlstGraph(BaseGraph):
-    """Adjacency-list graph used only to read / write edge-list files.
+def _csr_from_flat(keys, weights, n):
+    """Sorted CSR (uint32 / uint32 / float32) from ``src << 32 | dst`` keys of distinct edges."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    order = np.argsort(keys, kind="stable")
+    keys = keys[order]
+    counts = np.bincount((keys >> np.uint64(_SHIFT)).astype(np.int64), minlength=n)
+    indptr = np.zeros(n + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(counts)
+    w64 = np.asarray(weights, dtype=np.float64)[order]
+    return indptr, (keys & np.uint64(_LOW)).astype(np.uint32), w64.astype(np.float32), w64
 
-    ``_data[i]`` maps neighbour index -> weight for node ``i``; nodes are numbered in order of
-    first appearance in the edge list.
+
+def _native_edgelist(path, weighted, directed, delimiter):
+    """``(indptr, indices, data32, data64, ids, insertions)`` from the native reader, or ``None`` when
+    the file (or the build) needs the Python reader.  Host-only code of the C-ABI library; no GPU involved."""
+    try:
+        from . import _lib
+
+        lib = _lib.load()
+    except Exception:  # library not built: the Python reader still works
+        return None
+    handle = ctypes.c_void_p()
+    rc = lib.pw_edgelist_read(str(path).encode(), int(bool(weighted)), int(bool(directed)),
+                              delimiter.encode("utf-8", "surrogateescape"), ctypes.byref(handle))
+    if rc != 0:
+        return None
+    try:
+        dims = [ctypes.c_uint64() for _ in range(4)]
+        lib.pw_edgelist_shape(handle, *[ctypes.byref(d) for d in dims])
+        n, nnz, insertions, id_bytes = (int(d.value) for d in dims)
+        indptr = np.empty(n + 1, dtype=np.uint32)
+        indices = np.empty(nnz, dtype=np.uint32)
+        data = np.empty(nnz, dtype=np.float32)
+        data64 = np.empty(nnz, dtype=np.float64)
+        offs = np.empty(n + 1, dtype=np.uint64)
+        chars = np.empty(max(id_bytes, 1), dtype=np.uint8)
+        lib.pw_edgelist_export(handle, *(a.ctypes.data_as(ctypes.c_void_p)
+                                         for a in (indptr, indices, data, data64, offs, chars)))
+    finally:
+        lib.pw_edgelist_destroy(handle)
+    blob = chars[:id_bytes].tobytes().decode("ascii")
+    cuts = offs.tolist()
+    ids = [blob[a:b] for a, b in zip(cuts, cuts[1:])]
+    return indptr, indices, data, data64, ids, insertions
+
+
+class AdjlstGraph(BaseGraph):
+    """Mutable graph used to read / write edge-list files and to build the array layouts.
+
+    Vertices are numbered in order of first appearance.  Edges are held either in a flat map keyed by
+    ``src << 32 | dst`` (incremental ``add_edge``) or, after a bulk ``read``, as CSR arrays that are
+    expanded into the map only if the graph is modified afterwards.
     """
 
     def __init__(self):
         super().__init__()
-        self._data = []
-        self._num_edges = 0
+        self._w = {}          # (src << 32 | dst) -> weight (Python float, as given)
+        self._csr = None      # (indptr, indices, data32, data64) of a bulk read, valid while `_w` is empty
+        self._num_edges = 0   # counts insertions, like the reference (graph.py:240-243)
 
+    # ---- storage helpers -------------------------------------------------------------------------
+    def _thaw(self):
+        """Expand the arrays of a bulk read into the edge map (before any modification)."""
+        if self._csr is not None:
+            indptr, indices, _, w64 = self._csr
+            src = np.repeat(np.arange(indptr.size - 1, dtype=np.uint64), np.diff(indptr.astype(np.int64)))
+            keys = (src << np.uint64(_SHIFT)) | indices.astype(np.uint64)
+            self._w = dict(zip(keys.tolist(), w64.tolist()))
+            self._csr = None
+
+    def _arrays(self):
+        """``(indptr, indices, data float32, data float64)``, rows in vertex order, tails ascending."""
+        if self._csr is not None:
+            return self._csr
+        count = len(self._w)
+        return _csr_from_flat(np.fromiter(self._w.keys(), dtype=np.uint64, count=count),
+                              np.fromiter(self._w.values(), dtype=np.float64, count=count), self.num_nodes)
+
+    # ---- reference surface -------------------------------------------------------------------------
     @property
     def edges_iter(self):
-        for head, nbrs in enumerate(self._data):
-            for tail in sorted(nbrs):
-                yield head, tail, nbrs[tail]
+        """``(head, tail, weight)`` in row order, tails ascending."""
+        indptr, indices, _, w64 = self._arrays()
+        bounds = indptr.tolist()
+        tails, weights = indices.tolist(), w64.tolist()
+        for head in range(self.num_nodes):
+            for e in range(bounds[head], bounds[head + 1]):
+                yield head, tails[e], weights[e]
 
     @property
     def edges(self):
@@ -93,103 +161,78 @@ class AdjlstGraph(BaseGraph):
     def num_edges(self):
         return self._num_edges
 
-    @staticmethod
-    def _read_edge_line(edge_line, weighted, delimiter):
-        terms = edge_line.strip().split(delimiter)
-        id1, id2 = terms[0].strip(), terms[1].strip()
-        weight = 1.0
-        if weighted:
-            if len(terms) != 3:
-                raise ValueError(
-                    f"Expecting three columns in the edge list file for a "
-                    f"weighted graph, got {len(terms)} instead: {edge_line!r}",
-                )
-            weight = float(terms[-1])
-        return id1, id2, weight
-
-    @staticmethod
-    def _is_valid_edge_weight(id1, id2, weight):
-        if weight <= 0:
-            warnings.warn(
-                f"Non-positive edge ignored: w({id1},{id2}) = {weight}",
-                RuntimeWarning,
-                stacklevel=2,
-            )
-            return False
-        return True
-
-    def _check_edge_existence(self, id1, id2, idx1, idx2, weight):
-        old = self._data[idx1].get(idx2)
-        if old is not None and old != weight:
-            warnings.warn(
-                f"edge from {id1} to {id2} exists, with value of {old:.2f}. "
-                f"Now overwrite to {weight:.2f}.",
-                RuntimeWarning,
-                stacklevel=2,
-            )
+    def add_node(self, node_id):
+        """Register ``node_id`` (no-op if known)."""
+        if node_id not in self._node_idmap:
+            self._thaw()
+            self._node_idmap[node_id] = len(self._node_ids)
+            self._node_ids.append(node_id)
 
     def get_node_idx(self, node_id):
         self.add_node(node_id)
         return self._node_idmap[node_id]
 
-    def add_node(self, node_id):
-        if node_id not in self._node_idmap:
-            self._node_idmap[node_id] = self.num_nodes
-            self.nodes.append(node_id)
-            self._data.append({})
-
-    def _add_edge_from_idx(self, idx1, idx2, weight):
-        self._data[idx1][idx2] = weight
+    def _put(self, src, dst, weight):
+        self._w[(int(src) << _SHIFT) | int(dst)] = weight
         self._num_edges += 1
 
+    # name kept: SparseGraph.from_mat-style callers of the reference use it
+    _add_edge_from_idx = _put
+
     def add_edge(self, id1, id2, weight=1.0, directed=False):
-        """Insert an edge (both directions unless ``directed``); non-positive weights are skipped."""
-        if not self._is_valid_edge_weight(id1, id2, weight):
+        """Insert ``id1 -> id2`` (and the reverse unless ``directed``); non-positive weights are dropped
+        with a warning, a changed weight of an existing edge is reported and overwritten."""
+        if weight <= 0:
+            warnings.warn(f"Non-positive edge ignored: w({id1},{id2}) = {weight}", RuntimeWarning, stacklevel=2)
             return
-        idx1 = self.get_node_idx(id1)
-        idx2 = self.get_node_idx(id2)
-        self._check_edge_existence(id1, id2, idx1, idx2, weight)
-        self._add_edge_from_idx(idx1, idx2, weight)
+        self._thaw()
+        src, dst = self.get_node_idx(id1), self.get_node_idx(id2)
+        known = self._w.get((src << _SHIFT) | dst)
+        if known is not None and known != weight:
+            warnings.warn(f"edge from {id1} to {id2} exists, with value of {known:.2f}. "
+                          f"Now overwrite to {weight:.2f}.", RuntimeWarning, stacklevel=2)
+        self._put(src, dst, weight)
         if not directed:
-            self._add_edge_from_idx(idx2, idx1, weight)
+            self._put(dst, src, weight)
+
+    @staticmethod
+    def _read_edge_line(edge_line, weighted, delimiter):
+        cols = edge_line.strip().split(delimiter)
+        if weighted and len(cols) != 3:
+            raise ValueError("Expecting three columns in the edge list file for a weighted graph, "
+                             f"got {len(cols)} instead: {edge_line!r}")
+        return cols[0].strip(), cols[1].strip(), (float(cols[-1]) if weighted else 1.0)
 
     def read(self, path, weighted, directed, delimiter="\t"):
-        """Read a 2- or 3-column edge list."""
-        with open(path, encoding="utf-8") as f:
-            for line in f:
+        """Read a 2- or 3-column edge list (native bulk reader when the graph is still empty and the
+        file is well formed, line-by-line otherwise -- same result either way)."""
+        if not self._node_ids and not self._w and self._csr is None and self._num_edges == 0:
+            bulk = _native_edgelist(path, weighted, directed, delimiter)
+            if bulk is not None:
+                *arrays, ids, insertions = bulk
+                self.set_node_ids(ids)
+                self._csr = tuple(arrays)
+                self._num_edges = insertions
+                return
+        with open(path, encoding="utf-8") as stream:
+            for line in stream:
                 self.add_edge(*self._read_edge_line(line, weighted, delimiter), directed)
 
     def save(self, path, unweighted=False, delimiter="\t"):
-        with open(path, "w", encoding="utf-8") as f:
-            for h, t, w in self.edges_iter:
-                cols = [self.nodes[h], self.nodes[t]]
-                if not unweighted:
-                    cols.append(str(w))
-                f.write(delimiter.join(cols) + "\n")
+        with open(path, "w", encoding="utf-8") as out:
+            for head, tail, w in self.edges_iter:
+                cols = [self.nodes[head], self.nodes[tail]] + ([] if unweighted else [str(w)])
+                out.write(delimiter.join(cols) + "\n")
 
     def to_csr(self):
-        """CSR arrays with every row sorted by neighbour index."""
-        n = len(self.nodes)
-        deg = np.fromiter((len(r) for r in self._data), dtype=np.int64, count=n)
-        indptr = np.zeros(n + 1, dtype=np.uint32)
-        indptr[1:] = np.cumsum(deg)
-        nnz = int(indptr[-1])
-        indices = np.zeros(nnz, dtype=np.uint32)
-        data = np.zeros(nnz, dtype=np.float32)
-        pos = 0
-        for row in self._data:
-            for j in sorted(row):
-                indices[pos] = j
-                data[pos] = row[j]
-                pos += 1
-        return indptr, indices, data
+        """``(indptr, indices, data)`` with every row sorted by neighbour index."""
+        return self._arrays()[:3]
 
     def to_dense(self):
-        n = len(self.nodes)
+        indptr, indices, _, w64 = self._arrays()
+        n = self.num_nodes
         mat = np.zeros((n, n))
-        for src, nbrs in enumerate(self._data):
-            for dst, w in nbrs.items():
-                mat[src, dst] = w
+        mat[np.repeat(np.arange(n), np.diff(indptr.astype(np.int64))), indices] = w64
         return mat
 
     @classmethod
@@ -197,9 +240,9 @@ class AdjlstGraph(BaseGraph):
         g = cls(**kwargs)
         for node_id in node_ids:
             g.add_node(node_id)
-        rows, cols = np.nonzero(adj_mat)
-        for i, j in zip(rows, cols):
-            g._add_edge_from_idx(i, j, adj_mat[i, j])
+        adj_mat = np.asarray(adj_mat)
+        for i, j in zip(*np.nonzero(adj_mat)):
+            g._put(i, j, adj_mat[i, j])
         return g
 
 
@@ -208,9 +251,7 @@ class SparseGraph(BaseGraph):
 
     def __init__(self):
         super().__init__()
-        self.data = None
-        self.indptr = None
-        self.indices = None
+        self.data = self.indptr = self.indices = None
 
     @property
     def num_edges(self):
@@ -218,14 +259,17 @@ class SparseGraph(BaseGraph):
             raise ValueError("Empty graph.")
         return self.indptr[-1]
 
-    def read_edg(self, path, weighted, directed, delimiter="\t"):
-        adj = AdjlstGraph()
-        adj.read(path, weighted, directed, delimiter)
+    def _adopt(self, adj):
         self.set_node_ids(adj.nodes)
         self.indptr, self.indices, self.data = adj.to_csr()
 
+    def read_edg(self, path, weighted, directed, delimiter="\t"):
+        adj = AdjlstGraph()
+        adj.read(path, weighted, directed, delimiter)
+        self._adopt(adj)
+
     def read_npz(self, path, weighted, implicit_ids=False):
-        """Load ``IDs``/``data``/``indptr``/``indices`` (a scipy CSR npz works with implicit IDs)."""
+        """Load ``IDs`` / ``data`` / ``indptr`` / ``indices`` (a scipy CSR npz works with implicit IDs)."""
         raw = np.load(path)
         self.indptr = raw["indptr"].astype(np.uint32)
         self.indices = raw["indices"].astype(np.uint32)
@@ -234,8 +278,7 @@ class SparseGraph(BaseGraph):
             raise ValueError("Adjacency matrix data not found.")
         if not weighted:
             self.data[:] = 1.0
-        self.set_node_ids(raw.get("IDs"), implicit_ids=implicit_ids,
-                          num_nodes=int(self.indptr.size - 1))
+        self.set_node_ids(raw.get("IDs"), implicit_ids=implicit_ids, num_nodes=int(self.indptr.size - 1))
 
     def save(self, path):
         np.savez(path, IDs=self.nodes, data=self.data, indptr=self.indptr, indices=self.indices)
@@ -243,15 +286,14 @@ class SparseGraph(BaseGraph):
     @classmethod
     def from_adjlst_graph(cls, adjlst_graph, **kwargs):
         g = cls(**kwargs)
-        g.set_node_ids(adjlst_graph.nodes)
-        g.indptr, g.indices, g.data = adjlst_graph.to_csr()
+        g._adopt(adjlst_graph)
         return g
 
     @classmethod
     def from_mat(cls, adj_mat, node_ids, **kwargs):
         g = cls(**kwargs)
+        g._adopt(AdjlstGraph.from_mat(adj_mat, node_ids))
         g.set_node_ids(node_ids)
-        g.indptr, g.indices, g.data = AdjlstGraph.from_mat(adj_mat, node_ids).to_csr()
         return g
 
     @classmethod
@@ -260,9 +302,8 @@ class SparseGraph(BaseGraph):
         g = cls(**kwargs)
         g.indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
         g.indices = np.ascontiguousarray(indices, dtype=np.uint32)
-        if data is None:
-            data = np.ones(g.indices.size, dtype=np.float32)
-        g.data = np.ascontiguousarray(data, dtype=np.float32)
+        g.data = (np.ones(g.indices.size, dtype=np.float32) if data is None
+                  else np.ascontiguousarray(data, dtype=np.float32))
         g.set_node_ids(node_ids, implicit_ids=node_ids is None, num_nodes=int(g.indptr.size - 1))
         return g
 
@@ -272,8 +313,7 @@ class DenseGraph(BaseGraph):
 
     def __init__(self):
         super().__init__()
-        self._data = None
-        self._nonzero = None
+        self._data = self._nonzero = None
 
     @property
     def num_edges(self):
@@ -290,9 +330,7 @@ class DenseGraph(BaseGraph):
         self._data = data.astype(float)
         self._nonzero = np.array(self._data != 0, dtype=bool)
 
-    @property
-    def nonzero(self):
-        return self._nonzero
+    nonzero = property(lambda self: self._nonzero)
 
     def read_npz(self, path, weighted, implicit_ids=False):
         raw = np.load(path)
