@@ -1339,8 +1339,11 @@ walk_kernel(WalkArgs a) {
                     PROF_COUNT(pf, 10, 1);
                 }
             }
-            else choice = sample_step_weighted<T, DENSE>(a, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, queue, cur,
-                                                          j >= 2, prev, t0, dp, r, s0, d);
+            else {
+                const WalkArgs la = reload_walk_args();   // arguments are not kept live across the loop
+                choice = sample_step_weighted<T, DENSE>(la, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, queue, cur,
+                                                        j >= 2, prev, t0, dp, r, s0, d);
+            }
             choice = uni(choice);
             bool clamped = false;
             const bool real_edge = choice < d;
