@@ -68,12 +68,13 @@ struct CsrDev {
     // vrec[v] = { indptr[v], degree(v), foff[v], tab_off[v] / 2 }: everything the walk needs to know about
     // a vertex in ONE 16-byte scalar load (filter and index sizes follow from the degree).
     const uint4 *__restrict__ vrec;
-    // tri[e] = |N(u) & N(v)| for CSR entry e = (u -> v): the number of common neighbours of the two
-    // endpoints (a per-edge triangle count, built once).  With it the normaliser `tot` of a step is
-    // known BEFORE any membership work, so the membership test can stop as soon as the CDF search
-    // has found its element (on average half of the keys are never touched).  nullptr: not built
-    // (graphs with self loops, or PW_NO_LAZY).
-    const uint32_t *__restrict__ tri;
+    // tri[e] = { |N(u) & N(v)|, position of u in row v (or 0xffffffff) } for CSR entry e = (u -> v): the
+    // number of common neighbours of the two endpoints (a per-edge triangle count) and the place of
+    // the reverse edge, built once.  With the count the normaliser `tot` of a step is known BEFORE any
+    // membership work, so the membership test can stop as soon as the CDF search has found its element
+    // (on average half of the keys are never touched); the reverse position is where `prev` sits in
+    // cur's row on the next step (no index probe).  nullptr: not built (graphs with self loops).
+    const uint2 *__restrict__ tri;
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -133,7 +134,7 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.g.tab_off = (const uint64_t *)PW_KARG(uint64_t, g.tab_off);
     a.g.slots = (const uint64_t *)PW_KARG(uint64_t, g.slots);
     a.g.vrec = (const uint4 *)PW_KARG(uint64_t, g.vrec);
-    a.g.tri = (const uint32_t *)PW_KARG(uint64_t, g.tri);
+    a.g.tri = (const uint2 *)PW_KARG(uint64_t, g.tri);
     a.g.n_nodes = PW_KARG(uint32_t, g.n_nodes);
     a.g.nnz = PW_KARG(uint32_t, g.nnz);
     a.p = PW_KARG(double, p);
@@ -998,13 +999,14 @@ struct VertexCtx {
 };
 
 __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16_t *rank, uint32_t cur,
-                                                          uint32_t prev, uint32_t n_in, const VertexCtx &vc,
-                                                          const VertexCtx &vp, double r, Prof &pf) {
+                                                          uint32_t prev, uint32_t n_in, uint32_t prev_pos,
+                                                          const VertexCtx &vc, const VertexCtx &vp, double r,
+                                                          Prof &pf) {
     const int lane = lane_id();
     const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
-    // The step is a chain of memory latencies.  The vertex records of cur and prev and the
-    // common-neighbour count of the edge arrived with the previous step; what is left is the probe for
-    // prev's position in cur's row and the keys.
+    // The step is a chain of memory latencies.  The vertex records of cur and prev, the common-neighbour
+    // count of the edge and prev's position in cur's row (prev_pos, 0xffffffff == not a neighbour) all
+    // arrived with the previous step; the first thing requested here are the keys.
     const float w_out = PW_KARG(float, w_out), w_prev = PW_KARG(float, w_prev);
     const uint64_t p_slots = PW_KARG(uint64_t, g.slots);
     const uint64_t p_kf = PW_KARG(uint64_t, g.kf), p_fbits = PW_KARG(uint64_t, g.fbits);
@@ -1012,14 +1014,9 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const uint32_t k0 = scatter ? t0 : s0;
     const uint32_t kn = scatter ? dp : d;
     const gptr<uint64_t> krow = as_global<uint64_t>(p_kf) + k0;   // fw << 32 | key
-    // first 64 keys: requested before the (dependent, scalar) probe below so that the two overlap
     uint64_t kfw_first = 0;
     if (n_in && (uint32_t)lane < kn) kfw_first = krow[lane];
-
-    // position of prev in cur's row: scalar probe of cur's adjacency index
     const uint32_t ctmask = index_mask_for_degree(d);
-    const uint64_t ctb0 = 2ull * vc.tb;
-    const uint32_t prev_pos = adj_lookup_s(as_scalar<uint64_t>(p_slots) + ctb0, ctmask, prev);   // 0xffffffff == NOT_FOUND
     const uint32_t n_pv = prev_pos != NOT_FOUND ? 1u : 0u;
     if (n_in + n_pv > d) return LAZY_FALLBACK;
     const uint32_t n_out = d - n_in - n_pv;
@@ -1314,6 +1311,7 @@ walk_kernel(WalkArgs a) {
         enter(cur);
         bool lazy_next = false;    // the edge prev -> cur is a real CSR entry with a common-neighbour count
         uint32_t n_in = 0;         // tri[e(prev -> cur)], requested together with the sampled neighbour
+        uint32_t rev_pos = NOT_FOUND;   // position of prev in cur's row (same record)
         uint32_t len_out = L + 1;
         uint32_t j = 1;
         for (; j <= L; j++) {
@@ -1329,7 +1327,7 @@ walk_kernel(WalkArgs a) {
                 choice = LAZY_FALLBACK;
 #ifndef PW_NO_LAZY
                 PROF_TICK(pf, 0);
-                if (!DENSE && lazy_next) choice = sample_step_unit_lazy(mask, rank, cur, prev, n_in, vc, vp, r, pf);
+                if (!DENSE && lazy_next) choice = sample_step_unit_lazy(mask, rank, cur, prev, n_in, rev_pos, vc, vp, r, pf);
 #endif
                 if (choice == LAZY_FALLBACK) {
                     PROF_TICK(pf, 1);
@@ -1361,7 +1359,12 @@ walk_kernel(WalkArgs a) {
             if (UNIT && !DENSE) {
                 const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
                 lazy_next = real_edge && p_tri != 0 && PW_KARG(uint32_t, lazy_ok) != 0;
-                if (lazy_next) n_in = as_scalar<uint32_t>(p_tri)[pos];
+                if (lazy_next) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 er = as_scalar<u32x2>(p_tri)[pos];
+                    n_in = er.x;
+                    rev_pos = er.y;
+                }
             }
             if (lane == 0) ((gptr_mut<uint32_t>)PW_KARG(uint64_t, out))[job * W + j] = nxt;
             prev = cur;
