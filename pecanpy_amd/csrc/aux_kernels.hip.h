@@ -171,7 +171,7 @@ adj_index_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__re
 // per-edge common-neighbour counts tri[e] = |N(u) & N(v)| for e = (u -> v): one lane per CSR entry walks
 // the shorter of the two rows through the longer row's filter + adjacency index.
 __global__ void __launch_bounds__(256)
-tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint2 *tri) {
+tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint4 *tri) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= g.nnz) return;
     const uint32_t u = edge_row[e], v = g.indices[e];
@@ -196,7 +196,7 @@ tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint2 *tri) {
         const uint32_t vmask = (uint32_t)(g.tab_off[v + 1] - vtb) - 1u;
         rev = adj_lookup(g.slots + vtb, vmask, u, true);
     }
-    tri[e] = make_uint2(cnt, rev);
+    tri[e] = make_uint4(v, cnt, rev, dv);
 }
 
 __global__ void __launch_bounds__(256)

@@ -79,7 +79,7 @@ struct pw_graph {
     uint64_t *d_fbits = nullptr;
     uint2 *d_kf = nullptr;           // CSR graphs: (neighbour id, filter word) per CSR entry
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
-    uint2 *d_tri = nullptr;                             // CSR graphs: per-edge {common-neighbour count, reverse position}
+    uint4 *d_tri = nullptr;                             // CSR graphs: per-edge {neighbour, common-neighbour count, reverse position, degree}
     uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
@@ -330,7 +330,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
             if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         }
         if (e == hipSuccess && !has_loop) {
-            e = hipMalloc((void **)&g->d_tri, sizeof(uint2) * (size_t)nnz);
+            e = hipMalloc((void **)&g->d_tri, sizeof(uint4) * (size_t)nnz);
             if (e == hipSuccess) {
                 pw::CsrDev c = csr_dev(g);
                 hipLaunchKernelGGL(pw::tri_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,

@@ -68,13 +68,15 @@ struct CsrDev {
     // vrec[v] = { indptr[v], degree(v), foff[v], tab_off[v] / 2 }: everything the walk needs to know about
     // a vertex in ONE 16-byte scalar load (filter and index sizes follow from the degree).
     const uint4 *__restrict__ vrec;
-    // tri[e] = { |N(u) & N(v)|, position of u in row v (or 0xffffffff) } for CSR entry e = (u -> v): the
+    // tri[e] = { v, |N(u) & N(v)|, position of u in row v (or 0xffffffff), degree(v) } for CSR entry e = (u -> v): the
     // number of common neighbours of the two endpoints (a per-edge triangle count) and the place of
     // the reverse edge, built once.  With the count the normaliser `tot` of a step is known BEFORE any
     // membership work, so the membership test can stop as soon as the CDF search has found its element
     // (on average half of the keys are never touched); the reverse position is where `prev` sits in
-    // cur's row on the next step (no index probe).  nullptr: not built (graphs with self loops).
-    const uint2 *__restrict__ tri;
+    // cur's row on the next step (no index probe); v and its degree ride along so that one 16-byte load
+    // names the next vertex and tells which of the two rows will supply the keys.  nullptr: not built
+    // (graphs with self loops).
+    const uint4 *__restrict__ tri;
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -134,7 +136,7 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.g.tab_off = (const uint64_t *)PW_KARG(uint64_t, g.tab_off);
     a.g.slots = (const uint64_t *)PW_KARG(uint64_t, g.slots);
     a.g.vrec = (const uint4 *)PW_KARG(uint64_t, g.vrec);
-    a.g.tri = (const uint2 *)PW_KARG(uint64_t, g.tri);
+    a.g.tri = (const uint4 *)PW_KARG(uint64_t, g.tri);
     a.g.n_nodes = PW_KARG(uint32_t, g.n_nodes);
     a.g.nnz = PW_KARG(uint32_t, g.nnz);
     a.p = PW_KARG(double, p);
@@ -994,12 +996,15 @@ __device__ __forceinline__ uint32_t unit_search_units(const UnitRow &ur, uint32_
 
 // Vertex context carried by the walk loop: row start/degree plus the offsets of the row's filter and
 // adjacency index (one vrec load when the vertex is entered).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct VertexCtx {
     uint32_t s0, d, f0, tb;   // tb = tab_off / 2
 };
 
 __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16_t *rank, uint32_t cur,
                                                           uint32_t prev, uint32_t n_in, uint32_t prev_pos,
+                                                          bool keys_preloaded, uint64_t kfw_pre,
                                                           const VertexCtx &vc, const VertexCtx &vp, double r,
                                                           Prof &pf) {
     const int lane = lane_id();
@@ -1014,8 +1019,9 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const uint32_t k0 = scatter ? t0 : s0;
     const uint32_t kn = scatter ? dp : d;
     const gptr<uint64_t> krow = as_global<uint64_t>(p_kf) + k0;   // fw << 32 | key
-    uint64_t kfw_first = 0;
-    if (n_in && (uint32_t)lane < kn) kfw_first = krow[lane];
+    // first 64 keys: already requested by the previous step when they come from prev's row
+    uint64_t kfw_first = kfw_pre;
+    if (n_in && !keys_preloaded && (uint32_t)lane < kn) kfw_first = krow[lane];
     const uint32_t ctmask = index_mask_for_degree(d);
     const uint32_t n_pv = prev_pos != NOT_FOUND ? 1u : 0u;
     if (n_in + n_pv > d) return LAZY_FALLBACK;
@@ -1299,7 +1305,6 @@ walk_kernel(WalkArgs a) {
         VertexCtx vc{0, 0, 0, 0}, vp{0, 0, 0, 0};
         auto enter = [&](uint32_t v) {
             if (!DENSE) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 rec = as_scalar<u32x4>(PW_KARG(uint64_t, g.vrec))[v];   // one s_load_dwordx4
                 vc = VertexCtx{rec.x, rec.y, rec.z, rec.w};
             } else {
@@ -1312,6 +1317,8 @@ walk_kernel(WalkArgs a) {
         bool lazy_next = false;    // the edge prev -> cur is a real CSR entry with a common-neighbour count
         uint32_t n_in = 0;         // tri[e(prev -> cur)], requested together with the sampled neighbour
         uint32_t rev_pos = NOT_FOUND;   // position of prev in cur's row (same record)
+        bool keys_pre = false;     // the first 64 keys of the next step were requested with that record
+        uint64_t kfw_pre = 0;
         uint32_t len_out = L + 1;
         uint32_t j = 1;
         for (; j <= L; j++) {
@@ -1327,7 +1334,7 @@ walk_kernel(WalkArgs a) {
                 choice = LAZY_FALLBACK;
 #ifndef PW_NO_LAZY
                 PROF_TICK(pf, 0);
-                if (!DENSE && lazy_next) choice = sample_step_unit_lazy(mask, rank, cur, prev, n_in, rev_pos, vc, vp, r, pf);
+                if (!DENSE && lazy_next) choice = sample_step_unit_lazy(mask, rank, cur, prev, n_in, rev_pos, keys_pre, kfw_pre, vc, vp, r, pf);
 #endif
                 if (choice == LAZY_FALLBACK) {
                     PROF_TICK(pf, 1);
@@ -1353,18 +1360,27 @@ walk_kernel(WalkArgs a) {
             const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
             if (pos >= nnz) { pos = nnz - 1; clamped = true; }
             if (clamped && lane == 0) stat[2]++;
-            // the sampled neighbour and the common-neighbour count of the edge just taken: one round trip
-            const uint32_t nxt = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[pos];
+            // The edge just taken: one 16-byte record names the next vertex, its degree, the number of
+            // common neighbours and where cur sits in the next vertex's row.  When cur's row is the
+            // shorter one it supplies the keys of the next step: request the first 64 right away, together
+            // with the next vertex's record.
+            uint32_t nxt;
             lazy_next = false;
-            if (UNIT && !DENSE) {
-                const uint64_t p_tri = PW_KARG(uint64_t, g.tri);
-                lazy_next = real_edge && p_tri != 0 && PW_KARG(uint32_t, lazy_ok) != 0;
-                if (lazy_next) {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 er = as_scalar<u32x2>(p_tri)[pos];
-                    n_in = er.x;
-                    rev_pos = er.y;
+            keys_pre = false;
+            kfw_pre = 0;
+            const uint64_t p_tri = (UNIT && !DENSE) ? PW_KARG(uint64_t, g.tri) : 0ull;
+            if (p_tri != 0) {
+                const u32x4 er = as_scalar<u32x4>(p_tri)[pos];
+                nxt = er.x;
+                n_in = er.y;
+                rev_pos = er.z;
+                lazy_next = real_edge && PW_KARG(uint32_t, lazy_ok) != 0;
+                if (lazy_next && n_in && d <= er.w) {
+                    keys_pre = true;
+                    if ((uint32_t)lane < d) kfw_pre = (as_global<uint64_t>(PW_KARG(uint64_t, g.kf)) + s0)[lane];
                 }
+            } else {
+                nxt = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[pos];
             }
             if (lane == 0) ((gptr_mut<uint32_t>)PW_KARG(uint64_t, out))[job * W + j] = nxt;
             prev = cur;
