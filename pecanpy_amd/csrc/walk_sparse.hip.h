@@ -213,6 +213,7 @@ __host__ __device__ inline uint32_t filter_words_for_degree(uint32_t d) {
 }
 
 // sizes of a row's filter / adjacency index from its degree d >= 1 (the build code's rules, scalar ALU)
+__device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t next_pow2_u32(uint32_t x) {   // smallest power of two >= x, x >= 1
     return x <= 1u ? 1u : 1u << (32 - __builtin_clz(x - 1u));
 }
@@ -1039,7 +1040,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     const uint32_t sh_u = (__float_as_uint(u) >> 23) & 0xffu;
     const uint32_t sh_in = (127u - sh_u) & 31u, sh_out = (((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u) & 31u,
                    sh_prev = (((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u) & 31u;   // unused classes: count 0
-    const double units = td * (double)(1u << sh_in);               // td / u
+    const double units = ldexp(td, (int)(127u - sh_u));           // td / u (exact: u is a power of two)
     const uint32_t units_i = uni((uint32_t)units);
     const uint32_t r_units = uni((uint32_t)(r * units));
 
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         //   E(k) = (k + 1) << sh_out                       k <  prev_pos
         //        = (k << sh_out) + (1 << sh_prev)          k >= prev_pos
         const double R = r * units;
-        const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
+        const double wmax = (double)(1u << max_u32(sh_in, max_u32(sh_out, sh_prev))) + 2.0;   // heaviest element, in units
         const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
         const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;   // drift bound, see below
         const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
             // 2^-24 relative on the three values; every element weighs at least one unit).  Hence every j below the first k1 with E(k1) >= ceil(R - zr) has c_j < r
             // (induction on j), and E(k1) >= ceil(R + zr) gives c_k1 >= r: k1 is the chain's answer.
             const double R = r * units;
-            const double wmax = (double)(1u << (sh_prev > sh_in ? sh_prev : sh_in)) + 2.0;
+            const double wmax = (double)(1u << max_u32(sh_in, max_u32(sh_out, sh_prev))) + 2.0;   // heaviest element, in units
             // every element weighs at least one unit, so E(k) >= k + 1 and k1 < R: j + 1 <= min(known_end, R + 1)
             const double jb = (double)known_end < R + 2.0 ? (double)known_end : R + 2.0;
             // and E(i) <= E(j) - (j - i): the sum of the partial sums is at most (j+1) E(j) - j (j+1) / 2

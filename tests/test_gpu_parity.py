@@ -107,7 +107,8 @@ def _check_vs_oracle(indptr, indices, data, p, q, num_walks, L, seed, stream_ski
     return st
 
 
-@pytest.mark.parametrize("scale,p,q", [(10, 0.5, 2), (12, 0.25, 4), (13, 2, 0.5), (12, 1, 1)])
+@pytest.mark.parametrize("scale,p,q", [(10, 0.5, 2), (12, 0.25, 4), (13, 2, 0.5), (12, 1, 1), (12, 1, 0.25),
+                                       (12, 4, 0.125), (11, 0.0625, 16), (12, 8, 1), (11, 2.0 ** -40, 2.0 ** 40)])
 def test_rmat_unweighted_vs_oracle(scale, p, q):
     indptr, indices, data = rmat_csr(scale, seed=scale)
     _check_vs_oracle(indptr, indices, data, p, q, 2, 40, seed=scale)

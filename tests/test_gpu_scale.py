@@ -92,7 +92,7 @@ def test_full_size_lazy_step_equals_eager_step(run, monkeypatch):
     assert eager.last_stats["total_steps"] == run["stats"]["total_steps"]
     assert eager.last_stats["overflow_reads"] == run["stats"]["overflow_reads"]
     assert torch.equal(out, run["out"])
-    for p, q in ((0.25, 4.0), (2.0, 0.5), (1.0, 1.0)):
+    for p, q in ((0.25, 4.0), (2.0, 0.5), (1.0, 1.0), (1.0, 0.25), (4.0, 0.125), (0.125, 8.0)):
         a = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
         b = eager.simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
         assert torch.equal(a, b), (p, q)
