@@ -20,6 +20,7 @@ namespace pw {
 constexpr int DW = 512;                  // 32-bit mask words per segment
 constexpr uint32_t DSEG = DW * 32;       // columns per segment
 constexpr int DQW = DW / 2;              // 64-bit adjacency words per segment
+constexpr uint32_t MAX_SEG_COUNTS = 64;  // rows up to 64 segments (1 M columns) keep per-segment class counts
 
 struct DenseArgs {
     const uint64_t *__restrict__ adjbits;  // [n][wpr]
@@ -207,10 +208,12 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
 walk_dense_bits_kernel(DenseArgs a) {
     __shared__ uint32_t s_mi[WAVES_PER_BLOCK][DW], s_mo[WAVES_PER_BLOCK][DW];
     __shared__ uint16_t s_ri[WAVES_PER_BLOCK][DW + 2], s_ro[WAVES_PER_BLOCK][DW + 2];
+    __shared__ uint32_t s_seg_in[WAVES_PER_BLOCK][MAX_SEG_COUNTS], s_seg_all[WAVES_PER_BLOCK][MAX_SEG_COUNTS];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     uint32_t *mi = s_mi[wave], *mo = s_mo[wave];
     uint16_t *ri = s_ri[wave], *ro = s_ro[wave];
+    uint32_t *seg_in = s_seg_in[wave], *seg_all = s_seg_all[wave];
     const uint32_t L = a.L, n = a.n, wpr = a.wpr;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
@@ -246,17 +249,38 @@ walk_dense_bits_kernel(DenseArgs a) {
 
             // class counts over the whole row (for tot)
             uint32_t n_in = 0, n_pv = 0;
+            // per-segment class counts (in / all neighbours, prev excluded) for the exact-arithmetic search
+            const bool seg_counts = has_prev && n_seg <= MAX_SEG_COUNTS;
             if (has_prev) {
-                uint32_t acc = 0;
-                for (uint32_t w = lane; w < wpr; w += WAVE) {
-                    uint64_t cw = crow[w], pw = prow[w];
-                    if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));
-                    acc += (uint32_t)__popcll(cw & pw);
+                uint32_t acc = 0, acc_in_seg = 0, acc_all_seg = 0;
+                uint32_t it = 0;
+                for (uint32_t w0 = 0; w0 < wpr; w0 += WAVE, it++) {
+                    const uint32_t w = w0 + lane;
+                    if (w < wpr) {
+                        uint64_t cw = crow[w], pw = prow[w];
+                        if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));
+                        const uint32_t ci = (uint32_t)__popcll(cw & pw);
+                        acc += ci;
+                        acc_in_seg += ci;
+                        acc_all_seg += (uint32_t)__popcll(cw);
+                    }
+                    // a segment = DQW 64-bit words = DQW / WAVE iterations of this loop
+                    if (seg_counts && ((it + 1) % (DQW / WAVE) == 0 || w0 + WAVE >= wpr)) {
+                        uint32_t si = acc_in_seg, sa = acc_all_seg;
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) {
+                            si += (uint32_t)__shfl_xor((int)si, off, WAVE);
+                            sa += (uint32_t)__shfl_xor((int)sa, off, WAVE);
+                        }
+                        if (lane == 0) { seg_in[it / (DQW / WAVE)] = si; seg_all[it / (DQW / WAVE)] = sa; }
+                        acc_in_seg = acc_all_seg = 0;
+                    }
                 }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) acc += (uint32_t)__shfl_xor((int)acc, off, WAVE);
                 n_in = uni(acc);
                 n_pv = (uint32_t)((uni(crow[prev >> 6]) >> (prev & 63)) & 1ull);
+                wave_lds_fence();
             }
             const uint32_t n_out = d - n_in - n_pv;
             const uint32_t prev_col = n_pv ? prev : NOT_FOUND;
@@ -301,6 +325,58 @@ walk_dense_bits_kernel(DenseArgs a) {
                 }
                 nxt = uni(best);
             } else {
+                // Exact-arithmetic decision (same argument as the sparse lazy step, with 2^-53): partial sums of
+                // the exact CDF are E(k) / S in units of the smallest weight; the float64 chain cannot differ
+                // from them by more than zr units, so when no partial sum lies within zr of R = r * S the answer
+                // is the first column with E >= R -- found from the per-segment counts and ONE segment's ranks.
+                if (have_tot && has_prev && seg_counts) {
+                    double u = 1.0;
+                    if (n_out && w_out < u) u = w_out;
+                    if (n_pv && w_prevp < u) u = w_prevp;
+                    const double S = tot / u, wi = 1.0 / u, wo = w_out / u, wp = w_prevp / u;   // exact: powers of two
+                    const double wmax = fmax(wi, fmax(wo, wp)) + 2.0;
+                    if (S <= 1099511627776.0 && wmax <= 1048576.0) {
+                        const double R = r * S;
+                        const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
+                        const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 9007199254740992.0)
+                                          + R * (1.0 / 4503599627370496.0) + 1e-9;
+                        const double lo_d = ceil(R - zr), hi_d = ceil(R + zr);
+                        const uint64_t lo_th = lo_d > 0.0 ? (uint64_t)lo_d : 0ull, hi_th = (uint64_t)hi_d;
+                        const uint64_t Wi = (uint64_t)wi, Wo = (uint64_t)wo, Wp = (uint64_t)wp;
+                        const uint32_t pseg = prev_col != NOT_FOUND ? prev_col / DSEG : NOT_FOUND;
+                        // segment holding the first column with E >= lo_th
+                        uint64_t e0 = 0;
+                        uint32_t sx = NOT_FOUND;
+                        for (uint32_t sg = 0; sg < n_seg; sg++) {
+                            const uint32_t ci = uni(seg_in[sg]), ca = uni(seg_all[sg]);
+                            const uint64_t e1 = e0 + (uint64_t)ci * Wi + (uint64_t)(ca - ci) * Wo + (pseg == sg ? Wp : 0ull);
+                            if (e1 >= lo_th) { sx = sg; break; }
+                            e0 = e1;
+                        }
+                        if (sx != NOT_FOUND) {
+                            prepare_dense_segment(crow, prow, has_prev, wpr, n, sx, prev, mi, mo, ri, ro);
+                            const uint32_t lo = sx * DSEG, len = n - lo < DSEG ? n - lo : DSEG;
+                            const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
+                            uint32_t a0 = lo, a1 = lo + len - 1, kf = NOT_FOUND;
+                            uint64_t ef = 0;
+                            for (;;) {   // 64-ary search for the first column with E >= lo_th
+                                const uint32_t cnt = a1 - a0 + 1, step = (cnt + WAVE - 1) / WAVE;
+                                const uint64_t kp64 = (uint64_t)a0 + (uint64_t)(lane + 1) * step - 1;
+                                const uint32_t kp = kp64 > a1 ? a1 : (uint32_t)kp64;
+                                const uint64_t G = e0 + (uint64_t)cr.rank_in(kp + 1) * Wi + (uint64_t)cr.rank_out(kp + 1) * Wo +
+                                                   ((pseg == sx && prev_col <= kp) ? Wp : 0ull);
+                                const uint64_t hitm = ballot(G >= lo_th);
+                                if (!hitm) break;   // cannot happen: the segment total reaches lo_th
+                                const int first = __builtin_ctzll(hitm);
+                                if (step == 1) { kf = a0 + (uint32_t)first; ef = readlane_u64(G, first); break; }
+                                const uint64_t nhi = (uint64_t)a0 + (uint64_t)(first + 1) * step - 1;
+                                a0 += (uint32_t)first * step;
+                                if (nhi < a1) a1 = (uint32_t)nhi;
+                            }
+                            if (kf != NOT_FOUND && ef >= hi_th) nxt = kf;   // decisive; else the float chain below
+                        }
+                    }
+                }
                 for (uint32_t seg = 0; seg < n_seg && nxt == NOT_FOUND; seg++) {
                     prepare_dense_segment(crow, prow, has_prev, wpr, n, seg, prev, mi, mo, ri, ro);
                     const uint32_t lo = seg * DSEG, len = n - lo < DSEG ? n - lo : DSEG;

@@ -295,6 +295,23 @@ def test_dense_bits_kernel_vs_oracle(n, density, p, q):
     assert np.array_equal(eng2.simulate("DenseOTF", p, q, False, starts, 20, seed=5), want)
 
 
+@pytest.mark.parametrize("p,q", [(0.5, 2), (2, 0.25), (1, 1)])
+def test_dense_bits_exact_search_equals_float64_chain_kernel(p, q):
+    """The column-space kernel decides the CDF search in exact arithmetic; the compressed-row DenseOTF
+    kernel runs the float64 chain.  Same graph, 1.2e6 transitions: identical walks."""
+    from pecanpy_amd.synth import er_dense_mask
+
+    n = 5000
+    adj = er_dense_mask(n, 0.2, seed=9)
+    starts = orc.shuffled_starts(n, 3, 1)
+    chain = WalkEngine.from_dense(adj.astype(np.float64))          # n <= 12000: compressed-row kernel
+    bits = WalkEngine.from_dense_bits(_pack_bits(adj), n)           # packed rows: column-space kernel
+    a = chain.simulate("DenseOTF", p, q, False, starts, 80, seed=2)
+    b = bits.simulate("DenseOTF", p, q, False, starts, 80, seed=2)
+    assert np.array_equal(a, b), _diff_report(b, a)
+    assert chain.last_stats["total_steps"] == bits.last_stats["total_steps"] > 10**6
+
+
 def test_dense_and_sparse_agree_on_unweighted_graph():
     """reference test/test_walk.py:58-81: identical tables for SparseOTF and DenseOTF."""
     indptr, indices, data = rmat_csr(9, seed=11)
