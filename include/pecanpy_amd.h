@@ -75,7 +75,12 @@ int pw_device_count(void);
 /* ---- graph handles --------------------------------------------------------------------- */
 /* CSR in the reference's SparseGraph layout (graph.py:409-413): indptr uint32[n_nodes+1],
  * indices uint32[nnz] ascending and duplicate-free per row, data float32[nnz].
- * data may be NULL: all weights 1.0 (the reference's unweighted graphs, graph.py:170,480). */
+ * data may be NULL: all weights 1.0 (the reference's unweighted graphs, graph.py:170,480).
+ * Besides the three arrays the handle owns the membership index built here on the device (per-row
+ * Bloom filters, adjacency hash index, key stream, vertex records and -- for unit-weight graphs without
+ * self loops -- per-edge records with common-neighbour counts): about 55 bytes per CSR entry in total.
+ * Environment: PECANPY_AMD_NO_LAZY=1 skips the per-edge records (every step then takes the eager path;
+ * used by the test-suite to cross-check the two step implementations). */
 int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                   uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out);
 
