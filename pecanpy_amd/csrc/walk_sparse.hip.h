@@ -997,6 +997,24 @@ __device__ __forceinline__ uint32_t unit_search_units(const UnitRow &ur, uint32_
 
 // Vertex context carried by the walk loop: row start/degree plus the offsets of the row's filter and
 // adjacency index (one vrec load when the vertex is entered).
+// First position k >= s of a run without common neighbours whose exact mass reaches th:
+//   E(k) = base + (#"out" elements in [s, k]) << sh_out + (prev inside [s, k] ? wp : 0)
+// (prev_pos == NOT_FOUND: prev is not in the row).  Returns k, its mass through e_k.  Scalar arithmetic.
+__device__ __forceinline__ uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t prev_pos,
+                                                  uint32_t sh_out, uint32_t wp, uint32_t &e_k) {
+    const uint32_t wo_m1 = (1u << sh_out) - 1u;
+    const uint32_t need = th > base ? th - base : 0u;
+    uint32_t k = need ? s + ((need + wo_m1) >> sh_out) - 1u : s;   // first k with (k - s + 1) << sh_out >= need
+    e_k = base + ((k - s + 1u) << sh_out);
+    if (prev_pos != NOT_FOUND && prev_pos >= s && k >= prev_pos) {   // every k < prev_pos stays below th
+        const uint32_t need2 = need > wp ? need - wp : 0u;
+        k = s + ((need2 + wo_m1) >> sh_out);                         // first k with ((k - s) << sh_out) + wp >= need
+        if (k < prev_pos) k = prev_pos;
+        e_k = base + ((k - s) << sh_out) + wp;
+    }
+    return k;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct VertexCtx {
@@ -1038,17 +1056,25 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
     // Search trigger (a heuristic, exactness not needed): mass of a prefix in units of the smallest
     // weight u -- integers below 2^24 by the precondition above, so plain scalar arithmetic.
     const uint32_t sh_u = (__float_as_uint(u) >> 23) & 0xffu;
-    const uint32_t sh_in = (127u - sh_u) & 31u, sh_out = (((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u) & 31u,
-                   sh_prev = (((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u) & 31u;   // unused classes: count 0
+    const uint32_t sh_in = (127u - sh_u) & 31u,   // classes that do not occur in the row get shift 0 (their count is 0)
+                   sh_out = n_out ? (((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u) & 31u : 0u,
+                   sh_prev = n_pv ? (((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u) & 31u : 0u;
     const double units = ldexp(td, (int)(127u - sh_u));           // td / u (exact: u is a power of two)
     const uint32_t units_i = uni((uint32_t)units);
     const uint32_t r_units = uni((uint32_t)(r * units));
 
-    if (n_in == 0) {
-        // No common neighbour at all (a fifth of the edges of an R-MAT graph): every position is "out"
-        // except prev's, E(k) is a closed form and the exact decision needs neither keys nor the mask.
-        //   E(k) = (k + 1) << sh_out                       k <  prev_pos
-        //        = (k << sh_out) + (1 << sh_prev)          k >= prev_pos
+    const VertexCtx &vs = scatter ? vc : vp;                    // the searched row: cur (scatter) or prev
+    const uint32_t nw_mask = filter_mask_for_degree(vs.d);
+    const gptr<uint64_t> fb = as_global<uint64_t>(p_fbits) + vs.f0;
+    const uint32_t tmask = scatter ? ctmask : index_mask_for_degree(dp);
+    const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + 2ull * vs.tb;
+
+    if (n_in == 0 || kn <= WAVE) {
+        // Closed-form decision without the LDS mask.  Either there is no common neighbour at all (a fifth
+        // of the edges of an R-MAT graph: every position is "out" except prev's), or all keys fit one
+        // 64-key chunk (two fifths of the steps): the common neighbours are then at most 64 known
+        // positions P_0 < P_1 < ..., one per lane, and between them the row consists of "out" runs, so the
+        // first position whose exact mass reaches the target follows from a ballot and scalar arithmetic.
         const double R = r * units;
         const double wmax = (double)(1u << max_u32(sh_in, max_u32(sh_out, sh_prev))) + 2.0;   // heaviest element, in units
         const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
@@ -1056,26 +1082,55 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
         const double lo = R - zr;
         const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
-        const uint32_t wo_m1 = (1u << sh_out) - 1u, wp = 1u << sh_prev;
-        uint32_t k1 = lo_th ? ((lo_th + wo_m1) >> sh_out) - 1u : 0u;          // first k with (k + 1) << sh_out >= lo_th
-        uint32_t e1 = (k1 + 1u) << sh_out;
-        if (n_pv && k1 >= prev_pos) {                                         // all k < prev_pos stay below lo_th
-            const uint32_t need = lo_th > wp ? lo_th - wp : 0u;
-            k1 = (need + wo_m1) >> sh_out;                                    // first k with (k << sh_out) + wp >= lo_th
-            if (k1 < prev_pos) k1 = prev_pos;
-            e1 = (k1 << sh_out) + wp;
+        const uint32_t wp = 1u << sh_prev;
+        const uint32_t pp = n_pv ? prev_pos : NOT_FOUND;
+        uint32_t k1, e1;
+        if (n_in == 0) {
+            k1 = solve_out_run(0u, 0u, lo_th, pp, sh_out, wp, e1);
+        } else {
+            // classify the (at most 64) keys: position of every common neighbour in cur's row
+            const bool valid = (uint32_t)lane < kn;
+            const uint32_t key = (uint32_t)kfw_first, fw = (uint32_t)(kfw_first >> 32);
+            const uint64_t word = valid ? fb[filter_word(fw, nw_mask)] : 0ull;
+            const bool pass = valid && filter_pass(word, fw);
+            const uint32_t gpos = adj_lookup_g(tab, tmask, key, pass);
+            const bool hit = pass && gpos != 0xffffffffu;
+            const uint32_t P = scatter ? gpos : (uint32_t)lane;     // keys ascend, so do the positions
+            const uint64_t hb = ballot(hit);
+            const uint32_t i = (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));   // common neighbours before this one
+            const uint32_t pv = (pp != NOT_FOUND && pp < P) ? 1u : 0u;
+            const uint32_t e_before = ((P - i - pv) << sh_out) + (i << sh_in) + (pv << sh_prev);   // E(P - 1)
+            const uint32_t e_at = e_before + (1u << sh_in);                                         // E(P)
+            const uint64_t reach = ballot(hit && e_at >= lo_th);
+            // the run of "out" positions that holds the target: after the last common neighbour below it
+            uint64_t below = hb;                                   // common neighbours before the run
+            bool in_run = true;
+            int f = -1;
+            if (reach) {
+                f = __builtin_ctzll(reach);
+                below = hb & ((1ull << f) - 1ull);
+                // reached before P_f already?  (only possible if there is a position before it: P_f == 0 with
+                // a target of zero is the common neighbour itself)
+                in_run = readlane_u32(e_before, f) >= lo_th && readlane_u32(P, f) != 0u;
+            }
+            if (!in_run) {
+                k1 = readlane_u32(P, f);
+                e1 = readlane_u32(e_at, f);
+            } else {
+                uint32_t s_run = 0, base = 0;
+                if (below) {
+                    const int pl = 63 - __builtin_clzll(below);
+                    s_run = readlane_u32(P, pl) + 1u;
+                    base = readlane_u32(e_at, pl);
+                }
+                k1 = solve_out_run(s_run, base, lo_th, (pp != NOT_FOUND && pp >= s_run) ? pp : NOT_FOUND, sh_out, wp, e1);
+            }
         }
         if (k1 < d && e1 >= hi_th) return k1;
     }
     const uint32_t nwords_all = ((d < SEG ? d : SEG) + 31) >> 5;
     for (uint32_t w = lane; w < nwords_all; w += WAVE) mask[w] = 0;
     wave_lds_fence();
-
-    const VertexCtx &vs = scatter ? vc : vp;                    // the searched row: cur (scatter) or prev
-    const uint32_t nw_mask = filter_mask_for_degree(vs.d);
-    const gptr<uint64_t> fb = as_global<uint64_t>(p_fbits) + vs.f0;
-    const uint32_t tmask = scatter ? ctmask : index_mask_for_degree(dp);
-    const gptr<uint64_t> tab = as_global<uint64_t>(p_slots) + 2ull * vs.tb;
 
     PROF_TICK(pf, 1);
     // Rows longer than the LDS mask (SEG positions) are served through a sliding window [wb, wb + SEG):
