@@ -221,7 +221,7 @@ def main():
         if tj and world == 1 and not args.weighted:
             traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
             traffic_note = ("FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch "
-                            "(profiles/r01_rmat22_pmc_v12.txt), uncorrected (scattered 4-8 B/lane probes)")
+                            "(profiles/r01_rmat22_pmc_v13.txt), uncorrected (scattered 4-8 B/lane probes)")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
