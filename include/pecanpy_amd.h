@@ -79,6 +79,8 @@ int pw_device_count(void);
  * Besides the three arrays the handle owns the membership index built here on the device (per-row
  * Bloom filters, adjacency hash index, key stream, vertex records and -- for unit-weight graphs without
  * self loops -- per-edge records with common-neighbour counts): about 55 bytes per CSR entry in total.
+ * Limits: the 32-bit offsets of the index allow about 2^33 hash slots, i.e. graphs up to ~2 * 10^9 CSR
+ * entries (PW_ERR_INVALID "graph too large" beyond that; the reference's own limit is nnz < 2^32).
  * Environment: PECANPY_AMD_NO_LAZY=1 skips the per-edge records (every step then takes the eager path;
  * used by the test-suite to cross-check the two step implementations). */
 int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
