@@ -1317,7 +1317,7 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
 // UNIT: every edge weight is 1.0 (closed-form chain); EXTEND: node2vec+ (weighted graphs only --
 // on unit weights node2vec+ degenerates to node2vec bit for bit, so the host routes it to UNIT).
 template <typename T, bool DENSE, bool UNIT, bool EXTEND>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, (EXTEND && !DENSE) ? PW_MIN_WAVES - 1 : PW_MIN_WAVES)
 walk_kernel(WalkArgs a) {
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
     __shared__ uint16_t s_rank[UNIT ? WAVES_PER_BLOCK : 1][UNIT ? MASK_WORDS + 2 : 2];
