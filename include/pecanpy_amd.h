@@ -172,6 +172,15 @@ int pw_selftest_seqscan_f32(const float *x, uint32_t n, double r, int use_target
 int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_target, uint32_t chunk,
                             uint32_t *index, double *sum);
 
+/* Exact-arithmetic decision of the float32 CDF search used by the unit-weight walk step (csrc/seqscan.h:
+ * exact_thresholds_f32), on a host row: cls[k] = 0 (other neighbour, weight w_out), 1 (common neighbour,
+ * weight 1) or 2 (prev, weight w_prev); w_out, w_prev powers of two.  For every r[i]: chain[i] = what the
+ * reference's np.searchsorted(np.cumsum(w / w.sum()), r) returns under sequential float32 semantics
+ * (pecanpy.py:556-557; n if never reached), exact[i] = the index decided in integer arithmetic, or
+ * 0xffffffff when a partial sum lies inside the drift bound (the kernel then runs the float chain). */
+int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                               uint32_t n_r, uint32_t *chain, uint32_t *exact);
+
 #ifdef __cplusplus
 }
 #endif

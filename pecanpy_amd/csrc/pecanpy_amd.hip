@@ -10,6 +10,7 @@
 
 #include <new>
 #include <random>
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -906,6 +907,48 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
 PW_EXPORT int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out) {
     if (n && !out) return fail(PW_ERR_INVALID, "null pointer");
     pw::mt_random_sample_host(seed, offset, n, out);
+    return PW_OK;
+}
+
+// ---- host self test of the exact-arithmetic decision ---------------------------------------------------
+PW_EXPORT int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                                         uint32_t n_r, uint32_t *chain, uint32_t *exact) {
+    if (!cls || !r || !chain || !exact || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
+    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    uint32_t cnt[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < n; k++) {
+        if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
+        cnt[cls[k]]++;
+    }
+    if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
+    // same set-up as sample_step_unit_lazy (walk_sparse.hip.h)
+    float u = 1.0f;
+    if (cnt[0] && w_out < u) u = w_out;
+    if (cnt[2] && w_prev < u) u = w_prev;
+    const double td = (double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev;
+    if (!(td <= 16777216.0 * (double)u)) return fail(PW_ERR_UNSUPPORTED, "row total not exact in float32");
+    const float tot = (float)td;
+    const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
+    const double units = td / (double)u;
+    const uint32_t w_units[3] = {cnt[0] ? (uint32_t)(w_out / u) : 1u, (uint32_t)(1.0f / u), cnt[2] ? (uint32_t)(w_prev / u) : 1u};
+    const uint32_t wmax = std::max(w_units[0], std::max(w_units[1], w_units[2]));
+    std::vector<uint32_t> E(n);
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < n; k++) { acc += w_units[cls[k]]; E[k] = acc; }
+    for (uint32_t i = 0; i < n_r; i++) {
+        // the reference: np.searchsorted(np.cumsum(float32 values), r), sequential float32 additions
+        float c = 0.0f;
+        uint32_t kc = n;
+        for (uint32_t k = 0; k < n; k++) {
+            c = c + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
+            if ((double)c >= r[i]) { kc = k; break; }
+        }
+        chain[i] = kc;
+        const pw::ExactThresholds th = pw::exact_thresholds_f32(r[i] * units, n, wmax);
+        const uint32_t k1 = (uint32_t)(std::lower_bound(E.begin(), E.end(), th.lo) - E.begin());
+        exact[i] = (k1 < n && E[k1] >= th.hi) ? k1 : 0xffffffffu;
+    }
     return PW_OK;
 }
 

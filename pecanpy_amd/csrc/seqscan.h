@@ -17,6 +17,7 @@
 //
 // Everything here is plain integer code usable on host (tests / CPU emulation) and device.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -162,6 +163,33 @@ template <> PW_HD uint64_t Binade<double>::threshold(double r, int eb) {
     if (k > 0 || !(scaled < 9007199254740992.0)) return TOP;
     uint64_t t = (uint64_t)scaled;
     if ((double)t < scaled) t++;
+    return t;
+}
+
+
+// ---- exact-arithmetic decision of a float32 CDF search (unit-weight rows, dyadic biases) -------------
+// Setting: every element of a row weighs a whole number of units (>= 1), E(k) = exact mass of elements
+// 0..k, `units` = exact total, so the exact CDF is E(k) / units; the reference adds the float32 values
+// x = fl(weight / tot) one by one (np.cumsum) and returns the first k with c_k >= r (np.searchsorted).
+// As long as the earlier sums are below r the float chain obeys
+//     |c_j - E(j) / units| <= (sum_{i<=j} E(i) + E(j)) * 2^-24 / units
+//                          <= ((j + 1) (R + wmax) - j (j + 1) / 2 + R + wmax) * 2^-24 / units =: zr / units
+// with R = r * units (one relative rounding 2^-24 per addition, applied to the partial sum being rounded;
+// E(i) <= E(j) - (j - i); 2^-24 relative on the three values).  With lo = ceil(R - zr), hi = ceil(R + zr):
+// every j below the first k1 with E(k1) >= lo has c_j < r (induction), and E(k1) >= hi gives
+// c_k1 >= r -- then k1 is the reference's answer.  `prefix` bounds j + 1 from above (length of the
+// classified prefix or the row); E(k) >= k + 1 bounds it by R + 2 as well.
+struct ExactThresholds {
+    uint32_t lo, hi;
+};
+PW_HD ExactThresholds exact_thresholds_f32(double R, uint32_t prefix, uint32_t wmax_units) {
+    const double wmax = (double)wmax_units + 2.0;
+    const double jb = (double)prefix < R + 2.0 ? (double)prefix : R + 2.0;
+    const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;
+    const double lo = ceil(R - zr);
+    ExactThresholds t;
+    t.lo = lo > 0.0 ? (uint32_t)lo : 0u;
+    t.hi = (uint32_t)ceil(R + zr);
     return t;
 }
 

@@ -1075,13 +1075,8 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         // 64-key chunk (two fifths of the steps): the common neighbours are then at most 64 known
         // positions P_0 < P_1 < ..., one per lane, and between them the row consists of "out" runs, so the
         // first position whose exact mass reaches the target follows from a ballot and scalar arithmetic.
-        const double R = r * units;
-        const double wmax = (double)(1u << max_u32(sh_in, max_u32(sh_out, sh_prev))) + 2.0;   // heaviest element, in units
-        const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
-        const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;   // drift bound, see below
-        const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
-        const double lo = R - zr;
-        const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
+        const ExactThresholds th = exact_thresholds_f32(r * units, d, 1u << max_u32(sh_in, max_u32(sh_out, sh_prev)));
+        const uint32_t lo_th = uni(th.lo), hi_th = uni(th.hi);   // drift bound: seqscan.h
         const uint32_t wp = 1u << sh_prev;
         const uint32_t pp = n_pv ? prev_pos : NOT_FOUND;
         uint32_t k1, e1;
@@ -1189,23 +1184,11 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
         PROF_COUNT(pf, 9, 1);
         const UnitRow ur{mask, rank, wb, known_end - wb, prev_pos, true};
         if (exact_ok && k == 0 && wb == 0) {
-            // Decide in exact arithmetic when no partial sum lies next to the target.  With R = r * units
-            // (real) and c_i < r for i < j, the float chain obeys
-            //     |c_j - E(j) / units| <= (sum_{i<=j} E(i) + E(j)) * 2^-24 / units
-            //                          <= ((j + 1) * (R + wmax) - j (j + 1) / 2 + R + wmax) * 2^-24 / units =: zr / units
-            // (one relative rounding 2^-24 per addition, applied to the partial sum being rounded, plus
-            // 2^-24 relative on the three values; every element weighs at least one unit).  Hence every j below the first k1 with E(k1) >= ceil(R - zr) has c_j < r
-            // (induction on j), and E(k1) >= ceil(R + zr) gives c_k1 >= r: k1 is the chain's answer.
-            const double R = r * units;
-            const double wmax = (double)(1u << max_u32(sh_in, max_u32(sh_out, sh_prev))) + 2.0;   // heaviest element, in units
-            // every element weighs at least one unit, so E(k) >= k + 1 and k1 < R: j + 1 <= min(known_end, R + 1)
-            const double jb = (double)known_end < R + 2.0 ? (double)known_end : R + 2.0;
-            // and E(i) <= E(j) - (j - i): the sum of the partial sums is at most (j+1) E(j) - j (j+1) / 2
-            const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;
-            const uint32_t hi_th = uni((uint32_t)ceil(R + zr));
+            // Decide in exact arithmetic when no partial sum lies within the float32 drift bound of the
+            // target (argument and bound: seqscan.h, exact_thresholds_f32).
+            const ExactThresholds th = exact_thresholds_f32(r * units, known_end, 1u << max_u32(sh_in, max_u32(sh_out, sh_prev)));
+            const uint32_t lo_th = uni(th.lo), hi_th = uni(th.hi);
             if (est >= hi_th) {
-                const double lo = R - zr;
-                const uint32_t lo_th = lo > 0.0 ? uni((uint32_t)ceil(lo)) : 0u;
                 uint32_t e_at = 0;
                 const uint32_t k1 = unit_search_units(ur, known_end, lo_th, sh_in, sh_out, sh_prev, e_at);
                 PROF_TICK(pf, 7);

@@ -1,0 +1,90 @@
+"""The mathematical claim behind the lazy walk step, tested on the host without a GPU: whenever the
+exact-arithmetic decision (csrc/seqscan.h: exact_thresholds_f32, the very function the kernel calls)
+declares a CDF search decided, its index equals what the reference's sequential float32
+cumsum + searchsorted returns.  Targets are random and adversarial (exactly on / one ulp around the
+float32 partial sums and the exact rational partial sums)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pecanpy_amd import _lib
+
+AMBIGUOUS = 0xFFFFFFFF
+
+
+def decide(cls, w_out, w_prev, r):
+    lib = _lib.load()
+    cls = np.ascontiguousarray(cls, dtype=np.uint8)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    chain = np.empty(r.size, dtype=np.uint32)
+    exact = np.empty(r.size, dtype=np.uint32)
+    _lib.check(lib.pw_selftest_exact_decision(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
+                                              r.ctypes.data_as(C.c_void_p), r.size,
+                                              chain.ctypes.data_as(C.c_void_p), exact.ctypes.data_as(C.c_void_p)))
+    return chain, exact
+
+
+def float32_prefix(cls, w_out, w_prev):
+    """float32 partial sums of the reference (sequential) and the exact rational ones."""
+    w = np.where(cls == 1, 1.0, np.where(cls == 0, w_out, w_prev))
+    tot = np.float32(w.sum())                      # exact by construction (dyadic, small)
+    x = (w.astype(np.float32) / tot).astype(np.float32)
+    c = np.zeros(cls.size, dtype=np.float32)
+    acc = np.float32(0)
+    for k, v in enumerate(x):
+        acc = np.float32(acc + v)
+        c[k] = acc
+    return c, np.cumsum(w) / w.sum()
+
+
+def random_row(rng, n, p_common, with_prev):
+    cls = (rng.random(n) < p_common).astype(np.uint8)
+    if with_prev:
+        cls[rng.integers(0, n)] = 2
+    return cls
+
+
+BIASES = [(0.5, 2.0), (2.0, 0.5), (0.25, 4.0), (1.0, 1.0), (4.0, 0.125), (0.0625, 16.0), (8.0, 1.0)]
+
+
+@pytest.mark.parametrize("w_out,w_prev", BIASES)
+def test_decided_cases_agree_with_the_float32_chain(w_out, w_prev):
+    rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024))
+    decided = total = 0
+    for n in (1, 2, 3, 7, 40, 64, 65, 300, 1500, 6000):
+        for p_common in (0.0, 0.05, 0.4, 1.0):
+            cls = random_row(rng, n, p_common, with_prev=bool(rng.integers(0, 2)))
+            c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
+            cd = c32.astype(np.float64)
+            targets = [rng.random(400), cd, np.nextafter(cd, 0.0), np.nextafter(cd, 2.0),
+                       exact_cdf, np.nextafter(exact_cdf, 0.0), np.nextafter(exact_cdf, 2.0),
+                       exact_cdf * (1 - 2.0 ** -24), exact_cdf * (1 + 2.0 ** -24), np.array([0.0, 1e-300, 1 - 2.0 ** -53])]
+            r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
+            chain, exact = decide(cls, w_out, w_prev, r)
+            # the hook's chain is the reference semantics: cross-check it with NumPy once per row
+            want = np.searchsorted(cd, r, side="left")
+            assert np.array_equal(chain, want.astype(np.uint32))
+            ok = exact != AMBIGUOUS
+            assert np.array_equal(exact[ok], chain[ok]), (n, p_common, w_out, w_prev)
+            decided += int(ok[:400].sum())
+            total += 400
+    assert decided / total > 0.5          # the shortcut is not vacuous on uniform targets
+
+
+def test_short_rows_are_almost_always_decided():
+    rng = np.random.default_rng(5)
+    cls = random_row(rng, 200, 0.1, True)
+    chain, exact = decide(cls, 0.5, 2.0, rng.random(20000))
+    ok = exact != AMBIGUOUS
+    assert ok.mean() > 0.98 and np.array_equal(exact[ok], chain[ok])
+
+
+def test_rejects_non_dyadic_biases():
+    lib = _lib.load()
+    cls = np.zeros(4, dtype=np.uint8)
+    r = np.array([0.5])
+    out = np.empty(1, dtype=np.uint32)
+    rc = lib.pw_selftest_exact_decision(cls.ctypes.data_as(C.c_void_p), 4, 0.3, 2.0, r.ctypes.data_as(C.c_void_p), 1,
+                                        out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc != 0
