@@ -180,6 +180,9 @@ int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_targe
  * 0xffffffff when a partial sum lies inside the drift bound (the kernel then runs the float chain). */
 int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                uint32_t n_r, uint32_t *chain, uint32_t *exact);
+/* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
+int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
+                                   uint32_t n_r, uint32_t *chain, uint32_t *exact);
 
 #ifdef __cplusplus
 }

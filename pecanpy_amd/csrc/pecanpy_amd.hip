@@ -952,6 +952,45 @@ PW_EXPORT int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w
     return PW_OK;
 }
 
+PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev,
+                                             const double *r, uint32_t n_r, uint32_t *chain, uint32_t *exact) {
+    if (!cls || !r || !chain || !exact || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    auto pow2 = [](double w) { int e = 0; return std::frexp(w, &e) == 0.5; };
+    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    uint64_t cnt[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < n; k++) {
+        if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
+        cnt[cls[k]]++;
+    }
+    if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
+    // same set-up as walk_dense_bits_kernel (walk_dense.hip.h)
+    double u = 1.0;
+    if (cnt[0] && w_out < u) u = w_out;
+    if (cnt[2] && w_prev < u) u = w_prev;
+    const double tot = (double)cnt[1] + (double)cnt[0] * w_out + (double)cnt[2] * w_prev;
+    const double S = tot / u, wi = 1.0 / u, wo = w_out / u, wp = w_prev / u;
+    const double wmax = std::max(wi, std::max(wo, wp));
+    if (!(S <= 1099511627776.0 && wmax + 2.0 <= 1048576.0)) return fail(PW_ERR_UNSUPPORTED, "row outside the exact range");
+    const double x[3] = {w_out / tot, 1.0 / tot, w_prev / tot};
+    const uint64_t w_units[3] = {(uint64_t)wo, (uint64_t)wi, (uint64_t)wp};
+    std::vector<uint64_t> E(n);
+    uint64_t acc = 0;
+    for (uint32_t k = 0; k < n; k++) { acc += w_units[cls[k]]; E[k] = acc; }
+    for (uint32_t i = 0; i < n_r; i++) {
+        double c = 0.0;
+        uint32_t kc = n;
+        for (uint32_t k = 0; k < n; k++) {
+            c = c + x[cls[k]];
+            if (c >= r[i]) { kc = k; break; }
+        }
+        chain[i] = kc;
+        const pw::ExactThresholds64 th = pw::exact_thresholds_f64(r[i] * S, (double)n, wmax);
+        const uint32_t k1 = (uint32_t)(std::lower_bound(E.begin(), E.end(), th.lo) - E.begin());
+        exact[i] = (k1 < n && E[k1] >= th.hi) ? k1 : 0xffffffffu;
+    }
+    return PW_OK;
+}
+
 // ---- edge-list ingestion (host only) ----------------------------------------------------------------
 struct pw_edgelist {
     pw::EdgeList el;

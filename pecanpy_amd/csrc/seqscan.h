@@ -193,4 +193,20 @@ PW_HD ExactThresholds exact_thresholds_f32(double R, uint32_t prefix, uint32_t w
     return t;
 }
 
+// float64 flavour (DenseOTF): the same bound with 2^-53; R = r * units itself is rounded (2^-52 relative).
+struct ExactThresholds64 {
+    uint64_t lo, hi;
+};
+PW_HD ExactThresholds64 exact_thresholds_f64(double R, double prefix, double wmax_units) {
+    const double wmax = wmax_units + 2.0;
+    const double jb = prefix < R + 2.0 ? prefix : R + 2.0;
+    const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 9007199254740992.0) +
+                      R * (1.0 / 4503599627370496.0) + 1e-9;
+    const double lo = ceil(R - zr);
+    ExactThresholds64 t;
+    t.lo = lo > 0.0 ? (uint64_t)lo : 0ull;
+    t.hi = (uint64_t)ceil(R + zr);
+    return t;
+}
+
 }  // namespace pw

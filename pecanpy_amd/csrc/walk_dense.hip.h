@@ -336,12 +336,8 @@ walk_dense_bits_kernel(DenseArgs a) {
                     const double S = tot / u, wi = 1.0 / u, wo = w_out / u, wp = w_prevp / u;   // exact: powers of two
                     const double wmax = fmax(wi, fmax(wo, wp)) + 2.0;
                     if (S <= 1099511627776.0 && wmax <= 1048576.0) {
-                        const double R = r * S;
-                        const double jb = (double)d < R + 2.0 ? (double)d : R + 2.0;
-                        const double zr = ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 9007199254740992.0)
-                                          + R * (1.0 / 4503599627370496.0) + 1e-9;
-                        const double lo_d = ceil(R - zr), hi_d = ceil(R + zr);
-                        const uint64_t lo_th = lo_d > 0.0 ? (uint64_t)lo_d : 0ull, hi_th = (uint64_t)hi_d;
+                        const ExactThresholds64 th = exact_thresholds_f64(r * S, (double)d, wmax - 2.0);   // seqscan.h
+                        const uint64_t lo_th = th.lo, hi_th = th.hi;
                         const uint64_t Wi = (uint64_t)wi, Wo = (uint64_t)wo, Wp = (uint64_t)wp;
                         const uint32_t pseg = prev_col != NOT_FOUND ? prev_col / DSEG : NOT_FOUND;
                         // segment holding the first column with E >= lo_th

@@ -88,3 +88,37 @@ def test_rejects_non_dyadic_biases():
     rc = lib.pw_selftest_exact_decision(cls.ctypes.data_as(C.c_void_p), 4, 0.3, 2.0, r.ctypes.data_as(C.c_void_p), 1,
                                         out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc != 0
+
+
+def decide64(cls, w_out, w_prev, r):
+    lib = _lib.load()
+    cls = np.ascontiguousarray(cls, dtype=np.uint8)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    chain = np.empty(r.size, dtype=np.uint32)
+    exact = np.empty(r.size, dtype=np.uint32)
+    _lib.check(lib.pw_selftest_exact_decision_f64(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
+                                                  r.ctypes.data_as(C.c_void_p), r.size,
+                                                  chain.ctypes.data_as(C.c_void_p), exact.ctypes.data_as(C.c_void_p)))
+    return chain, exact
+
+
+@pytest.mark.parametrize("w_out,w_prev", BIASES)
+def test_float64_flavour_of_the_dense_kernel(w_out, w_prev):
+    rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 7)
+    for n in (1, 3, 64, 1000, 30000):
+        cls = random_row(rng, n, 0.25, True)
+        w = np.where(cls == 1, 1.0, np.where(cls == 0, w_out, w_prev))
+        tot = w.sum()
+        c64 = np.empty(n)
+        acc = 0.0
+        for k, v in enumerate(w / tot):          # sequential float64, like Numba's cumsum
+            acc = acc + v
+            c64[k] = acc
+        exact_cdf = np.cumsum(w) / tot
+        r = np.clip(np.concatenate([rng.random(300), c64, np.nextafter(c64, 0.0), np.nextafter(c64, 2.0), exact_cdf,
+                                    np.nextafter(exact_cdf, 0.0), np.nextafter(exact_cdf, 2.0)]), 0.0, np.nextafter(1.0, 0.0))
+        chain, exact = decide64(cls, w_out, w_prev, r)
+        assert np.array_equal(chain, np.searchsorted(c64, r, side="left").astype(np.uint32))
+        ok = exact != AMBIGUOUS
+        assert np.array_equal(exact[ok], chain[ok]), (n, w_out, w_prev)
+        assert ok[:300].mean() > 0.99             # float64 drift is far below one unit: practically always decided
