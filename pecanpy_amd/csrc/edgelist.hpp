@@ -21,7 +21,6 @@
 
 #include <algorithm>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 namespace pw {
@@ -89,13 +88,42 @@ inline bool parse_weight(Sv t, double &w) {
     return end == buf + t.n;
 }
 
-struct Ins {
-    uint64_t key;   // src << 32 | dst
-    uint64_t seq;   // insertion order
-    double w;
-};
-
 }  // namespace el_detail
+
+// open-addressing id table: slot = index into `ids` + 1 (0 = empty); hashes kept beside the views
+struct IdTable {
+    std::vector<el_detail::Sv> ids;
+    std::vector<uint64_t> hashes;
+    std::vector<uint32_t> slots;
+    uint64_t mask = 0;
+    IdTable() { slots.assign(1u << 16, 0u); mask = slots.size() - 1; }
+    void grow() {
+        std::vector<uint32_t> bigger(slots.size() * 2, 0u);
+        const uint64_t m = bigger.size() - 1;
+        for (uint32_t i = 0; i < ids.size(); i++) {
+            uint64_t p = hashes[i] & m;
+            while (bigger[p]) p = (p + 1) & m;
+            bigger[p] = i + 1;
+        }
+        slots.swap(bigger);
+        mask = m;
+    }
+    uint32_t get(el_detail::Sv id) {
+        const uint64_t h = el_detail::SvHash()(id);
+        uint64_t p = h & mask;
+        while (slots[p]) {
+            const uint32_t i = slots[p] - 1;
+            if (hashes[i] == h && ids[i] == id) return i;
+            p = (p + 1) & mask;
+        }
+        const uint32_t idx = (uint32_t)ids.size();
+        ids.push_back(id);
+        hashes.push_back(h);
+        slots[p] = idx + 1;
+        if (ids.size() * 2 > slots.size()) grow();
+        return idx;
+    }
+};
 
 inline int read_edgelist(const char *path, bool weighted, bool directed, const char *delimiter, EdgeList &out) {
     using namespace el_detail;
@@ -103,11 +131,17 @@ inline int read_edgelist(const char *path, bool weighted, bool directed, const c
     if (dl == 0) return EL_NEEDS_SLOW_READER;   // str.split("") raises in Python
     for (size_t i = 0; i < dl; i++)
         if ((unsigned char)delimiter[i] >= 0x80 || delimiter[i] == '\n' || delimiter[i] == '\r') return EL_NEEDS_SLOW_READER;
+    const char d0 = delimiter[0];
 
     FILE *f = fopen(path, "rb");
     if (!f) return EL_IO_ERROR;
     std::string buf;
     {
+        if (fseek(f, 0, SEEK_END) == 0) {
+            const long sz = ftell(f);
+            if (sz > 0) buf.reserve((size_t)sz + 1);
+            rewind(f);
+        }
         char chunk[1 << 16];
         size_t got;
         while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) buf.append(chunk, got);
@@ -115,32 +149,28 @@ inline int read_edgelist(const char *path, bool weighted, bool directed, const c
         fclose(f);
         if (bad) return EL_IO_ERROR;
     }
-    // bytes whose treatment differs between this reader and Python's text layer / str.strip()
-    for (size_t i = 0; i < buf.size(); i++) {
-        const unsigned char c = (unsigned char)buf[i];
-        if (c >= 0x80 || (c < 0x20 && c != '\t' && c != '\n' && c != '\r')) return EL_NEEDS_SLOW_READER;
-        if (c == '\r' && (i + 1 >= buf.size() || buf[i + 1] != '\n')) return EL_NEEDS_SLOW_READER;   // lone CR = newline
-    }
 
-    std::unordered_map<Sv, uint32_t, SvHash> idmap;
-    std::vector<Sv> ids;
-    std::vector<Ins> ins;
-    auto vertex = [&](Sv id) -> uint32_t {
-        auto it = idmap.find(id);
-        if (it != idmap.end()) return it->second;
-        const uint32_t idx = (uint32_t)ids.size();
-        idmap.emplace(id, idx);
-        ids.push_back(id);
-        return idx;
-    };
+    IdTable table;
+    struct Raw { uint32_t u, v; double w; };
+    std::vector<Raw> raw;          // one entry per line, file order
+    raw.reserve(buf.size() / 8 + 16);
+    Sv last1{nullptr, 0}, last2{nullptr, 0};
+    uint32_t last_u = 0, last_v = 0;
 
-    uint64_t seq = 0;
     size_t pos = 0;
     const size_t end = buf.size();
+    const char *base = buf.data();
     while (pos < end) {
+        // one pass over the line: find its end and reject the bytes whose treatment differs between this
+        // reader and Python's text layer / str.strip()
         size_t nl = pos;
-        while (nl < end && buf[nl] != '\n') nl++;
-        Sv line = strip(Sv{buf.data() + pos, nl - pos});
+        for (; nl < end; nl++) {
+            const unsigned char c = (unsigned char)base[nl];
+            if (c == '\n') break;
+            if (c >= 0x80 || (c < 0x20 && c != '\t' && c != '\r')) return EL_NEEDS_SLOW_READER;
+            if (c == '\r' && (nl + 1 >= end || base[nl + 1] != '\n')) return EL_NEEDS_SLOW_READER;   // lone CR = newline
+        }
+        Sv line = strip(Sv{base + pos, nl - pos});
         pos = nl + 1;
         // split(delimiter) of the stripped line
         Sv terms[3];
@@ -149,10 +179,8 @@ inline int read_edgelist(const char *path, bool weighted, bool directed, const c
         for (;;) {
             size_t b = a;
             bool found = false;
-            while (b + dl <= line.n) {
-                if (memcmp(line.p + b, delimiter, dl) == 0) { found = true; break; }
-                b++;
-            }
+            for (; b + dl <= line.n; b++)
+                if (line.p[b] == d0 && (dl == 1 || memcmp(line.p + b, delimiter, dl) == 0)) { found = true; break; }
             if (!found) b = line.n;
             if (n_terms < 3) terms[n_terms] = Sv{line.p + a, b - a};
             n_terms++;
@@ -167,44 +195,69 @@ inline int read_edgelist(const char *path, bool weighted, bool directed, const c
             if (!(w > 0.0)) return EL_NEEDS_SLOW_READER;           // "Non-positive edge ignored" warning
         }
         const Sv id1 = strip(terms[0]), id2 = strip(terms[1]);
-        if (ids.size() + 2 >= 0xffffffffull) return EL_NEEDS_SLOW_READER;
-        const uint32_t u = vertex(id1);
-        const uint32_t v = vertex(id2);
-        ins.push_back(Ins{((uint64_t)u << 32) | v, seq++, w});
-        if (!directed) ins.push_back(Ins{((uint64_t)v << 32) | u, seq++, w});
+        if (table.ids.size() + 2 >= 0xffffffffull) return EL_NEEDS_SLOW_READER;
+        // edge lists are usually grouped by source: remember the previous line's ids
+        const uint32_t u = (last1.p && last1 == id1) ? last_u : table.get(id1);
+        const uint32_t v = (last2.p && last2 == id2) ? last_v : ((id2 == id1) ? u : table.get(id2));
+        last1 = id1; last_u = u;
+        last2 = id2; last_v = v;
+        raw.push_back(Raw{u, v, w});
     }
 
-    std::sort(ins.begin(), ins.end(), [](const Ins &x, const Ins &y) {
-        return x.key != y.key ? x.key < y.key : x.seq < y.seq;
-    });
-    const size_t n = ids.size();
+    // bucket the insertions by source vertex, in insertion order (counting sort = stable)
+    const size_t n = table.ids.size();
+    const uint64_t n_ins = (uint64_t)raw.size() * (directed ? 1u : 2u);
+    if (n_ins >= 0xffffffffull) return EL_NEEDS_SLOW_READER;
+    std::vector<uint64_t> start(n + 1, 0);
+    for (const Raw &e : raw) {
+        start[e.u + 1]++;
+        if (!directed) start[e.v + 1]++;
+    }
+    for (size_t i = 0; i < n; i++) start[i + 1] += start[i];
+    struct Half { uint32_t dst; uint32_t seq; double w; };   // seq < 2^32 checked above
+    std::vector<Half> half(n_ins);
+    {
+        std::vector<uint64_t> fill(start.begin(), start.end() - 1);
+        uint32_t seq = 0;
+        for (const Raw &e : raw) {
+            half[fill[e.u]++] = Half{e.v, seq++, e.w};
+            if (!directed) half[fill[e.v]++] = Half{e.u, seq++, e.w};
+        }
+    }
+    std::vector<Raw>().swap(raw);
+
     out.indptr.assign(n + 1, 0);
     out.indices.clear();
     out.data.clear();
     out.data64.clear();
-    out.indices.reserve(ins.size());
-    out.data.reserve(ins.size());
-    out.data64.reserve(ins.size());
-    for (size_t i = 0; i < ins.size();) {
-        size_t j = i;
-        while (j + 1 < ins.size() && ins[j + 1].key == ins[i].key) {
-            j++;
-            // an edge given twice with different weights triggers the reference's overwrite warning
-            if (ins[j].w != ins[i].w) return EL_NEEDS_SLOW_READER;
+    out.indices.reserve(n_ins);
+    out.data.reserve(n_ins);
+    out.data64.reserve(n_ins);
+    for (size_t r = 0; r < n; r++) {
+        Half *b = half.data() + start[r], *e = half.data() + start[r + 1];
+        bool sorted = true;
+        for (Half *p = b; p + 1 < e; p++)
+            if (p[1].dst <= p[0].dst) { sorted = false; break; }
+        if (!sorted) std::sort(b, e, [](const Half &x, const Half &y) { return x.dst != y.dst ? x.dst < y.dst : x.seq < y.seq; });
+        for (Half *p = b; p < e;) {
+            Half *q = p;
+            while (q + 1 < e && q[1].dst == p->dst) {
+                q++;
+                // an edge given twice with different weights triggers the reference's overwrite warning
+                if (q->w != p->w) return EL_NEEDS_SLOW_READER;
+            }
+            out.indices.push_back(q->dst);        // the last insertion wins
+            out.data.push_back((float)q->w);
+            out.data64.push_back(q->w);
+            p = q + 1;
         }
-        out.indices.push_back((uint32_t)ins[j].key);
-        out.data.push_back((float)ins[j].w);
-        out.data64.push_back(ins[j].w);
-        out.indptr[(size_t)(ins[i].key >> 32) + 1]++;
-        i = j + 1;
+        out.indptr[r + 1] = (uint32_t)out.indices.size();
     }
-    if (out.indices.size() >= 0xffffffffull) return EL_NEEDS_SLOW_READER;
-    for (size_t i = 0; i < n; i++) out.indptr[i + 1] += out.indptr[i];
-    out.insertions = seq;
+    out.insertions = n_ins;
     out.id_off.assign(n + 1, 0);
     out.id_chars.clear();
     for (size_t i = 0; i < n; i++) {
-        out.id_chars.append(ids[i].p, ids[i].n);
+        out.id_chars.append(table.ids[i].p, table.ids[i].n);
         out.id_off[i + 1] = out.id_chars.size();
     }
     return EL_OK;
