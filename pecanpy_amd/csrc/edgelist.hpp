@@ -90,17 +90,23 @@ inline bool parse_weight(Sv t, double &w) {
 
 }  // namespace el_detail
 
-// open-addressing id table: slot = index into `ids` + 1 (0 = empty); hashes kept beside the views
+// Vertex ids -> indices in order of first appearance.  Canonical decimal ids ("0", "17", no sign, no leading
+// zero, below 2^26) -- what most edge lists contain -- go through a direct value table; everything else
+// through an open-addressing hash table (slot = entry + 1, 0 = empty).  Two ids are equal iff their strings
+// are equal, and a canonical decimal string is determined by its value, so the two tables never overlap.
 struct IdTable {
-    std::vector<el_detail::Sv> ids;
-    std::vector<uint64_t> hashes;
+    std::vector<el_detail::Sv> ids;          // all ids, first-appearance order
+    std::vector<uint32_t> by_value;          // canonical decimal value -> index + 1
+    std::vector<uint64_t> hashes;            // hashed entries: hash, index into `ids`
+    std::vector<uint32_t> entry_id;
     std::vector<uint32_t> slots;
     uint64_t mask = 0;
-    IdTable() { slots.assign(1u << 16, 0u); mask = slots.size() - 1; }
+    static constexpr uint32_t VALUE_CAP = 1u << 26;
+    IdTable() { slots.assign(1u << 12, 0u); mask = slots.size() - 1; }
     void grow() {
         std::vector<uint32_t> bigger(slots.size() * 2, 0u);
         const uint64_t m = bigger.size() - 1;
-        for (uint32_t i = 0; i < ids.size(); i++) {
+        for (uint32_t i = 0; i < hashes.size(); i++) {
             uint64_t p = hashes[i] & m;
             while (bigger[p]) p = (p + 1) & m;
             bigger[p] = i + 1;
@@ -108,19 +114,37 @@ struct IdTable {
         slots.swap(bigger);
         mask = m;
     }
+    uint32_t add(el_detail::Sv id) {
+        ids.push_back(id);
+        return (uint32_t)ids.size() - 1;
+    }
     uint32_t get(el_detail::Sv id) {
+        if (id.n >= 1 && id.n <= 8 && (id.n == 1 || id.p[0] != '0')) {
+            uint32_t v = 0;
+            size_t i = 0;
+            for (; i < id.n; i++) {
+                const unsigned c = (unsigned)id.p[i] - '0';
+                if (c > 9) break;
+                v = v * 10 + c;
+            }
+            if (i == id.n && v < VALUE_CAP) {
+                if (v >= by_value.size()) by_value.resize(std::max<size_t>((size_t)v + 1, by_value.size() * 2), 0u);
+                if (by_value[v] == 0) by_value[v] = add(id) + 1;
+                return by_value[v] - 1;
+            }
+        }
         const uint64_t h = el_detail::SvHash()(id);
         uint64_t p = h & mask;
         while (slots[p]) {
-            const uint32_t i = slots[p] - 1;
-            if (hashes[i] == h && ids[i] == id) return i;
+            const uint32_t e = slots[p] - 1;
+            if (hashes[e] == h && ids[entry_id[e]] == id) return entry_id[e];
             p = (p + 1) & mask;
         }
-        const uint32_t idx = (uint32_t)ids.size();
-        ids.push_back(id);
+        const uint32_t idx = add(id);
         hashes.push_back(h);
-        slots[p] = idx + 1;
-        if (ids.size() * 2 > slots.size()) grow();
+        entry_id.push_back(idx);
+        slots[p] = (uint32_t)hashes.size();
+        if (hashes.size() * 2 > slots.size()) grow();
         return idx;
     }
 };

@@ -46,6 +46,11 @@ def cases():
     add("comma_delimiter", "a,b,1.5\nb,c,2.5\n", True, False, ",")
     add("multichar_delimiter", "a::b::1.5\nb::c::2.5\n", True, True, "::")
     add("space_delimiter", "a b\nb c\n", False, False, " ")
+    # numeric-looking ids are strings: "7", "07", "+7", "7.0" are four different vertices
+    add("numeric_id_spellings", "7\t07\n07\t+7\n+7\t7.0\n7.0\t7\n0\t00\n99999999\t100000000\n"
+                                "67108863\t67108864\n123456789012\t7\n-1\t0\n", False, False)
+    add("numeric_ids_out_of_order", "".join(f"{a}\t{b}\n" for a, b in [(5, 3), (3, 9), (9, 5), (0, 5), (12, 0), (3, 5)]),
+        False, True)
     add("wrong_columns_weighted", "a\tb\n", True, False)
     add("blank_line", "a\tb\n\nb\tc\n", False, False)
     add("single_column", "abc\n", False, False)
