@@ -143,6 +143,14 @@ int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
 /* doubles #offset.. of RandomState(seed).random_sample, produced with MT19937 jump-ahead. */
 int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out);
 
+/* ---- node2vec+ noisy-edge thresholds (host side; usable without a GPU) --------------------- */
+/* thr[i] = max(mean(row i) + gamma * std(row i), 0) exactly as the reference's NumPy expression evaluates it
+ * (rw/sparse_rw.py:22-35 on float32 CSR rows; rw/dense_rw.py:11-19 on the non-zero entries of float64 rows):
+ * NumPy's pairwise summation, every step in the array's precision.  Rows without entries give NaN, as there.
+ * The result is what pw_graph_set_thresholds() expects. */
+int pw_noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr);
+int pw_noise_thresholds_dense(const double *data, uint32_t n_nodes, double gamma, float *thr);
+
 /* ---- edge-list ingestion (host side; usable without a GPU) -------------------------------- */
 /* Fast path of AdjlstGraph.read + to_csr (reference src/pecanpy/graph.py:270-341): parses a 2- or
  * 3-column edge list into the reference's CSR (vertices numbered by first appearance, rows ascending,

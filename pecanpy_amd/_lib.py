@@ -60,6 +60,8 @@ SYMBOLS = {
     "pw_count_stream_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.POINTER(C.c_uint64)]),
     "pw_mt_random_sample": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pw_noise_thresholds_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
+    "pw_noise_thresholds_dense": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
     "pw_edgelist_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "pw_edgelist_shape": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
     "pw_edgelist_export": (C.c_int, [C.c_void_p] * 7),

@@ -18,6 +18,7 @@
 #include "../../include/pecanpy_amd.h"
 #include "aux_kernels.hip.h"
 #include "edgelist.hpp"
+#include "thresholds.hpp"
 #include "mtjump.hpp"
 #include "seqscan.h"
 #include "walk_dense.hip.h"
@@ -988,6 +989,19 @@ PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, dou
         const uint32_t k1 = (uint32_t)(std::lower_bound(E.begin(), E.end(), th.lo) - E.begin());
         exact[i] = (k1 < n && E[k1] >= th.hi) ? k1 : 0xffffffffu;
     }
+    return PW_OK;
+}
+
+// ---- node2vec+ thresholds (host only) -----------------------------------------------------------------
+PW_EXPORT int pw_noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr) {
+    if (!indptr || !thr || (!data && indptr[n_nodes] != 0)) return fail(PW_ERR_INVALID, "null pointer");
+    pw::noise_thresholds_csr(indptr, data, n_nodes, gamma, thr);
+    return PW_OK;
+}
+
+PW_EXPORT int pw_noise_thresholds_dense(const double *data, uint32_t n_nodes, double gamma, float *thr) {
+    if (!data || !thr) return fail(PW_ERR_INVALID, "null pointer");
+    pw::noise_thresholds_dense(data, n_nodes, gamma, thr);
     return PW_OK;
 }
 

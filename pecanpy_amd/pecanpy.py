@@ -231,14 +231,24 @@ class _SparseBase(Base, SparseGraph):
         return lambda idx: indptr[idx] != indptr[idx + 1]
 
     def get_noise_thresholds(self):
-        """Per-node noisy-edge threshold mean + gamma*std, clipped at 0 (sparse_rw.py:22-35).
-        Plain NumPy on the host, evaluated row by row exactly like the reference."""
-        data, indptr = self.data, self.indptr
+        """Per-node noisy-edge threshold ``max(mean + gamma * std, 0)`` (sparse_rw.py:22-35), bit for bit
+        what the reference's row-by-row NumPy expression gives: evaluated by the native restatement of
+        NumPy's pairwise reductions (``pw_noise_thresholds_csr``), by the NumPy loop itself when the
+        library is not built."""
+        data = np.ascontiguousarray(self.data, dtype=np.float32)
+        indptr = np.ascontiguousarray(self.indptr, dtype=np.uint32)
         n = self.num_nodes
         thr = np.zeros(n, dtype=np.float32)
-        if data.size and np.all(data == data[0]) and np.all(indptr[1:] != indptr[:-1]):
-            thr[:] = data[0]  # constant rows: mean = w, std = 0 (exact)
-            return np.maximum(thr, 0)
+        try:
+            from . import _lib
+
+            lib = _lib.load()
+        except Exception:  # library not built
+            lib = None
+        if lib is not None:
+            _lib.check(lib.pw_noise_thresholds_csr(indptr.ctypes.data, data.ctypes.data, n, float(self.gamma),
+                                                   thr.ctypes.data))
+            return thr
         for i in range(n):
             row = data[indptr[i]:indptr[i + 1]]
             thr[i] = row.mean() + self.gamma * row.std()
@@ -315,9 +325,20 @@ class DenseOTF(Base, DenseGraph):
         return lambda idx: bool(nonzero[idx].any())
 
     def get_noise_thresholds(self):
-        """Dense variant (rw/dense_rw.py:11-19)."""
+        """Dense variant (rw/dense_rw.py:11-19): float64 rows, non-zero entries only; native restatement
+        of NumPy's reductions (``pw_noise_thresholds_dense``) with the NumPy loop as fallback."""
         n = self.num_nodes
         thr = np.zeros(n, dtype=np.float32)
+        try:
+            from . import _lib
+
+            lib = _lib.load()
+        except Exception:  # library not built
+            lib = None
+        if lib is not None:
+            mat = np.ascontiguousarray(self.data, dtype=np.float64)
+            _lib.check(lib.pw_noise_thresholds_dense(mat.ctypes.data, n, float(self.gamma), thr.ctypes.data))
+            return thr
         for i in range(n):
             w = self.data[i, self.nonzero[i]]
             thr[i] = w.mean() + self.gamma * w.std()
