@@ -65,6 +65,13 @@ typedef struct {
     uint32_t walk_kernel_launches;
     uint32_t stream_addressing; /* 0: the reference's exact draw assignment; 1: nominal per-walk slots
                                    (fallback on sink-heavy directed graphs) */
+    /* lane kernel (one walk per lane, csrc/walk_lanes.hip.h): unit-weight CSR graphs, 1/p and 1/q powers of two */
+    uint32_t lane_kernel;       /* 1 when the call ran on the lane kernel */
+    uint32_t reserved;
+    uint64_t redo_walks;        /* walks the lane kernel handed to the wave-per-walk kernel (overflow reads, ...) */
+    uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
+    uint64_t ambiguous_steps;   /* steps decided by the float32 chain instead of exact integer arithmetic */
+    double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */
@@ -85,6 +92,10 @@ int pw_device_count(void);
  * used by the test-suite to cross-check the two step implementations). */
 int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                   uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out);
+
+/* Device time (ms) of the index kernels pw_csr_create ran, device bytes of the index, and the number of entries
+ * of the lane kernel's common-neighbour lists (0: lane index not built).  Any pointer may be NULL. */
+int pw_graph_index_info(const pw_graph *g, double *build_ms, uint64_t *index_bytes, uint64_t *lane_list_entries);
 
 /* Dense adjacency in the reference's DenseGraph layout (graph.py:576-580): float64[n, n]
  * row-major; nonzero mask = (data != 0). */
@@ -188,6 +199,12 @@ int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_targe
  * 0xffffffff when a partial sum lies inside the drift bound (the kernel then runs the float chain). */
 int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                uint32_t n_r, uint32_t *chain, uint32_t *exact);
+/* The same decision as one thread of the lane kernel takes it (csrc/seqscan.h: lane_decide), from the ascending
+ * positions of the common neighbours: lane[i] = decided index, 0xfffffffd when the float chain has to decide (then
+ * kmax[i] = number of leading positions the chain may need: chain[i] < kmax[i] or chain[i] == n), 0xfffffffc when
+ * the row is outside the exact range. */
+int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                            uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

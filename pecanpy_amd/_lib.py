@@ -23,6 +23,12 @@ class PwStats(C.Structure):
         ("rng_kernel_ms", C.c_double),
         ("walk_kernel_launches", C.c_uint32),
         ("stream_addressing", C.c_uint32),
+        ("lane_kernel", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("redo_walks", C.c_uint64),
+        ("list_entries_read", C.c_uint64),
+        ("ambiguous_steps", C.c_uint64),
+        ("lane_kernel_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -49,6 +55,7 @@ SYMBOLS = {
     "pw_device_count": (C.c_int, []),
     "pw_csr_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                 C.POINTER(C.c_void_p)]),
+    "pw_graph_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pw_dense_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "pw_dense_create_bits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pw_graph_set_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -68,6 +75,8 @@ SYMBOLS = {
     "pw_edgelist_destroy": (None, [C.c_void_p]),
     "pw_selftest_exact_decision": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
                                              C.c_void_p, C.c_void_p]),
+    "pw_selftest_lane_decide": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "pw_selftest_exact_decision_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p,
                                                  C.c_uint32, C.c_void_p, C.c_void_p]),
     "pw_selftest_seqscan_f32": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32,

@@ -199,11 +199,32 @@ tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint4 *tri) {
     tri[e] = make_uint4(v, cnt, rev, dv);
 }
 
+// Input checks of pw_csr_create, one lane per CSR entry (the reference's isnotin needs
+// ascending, duplicate-free rows, src/pecanpy/rw/sparse_rw.py:142-230, and reads wherever an index points):
+//   flags[0] = first entry whose column index is >= n_nodes      (atomicMin, ~0 = none)
+//   flags[1] = first entry not strictly greater than its predecessor in the same row
+//   flags[2] = 1 when some weight differs from 1.0f  (data == nullptr: all weights are 1)
+//   flags[3] = 1 when the graph has a self loop
 __global__ void __launch_bounds__(256)
-self_loop_kernel(const uint32_t *__restrict__ indices, const uint32_t *__restrict__ edge_row, uint32_t nnz,
-                 unsigned int *flag) {
+csr_validate_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                    const float *__restrict__ data, const uint32_t *__restrict__ edge_row, uint32_t n_nodes,
+                    uint32_t nnz, unsigned long long *flags) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < nnz && indices[e] == edge_row[e]) atomicOr(flag, 1u);
+    if (e >= nnz) return;
+    const uint32_t u = edge_row[e], v = indices[e];
+    if (v >= n_nodes) atomicMin(&flags[0], (unsigned long long)e);
+    if (e > indptr[u] && indices[e - 1] >= v) atomicMin(&flags[1], (unsigned long long)e);
+    if (data && data[e] != 1.0f) flags[2] = 1ull;
+    if (u == v) flags[3] = 1ull;
+}
+
+// vrec[v] = { indptr[v], degree(v), foff[v], tab_off[v] / 2 } for v in [0, n_nodes]  (walk_sparse.hip.h: CsrDev::vrec)
+__global__ void __launch_bounds__(256)
+vrec_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ foff,
+                  const uint64_t *__restrict__ tab_off, uint32_t n_nodes, uint4 *vrec) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n_nodes) return;
+    vrec[v] = make_uint4(indptr[v], v < n_nodes ? indptr[v + 1] - indptr[v] : 0u, foff[v], (uint32_t)(tab_off[v] >> 1));
 }
 
 __global__ void csr_edge_rows_kernel(const uint32_t *__restrict__ indptr, uint32_t n_nodes, uint32_t *edge_row) {

@@ -24,12 +24,17 @@
 #include "walk_dense.hip.h"
 #include "walk_seq.hip.h"
 #include "walk_sparse.hip.h"
+#include "walk_lanes.hip.h"
 
 #define PW_EXPORT extern "C" __attribute__((visibility("default")))
 
 namespace {
 
 thread_local std::string g_err;
+
+// pw_graph::counters layout: [0] job counter [1..4] stats [5] changed count [6] redo count [7] list entries read
+// by the lane kernel [8] ambiguous steps (float chain) of the lane kernel
+constexpr int N_COUNTERS = 16;
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -83,14 +88,20 @@ struct pw_graph {
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
     uint4 *d_tri = nullptr;                             // CSR graphs: per-edge {neighbour, common-neighbour count, reverse position, degree}
     uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
+    pw::ERec *d_erec = nullptr;                         // lane kernel (walk_lanes.hip.h): 32-byte record per CSR entry
+    uint32_t *d_clist = nullptr;                        // lane kernel: per-edge positions of the common neighbours
+    uint64_t n_clist = 0;
+    double index_build_ms = 0;                          // device time of all index kernels of pw_csr_create
+    uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double lane_ms = 0;              // lane kernel time of the current call
     int n_cu = 0;
     // scratch reused across calls
     DevBuf<uint64_t> stream_off, tile_sums;
     DevBuf<double> rng;
-    DevBuf<uint32_t> mt_state, changed;
+    DevBuf<uint32_t> mt_state, changed, redo;
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
     bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
@@ -184,6 +195,9 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_slots) (void)hipFree(g->d_slots);
     if (g->d_tri) (void)hipFree(g->d_tri);
     if (g->d_vrec) (void)hipFree(g->d_vrec);
+    if (g->d_erec) (void)hipFree(g->d_erec);
+    if (g->d_clist) (void)hipFree(g->d_clist);
+    g->redo.release();
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -220,6 +234,55 @@ static int graph_common_init(pw_graph *g, int device) {
 
 static pw::CsrDev csr_dev(const pw_graph *g);
 
+// Lane-kernel index (walk_lanes.hip.h): per-edge lists of common-neighbour positions + 32-byte edge records, from
+// the per-edge counts of tri_build_kernel.  Skipped (the wave-per-walk kernel then serves every call) when the
+// lists would not fit comfortably into free device memory or PECANPY_AMD_NO_LANES is set.
+static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
+    if (getenv("PECANPY_AMD_NO_LANES") || !g->d_tri || !g->nnz) return 0;
+    const uint32_t nnz = g->nnz;
+    const uint64_t n_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
+    uint64_t *d_tiles = nullptr, *d_coff = nullptr;
+    auto cleanup = [&]() {
+        if (d_tiles) (void)hipFree(d_tiles);
+        if (d_coff) (void)hipFree(d_coff);
+    };
+    hipError_t e = hipMalloc((void **)&d_tiles, sizeof(uint64_t) * (n_tiles + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_coff, sizeof(uint64_t) * (size_t)nnz);
+    uint64_t total = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pw::clist_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_tri, nnz, d_tiles);
+        hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
+        hipLaunchKernelGGL(pw::clist_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_tri, nnz, d_tiles, d_coff);
+        e = hipMemcpyAsync(&total, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    }
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("lane index (offsets): ") + hipGetErrorString(e)); }
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint64_t need = total * sizeof(uint32_t) + (uint64_t)nnz * sizeof(pw::ERec);
+    if (need > free_b / 2) { cleanup(); return 0; }   // leave room for the stream and the walk matrix
+    e = hipMalloc((void **)&g->d_clist, sizeof(uint32_t) * (size_t)(total ? total : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_erec, sizeof(pw::ERec) * (size_t)nnz);
+    if (e == hipSuccess) {
+        pw::CsrDev c = csr_dev(g);
+        hipLaunchKernelGGL(pw::clist_fill_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c,
+                           d_edge_row, d_coff, g->d_clist, g->d_erec);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) {
+        if (g->d_clist) (void)hipFree(g->d_clist);
+        if (g->d_erec) (void)hipFree(g->d_erec);
+        g->d_clist = nullptr;
+        g->d_erec = nullptr;
+        return fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e));
+    }
+    g->n_clist = total;
+    g->index_bytes += need;
+    return 0;
+}
+
 PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                             uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out) {
     if (!indptr || !out || (nnz && !indices)) return fail(PW_ERR_INVALID, "null pointer");
@@ -230,19 +293,29 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     g->kind = 0;
     g->n_nodes = n_nodes;
     g->nnz = nnz;
+    // O(n_nodes) host pass: monotone offsets, maximum degree, sizes of the per-row filters and index tables
+    std::vector<uint32_t> foff((size_t)n_nodes + 1);
+    std::vector<uint64_t> off((size_t)n_nodes + 1);
     uint32_t md = 0;
+    uint64_t frun = 0, trun = 0;
     for (uint32_t i = 0; i < n_nodes; i++) {
         if (indptr[i + 1] < indptr[i]) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "indptr not monotone"); }
-        uint32_t d = indptr[i + 1] - indptr[i];
+        const uint32_t d = indptr[i + 1] - indptr[i];
         if (d > md) md = d;
+        foff[i] = (uint32_t)frun;
+        frun += pw::filter_words_for_degree(d);
+        off[i] = trun;
+        if (d) {
+            uint64_t sz = 2;
+            while (sz < 2ull * d) sz <<= 1;
+            trun += sz;
+        }
     }
+    if (frun >= 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit filter offsets"); }
+    if ((trun >> 1) > 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit index offsets"); }
+    foff[n_nodes] = (uint32_t)frun;
+    off[n_nodes] = trun;
     g->max_degree = md;
-    bool unit = true;
-    if (data) {
-        for (uint32_t k = 0; k < nnz; k++)
-            if (data[k] != 1.0f) { unit = false; break; }
-    }
-    g->unit = unit;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         HIP_TRY(hipMalloc(dst, bytes ? bytes : 4));
         if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -250,102 +323,103 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     };
     rc = up((void **)&g->d_indptr, indptr, sizeof(uint32_t) * ((size_t)n_nodes + 1));
     if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
-    if (!rc && !unit) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
+    if (!rc && data) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
     if (rc) { pw_graph_destroy(g); return rc; }
-    std::vector<uint32_t> foff((size_t)n_nodes + 1);
-    std::vector<uint64_t> off((size_t)n_nodes + 1);
-    {   // per-row membership filters
-        uint64_t run = 0;
-        for (uint32_t i = 0; i < n_nodes; i++) {
-            foff[i] = (uint32_t)run;
-            run += pw::filter_words_for_degree(indptr[i + 1] - indptr[i]);
-        }
-        if (run >= 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit filter offsets"); }
-        foff[n_nodes] = (uint32_t)run;
-        rc = up((void **)&g->d_foff, foff.data(), sizeof(uint32_t) * foff.size());
-        if (!rc) {
-            hipError_t e = hipMalloc((void **)&g->d_fbits, sizeof(uint64_t) * (run ? run : 1));
-            if (e == hipSuccess) e = hipMalloc((void **)&g->d_kf, sizeof(uint2) * (size_t)(nnz ? nnz : 1));
-            if (e == hipSuccess) e = hipMemsetAsync(g->d_fbits, 0, sizeof(uint64_t) * (run ? run : 1), g->stream);
-            if (e == hipSuccess && n_nodes && nnz) {
-                hipLaunchKernelGGL(pw::filter_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
-                                   g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, g->d_kf, n_nodes, nnz);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-            if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("membership filter build: ") + hipGetErrorString(e));
-        }
-        if (rc) { pw_graph_destroy(g); return rc; }
-    }
-    {   // adjacency index: per-row open-addressing table of next_pow2(2 * degree) slots
-        uint64_t run = 0;
-        for (uint32_t i = 0; i < n_nodes; i++) {
-            off[i] = run;
-            uint32_t d = indptr[i + 1] - indptr[i];
-            if (d) {
-                uint64_t sz = 2;
-                while (sz < 2ull * d) sz <<= 1;
-                run += sz;
-            }
-        }
-        off[n_nodes] = run;
-        rc = up((void **)&g->d_tab_off, off.data(), sizeof(uint64_t) * off.size());
-        if (!rc) {
-            hipError_t e = hipMalloc((void **)&g->d_slots, sizeof(uint64_t) * (run ? run : 1));
-            if (e == hipSuccess) e = hipMemsetAsync(g->d_slots, 0xff, sizeof(uint64_t) * (run ? run : 1), g->stream);
-            if (e == hipSuccess && n_nodes) {
-                hipLaunchKernelGGL(pw::adj_index_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
-                                   g->d_indices, g->d_tab_off, (unsigned long long *)g->d_slots, n_nodes);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-            if (e != hipSuccess) rc = fail(PW_ERR_HIP, std::string("adjacency index build: ") + hipGetErrorString(e));
-        }
-        if (rc) { pw_graph_destroy(g); return rc; }
-    }
-    {   // per-vertex records
-        if ((off[n_nodes] >> 1) > 0xffffffffull) { pw_graph_destroy(g); return fail(PW_ERR_INVALID, "graph too large for 32-bit index offsets"); }
-        std::vector<uint32_t> rec(4 * ((size_t)n_nodes + 1));
-        for (uint32_t i = 0; i <= n_nodes; i++) {
-            rec[4 * (size_t)i + 0] = indptr[i];
-            rec[4 * (size_t)i + 1] = i < n_nodes ? indptr[i + 1] - indptr[i] : 0u;
-            rec[4 * (size_t)i + 2] = foff[i];
-            rec[4 * (size_t)i + 3] = (uint32_t)(off[i] >> 1);   // table sizes are powers of two >= 2
-        }
-        rc = up((void **)&g->d_vrec, rec.data(), sizeof(uint32_t) * rec.size());
-        if (rc) { pw_graph_destroy(g); return rc; }
-    }
-    if (unit && nnz && !getenv("PECANPY_AMD_NO_LAZY")) {
-        // per-edge common-neighbour counts (lazy membership of the unit-weight kernel); skipped for
-        // graphs with self loops, where "common neighbour" and the reference's prev handling differ
-        uint32_t *d_edge_row = nullptr;
-        unsigned int *d_flag = nullptr;
-        hipError_t e = hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)nnz);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_flag, sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(unsigned int), g->stream);
-        unsigned int has_loop = 1;
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, n_nodes, d_edge_row);
-            hipLaunchKernelGGL(pw::self_loop_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
-                               g->d_indices, d_edge_row, nnz, d_flag);
-            e = hipMemcpyAsync(&has_loop, d_flag, sizeof(has_loop), hipMemcpyDeviceToHost, g->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-        }
-        if (e == hipSuccess && !has_loop) {
-            e = hipMalloc((void **)&g->d_tri, sizeof(uint4) * (size_t)nnz);
-            if (e == hipSuccess) {
-                pw::CsrDev c = csr_dev(g);
-                hipLaunchKernelGGL(pw::tri_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
-                                   c, d_edge_row, g->d_tri);
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-            }
-        }
+
+    // ---- device side: validation, weight scan, membership index ------------------------------------------------
+    uint32_t *d_edge_row = nullptr;
+    unsigned long long *d_flags = nullptr;   // [0] first entry with index >= n_nodes  [1] first entry out of order
+                                             // [2] some weight != 1.0f  [3] self loop present
+    auto bail = [&](int code, const std::string &msg) {
         if (d_edge_row) (void)hipFree(d_edge_row);
-        if (d_flag) (void)hipFree(d_flag);
-        if (e != hipSuccess) { pw_graph_destroy(g); return fail(PW_ERR_HIP, std::string("common-neighbour counts: ") + hipGetErrorString(e)); }
+        if (d_flags) (void)hipFree(d_flags);
+        pw_graph_destroy(g);
+        return fail(code, msg);
+    };
+    hipError_t e = hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)(nnz ? nnz : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 4 * sizeof(unsigned long long));
+    unsigned long long h_flags[4] = {~0ull, ~0ull, 0ull, 0ull};
+    if (e == hipSuccess) e = hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) e = hipEventRecord(g->ev[0], g->stream);
+    if (e == hipSuccess && nnz) {
+        hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, n_nodes, d_edge_row);
+        hipLaunchKernelGGL(pw::csr_validate_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                           g->d_indptr, g->d_indices, (const float *)g->d_data, d_edge_row, n_nodes, nnz, d_flags);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("CSR validation: ") + hipGetErrorString(e));
+    if (h_flags[0] != ~0ull) {
+        uint32_t row = 0;
+        (void)hipMemcpy(&row, d_edge_row + h_flags[0], sizeof(row), hipMemcpyDeviceToHost);
+        return bail(PW_ERR_INVALID, "CSR entry " + std::to_string(h_flags[0]) + " (row " + std::to_string(row) +
+                                        "): column index >= n_nodes");
+    }
+    if (h_flags[1] != ~0ull) {
+        uint32_t row = 0;
+        (void)hipMemcpy(&row, d_edge_row + h_flags[1], sizeof(row), hipMemcpyDeviceToHost);
+        return bail(PW_ERR_INVALID, "row " + std::to_string(row) + " (CSR entry " + std::to_string(h_flags[1]) +
+                                        "): column indices must be strictly ascending within a row (sorted, no duplicates), "
+                                        "as the reference's to_csr produces them (graph.py:336)");
+    }
+    g->unit = !(data && h_flags[2]);
+    if (g->unit && g->d_data) { (void)hipFree(g->d_data); g->d_data = nullptr; }   // unit weights are never read
+    const bool has_loop = h_flags[3] != 0;
+
+    rc = up((void **)&g->d_foff, foff.data(), sizeof(uint32_t) * foff.size());
+    if (!rc) rc = up((void **)&g->d_tab_off, off.data(), sizeof(uint64_t) * off.size());
+    if (rc) { if (d_edge_row) (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
+    e = hipMalloc((void **)&g->d_fbits, sizeof(uint64_t) * (frun ? frun : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_kf, sizeof(uint2) * (size_t)(nnz ? nnz : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_slots, sizeof(uint64_t) * (trun ? trun : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_vrec, sizeof(uint4) * ((size_t)n_nodes + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(g->d_fbits, 0, sizeof(uint64_t) * (frun ? frun : 1), g->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->d_slots, 0xff, sizeof(uint64_t) * (trun ? trun : 1), g->stream);
+    if (e != hipSuccess) return bail(PW_ERR_NOMEM, std::string("membership index: ") + hipGetErrorString(e));
+    g->index_bytes = sizeof(uint64_t) * (frun + trun) + sizeof(uint2) * (uint64_t)nnz + sizeof(uint4) * ((uint64_t)n_nodes + 1);
+    hipLaunchKernelGGL(pw::vrec_build_kernel, dim3((n_nodes + 256) / 256), dim3(256), 0, g->stream, g->d_indptr, g->d_foff,
+                       g->d_tab_off, n_nodes, g->d_vrec);
+    if (n_nodes && nnz) {
+        hipLaunchKernelGGL(pw::filter_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
+                           g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, g->d_kf, n_nodes, nnz);
+        hipLaunchKernelGGL(pw::adj_index_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
+                           g->d_indices, g->d_tab_off, (unsigned long long *)g->d_slots, n_nodes);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
+    if (g->unit && nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {
+        // per-edge common-neighbour counts (lazy membership of the unit-weight kernels); skipped for graphs
+        // with self loops, where "common neighbour" and the reference's prev handling differ
+        e = hipMalloc((void **)&g->d_tri, sizeof(uint4) * (size_t)nnz);
+        if (e == hipSuccess) {
+            pw::CsrDev c = csr_dev(g);
+            hipLaunchKernelGGL(pw::tri_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                               c, d_edge_row, g->d_tri);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        }
+        if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("common-neighbour counts: ") + hipGetErrorString(e));
+        g->index_bytes += sizeof(uint4) * (uint64_t)nnz;
+        rc = build_lane_index(g, d_edge_row);
+        if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
+    }
+    (void)hipEventRecord(g->ev[1], g->stream);
+    (void)hipStreamSynchronize(g->stream);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->ev[0], g->ev[1]) == hipSuccess) g->index_build_ms = ms;
+    (void)hipFree(d_edge_row);
+    (void)hipFree(d_flags);
     *out = g;
+    return PW_OK;
+}
+
+PW_EXPORT int pw_graph_index_info(const pw_graph *g, double *build_ms, uint64_t *index_bytes, uint64_t *lane_list_entries) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (build_ms) *build_ms = g->index_build_ms;
+    if (index_bytes) *index_bytes = g->index_bytes;
+    if (lane_list_entries) *lane_list_entries = g->d_erec ? g->n_clist : 0;
     return PW_OK;
 }
 
@@ -485,7 +559,7 @@ PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_
                                     uint32_t walk_length, uint64_t *out_draws) {
     if (!g || !starts || !out_draws) return fail(PW_ERR_INVALID, "null pointer");
     if (set_device(g)) return PW_ERR_HIP;
-    if (g->counters.ensure(8)) return PW_ERR_NOMEM;
+    if (g->counters.ensure(N_COUNTERS)) return PW_ERR_NOMEM;
     uint32_t *d_starts = nullptr;
     HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
     hipError_t e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
@@ -668,7 +742,7 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
     return 0;
 }
 
-static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
+static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
     if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa);
@@ -685,6 +759,70 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
+    return g->kind == 0 && g->unit && g->d_erec && wa.lazy_ok && !getenv("PECANPY_AMD_NO_LANES");
+}
+
+// One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
+// walked again by the wave-per-walk kernel.  *n_redo receives their number.
+static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
+    const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
+    if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
+    pw::LanesArgs la;
+    la.erec = g->d_erec;
+    la.clist = g->d_clist;
+    la.vrec = g->d_vrec;
+    la.nnz = g->nnz;
+    la.L = wa.L;
+    la.n_jobs = wa.n_jobs;
+    la.starts = wa.starts;
+    la.stream_off = wa.stream_off;
+    la.job_list = wa.job_list;
+    la.n_list = wa.n_list;
+    la.rng = wa.rng;
+    la.rng_base = wa.rng_base;
+    la.out = wa.out;
+    la.job_counter = g->counters.p;
+    la.stats = g->counters.p + 1;
+    la.redo_list = g->redo.p;
+    la.redo_count = g->counters.p + 6;
+    la.w_out = wa.w_out;
+    la.w_prev = wa.w_prev;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ < 1) occ = 1;
+    uint64_t want = (n_work + pw::WAVES_PER_BLOCK * pw::WAVE - 1) / (pw::WAVES_PER_BLOCK * pw::WAVE);
+    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
+    if (grid > want) grid = want;
+    if (grid < 1) grid = 1;
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+    hipLaunchKernelGGL(pw::walk_lanes_kernel, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+    unsigned long long nr = 0;
+    HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float lms = 0;
+    HIP_TRY(hipEventElapsedTime(&lms, g->ev[4], g->ev[5]));
+    g->lane_ms += lms;
+    *n_redo = nr;
+    return 0;
+}
+
+static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
+    if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
+    uint64_t n_redo = 0;
+    int rc = launch_lane_walks(g, wa, &n_redo);
+    if (rc || !n_redo) return rc;
+    if (redo_total) *redo_total += n_redo;
+    pw::WalkArgs wr = wa;
+    wr.job_list = g->redo.p;
+    wr.n_list = n_redo;
+    return launch_wave_walks(g, wr, extend);
 }
 
 PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
@@ -705,7 +843,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     memset(&st, 0, sizeof(st));
     if (n_jobs == 0) { if (stats) *stats = st; return PW_OK; }
     if (!has_seed) seed = os_seed();
-    if (g->counters.ensure(8)) return PW_ERR_NOMEM;
+    if (g->counters.ensure(N_COUNTERS)) return PW_ERR_NOMEM;
     if (mode >= PW_MODE_PRECOMP) {
         if (stream_skip) return fail(PW_ERR_UNSUPPORTED, "alias / first-order modes consume a variable number of "
                                                          "words per step: the stream cannot be sharded");
@@ -770,7 +908,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     HIP_TRY(hipEventRecord(g->ev[1], g->stream));
 
     // 3. walks
-    HIP_TRY(hipMemsetAsync(g->counters.p, 0, 8 * sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, N_COUNTERS * sizeof(unsigned long long), g->stream));
     pw::WalkArgs wa;
     wa.g = csr_dev(g);
     wa.p = p;
@@ -796,11 +934,16 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         };
         wa.lazy_ok = (pow2_ok(wa.w_out) && pow2_ok(wa.w_prev)) ? 1u : 0u;
     }
+    uint64_t redo_total = 0;
+    const bool lanes = lanes_eligible(g, wa);
+    g->lane_ms = 0;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-    rc = launch_walks(g, wa, extend != 0);
+    // the lane kernel only writes the cells a walk fills: the matrix starts zeroed (pecanpy.py:182-187)
+    if (lanes) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
+    rc = launch_walks(g, wa, extend != 0, &redo_total);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->ev[3], g->stream));
-    unsigned long long h[8];
+    unsigned long long h[N_COUNTERS];
     HIP_TRY(hipMemcpyAsync(h, g->counters.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
 #ifdef PW_PROF
@@ -847,7 +990,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         wa.job_list = g->changed.p;
         wa.n_list = n_changed;
         HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-        rc = launch_walks(g, wa, extend != 0);
+        rc = launch_walks(g, wa, extend != 0, &redo_total);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(g->ev[3], g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -877,6 +1020,11 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.overflow_reads = h[2];
     st.clamped_reads = h[3];
     st.dead_end_walks = dead;
+    st.lane_kernel = lanes ? 1u : 0u;
+    st.redo_walks = redo_total;
+    st.list_entries_read = h[7];
+    st.ambiguous_steps = h[8];
+    st.lane_kernel_ms = g->lane_ms;
     if (stats) *stats = st;
     return PW_OK;
 }
@@ -988,6 +1136,40 @@ PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, dou
         const pw::ExactThresholds64 th = pw::exact_thresholds_f64(r[i] * S, (double)n, wmax);
         const uint32_t k1 = (uint32_t)(std::lower_bound(E.begin(), E.end(), th.lo) - E.begin());
         exact[i] = (k1 < n && E[k1] >= th.hi) ? k1 : 0xffffffffu;
+    }
+    return PW_OK;
+}
+
+// ---- host self test of the lane kernel's per-thread decision (seqscan.h: lane_decide) ----------------------------
+PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                                      uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax) {
+    if (!cls || !r || !chain || !lane || !kmax || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
+    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    std::vector<uint32_t> cl;
+    uint32_t pp = 0xffffffffu, cnt[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < n; k++) {
+        if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
+        cnt[cls[k]]++;
+        if (cls[k] == 1) cl.push_back(k);
+        if (cls[k] == 2) pp = k;
+    }
+    if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
+    const double td = (double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev;
+    const float tot = (float)td;
+    const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
+    for (uint32_t i = 0; i < n_r; i++) {
+        float c = 0.0f;
+        uint32_t kc = n;
+        for (uint32_t k = 0; k < n; k++) {   // the reference: sequential float32 cumsum + searchsorted
+            c = c + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
+            if ((double)c >= r[i]) { kc = k; break; }
+        }
+        chain[i] = kc;
+        pw::LaneStep ls{0.0f, 0u, 0u};
+        lane[i] = pw::lane_decide(n, (uint32_t)cl.size(), pp, r[i], w_out, w_prev, cl.data(), ls);
+        kmax[i] = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : 0u;
+        if (lane[i] != pw::LANE_REDO && ls.tot != tot) return fail(PW_ERR_INVALID, "row total mismatch");
     }
     return PW_OK;
 }

@@ -21,7 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PW_HD __host__ __device__ __forceinline__
 #else
 #define PW_HD inline
@@ -207,6 +207,85 @@ PW_HD ExactThresholds64 exact_thresholds_f64(double R, double prefix, double wma
     t.lo = lo > 0.0 ? (uint64_t)lo : 0ull;
     t.hi = (uint64_t)ceil(R + zr);
     return t;
+}
+
+// First position k >= s of a run without common neighbours whose exact mass reaches th:
+//   E(k) = base + (#"out" elements in [s, k]) << sh_out + (prev inside [s, k] ? wp : 0)
+// (prev_pos == 0xffffffff: prev is not in the run).  Returns k, its mass through e_k.  Integer arithmetic.
+PW_HD uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t prev_pos, uint32_t sh_out, uint32_t wp,
+                             uint32_t &e_k) {
+    const uint32_t wo_m1 = (1u << sh_out) - 1u;
+    const uint32_t need = th > base ? th - base : 0u;
+    uint32_t k = need ? s + ((need + wo_m1) >> sh_out) - 1u : s;   // first k with (k - s + 1) << sh_out >= need
+    e_k = base + ((k - s + 1u) << sh_out);
+    if (prev_pos != 0xffffffffu && prev_pos >= s && k >= prev_pos) {   // every k < prev_pos stays below th
+        const uint32_t need2 = need > wp ? need - wp : 0u;
+        k = s + ((need2 + wo_m1) >> sh_out);                         // first k with ((k - s) << sh_out) + wp >= need
+        if (k < prev_pos) k = prev_pos;
+        e_k = base + ((k - s) << sh_out) + wp;
+    }
+    return k;
+}
+
+// ---- the exact decision evaluated by ONE thread from the positions of the common neighbours (lane kernel) ------
+// Row of d neighbours; cl[0..n_in) = ascending positions of the common neighbours of prev and cur ("in", weight
+// 1), pp = position of prev (weight w_prev; 0xffffffff: prev is not a neighbour), everything else "out" (weight
+// w_out); w_out, w_prev powers of two.  Returns the position np.searchsorted(np.cumsum(float32 probs), r) selects
+// when the decision is certain; LANE_AMBIGUOUS when a partial sum of the exact CDF lies inside the drift bound
+// (the float chain then needs the first `kmax` positions at most); LANE_REDO when the row is outside the exact
+// range.  The run structure: the i-th common neighbour sits at P_i with exact mass
+//   E(P_i) = ((P_i - i - [pp < P_i]) << sh_out) + ((i + 1) << sh_in) + ([pp < P_i] << sh_prev),
+// monotone in i, so the first i with E(P_i) >= lo is found by bisection; between P_{i-1} and P_i the row consists
+// of "out" positions (and possibly prev), where the first position reaching lo is a closed form (solve_out_run).
+constexpr uint32_t LANE_AMBIGUOUS = 0xfffffffdu;
+constexpr uint32_t LANE_REDO = 0xfffffffcu;
+
+struct LaneStep {
+    float tot;        // exact row total (float32)
+    uint32_t kmax;    // ambiguous steps: leading positions the float chain can need
+    uint32_t probes;  // list entries read by the bisection
+};
+
+PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
+                           const uint32_t *cl, LaneStep &ls) {
+    const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
+    ls.probes = 0;
+    if (n_in + n_pv > d) return LANE_REDO;
+    const uint32_t n_out = d - n_in - n_pv;
+    float u = 1.0f;
+    if (n_out && w_out < u) u = w_out;
+    if (n_pv && w_prev < u) u = w_prev;
+    const double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
+    if (!(td <= 16777216.0 * (double)u)) return LANE_REDO;   // every partial sum exact: tot = exact sum
+    ls.tot = (float)td;
+    const uint32_t sh_u = (FloatTraits<float>::bits(u) >> 23) & 0xffu;
+    const uint32_t sh_in = (127u - sh_u) & 31u,   // classes that do not occur in the row get shift 0
+                   sh_out = n_out ? (((FloatTraits<float>::bits(w_out) >> 23) & 0xffu) - sh_u) & 31u : 0u,
+                   sh_prev = n_pv ? (((FloatTraits<float>::bits(w_prev) >> 23) & 0xffu) - sh_u) & 31u : 0u;
+    const double units = ldexp(td, (int)(127u - sh_u));   // td / u, exact
+    uint32_t sh_max = sh_in > sh_out ? sh_in : sh_out;
+    if (sh_prev > sh_max) sh_max = sh_prev;
+    const ExactThresholds th = exact_thresholds_f32(r * units, d, 1u << sh_max);
+    const uint32_t lo_th = th.lo, hi_th = th.hi;
+    const uint32_t wp = 1u << sh_prev;
+    uint32_t lo = 0, hi = n_in, s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0;
+    while (lo < hi) {
+        ls.probes++;
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t P = cl[mid];
+        const uint32_t pv = pp < P ? 1u : 0u;   // 0xffffffff compares greater than any position
+        const uint32_t ea = ((P - mid - pv) << sh_out) + ((mid + 1u) << sh_in) + (pv << sh_prev);   // E(P)
+        if (ea >= lo_th) { hi = mid; p_f = P; e_f = ea; }
+        else { lo = mid + 1u; s_run = P + 1u; base = ea; }
+    }
+    uint32_t e1;
+    uint32_t k1 = solve_out_run(s_run, base, lo_th, (n_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, wp, e1);
+    if (p_f != 0xffffffffu && k1 >= p_f) { k1 = p_f; e1 = e_f; }
+    if (k1 < d && e1 >= hi_th) return k1;
+    // every j < k1 has c_j < r; the chain reaches r at the latest where E >= hi_th, and E grows by >= 1 per element
+    const uint64_t km = (uint64_t)k1 + (uint64_t)(hi_th > lo_th ? hi_th - lo_th : 0u) + 2ull;
+    ls.kmax = km < d ? (uint32_t)km : d;
+    return LANE_AMBIGUOUS;
 }
 
 }  // namespace pw

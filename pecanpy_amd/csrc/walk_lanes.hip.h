@@ -57,61 +57,13 @@ struct LanesArgs {
     uint32_t *out;                            // [n_jobs, L + 2], zero-filled by the caller before the first launch
     unsigned long long *job_counter;
     unsigned long long *stats;                // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
+                                              // [6] list entries read [7] ambiguous steps (float chain)
     uint32_t *redo_list;                      // jobs handed to walk_kernel
     unsigned long long *redo_count;
     float w_out, w_prev;                      // fl32(1/q), fl32(1/p): powers of two (host checked)
 };
 
-// ---- per-lane exact decision ------------------------------------------------------------------------------
-// Returns the sampled position k1 < d when the decision is certain, LANE_AMBIGUOUS when the float chain has to
-// decide (kmax = number of leading row positions the chain can need), LANE_REDO when a precondition fails.
-constexpr uint32_t LANE_AMBIGUOUS = 0xfffffffdu;
-constexpr uint32_t LANE_REDO = 0xfffffffcu;
-
-struct LaneStep {
-    float tot;        // exact row total (float32)
-    uint32_t kmax;
-};
-
-__device__ __forceinline__ uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
-                                                const uint32_t *__restrict__ cl, LaneStep &ls) {
-    const uint32_t n_pv = pp != NOT_FOUND ? 1u : 0u;
-    if (n_in + n_pv > d) return LANE_REDO;
-    const uint32_t n_out = d - n_in - n_pv;
-    float u = 1.0f;
-    if (n_out && w_out < u) u = w_out;
-    if (n_pv && w_prev < u) u = w_prev;
-    const double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
-    if (!(td <= 16777216.0 * (double)u)) return LANE_REDO;   // every partial sum exact: tot = exact sum
-    ls.tot = (float)td;
-    const uint32_t sh_u = (__float_as_uint(u) >> 23) & 0xffu;
-    const uint32_t sh_in = (127u - sh_u) & 31u,
-                   sh_out = n_out ? (((__float_as_uint(w_out) >> 23) & 0xffu) - sh_u) & 31u : 0u,
-                   sh_prev = n_pv ? (((__float_as_uint(w_prev) >> 23) & 0xffu) - sh_u) & 31u : 0u;
-    const double units = ldexp(td, (int)(127u - sh_u));   // td / u, exact
-    const ExactThresholds th = exact_thresholds_f32(r * units, d, 1u << max_u32(sh_in, max_u32(sh_out, sh_prev)));
-    const uint32_t lo_th = th.lo, hi_th = th.hi;
-    const uint32_t wp = 1u << sh_prev;
-    // first common neighbour i whose exact mass E(P_i) reaches lo_th; the run of "out" positions before it
-    // starts behind the last common neighbour that stays below
-    uint32_t lo = 0, hi = n_in, s_run = 0, base = 0, p_f = NOT_FOUND, e_f = 0;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t P = cl[mid];
-        const uint32_t pv = pp < P ? 1u : 0u;   // NOT_FOUND compares greater than any position
-        const uint32_t ea = ((P - mid - pv) << sh_out) + ((mid + 1u) << sh_in) + (pv << sh_prev);   // E(P)
-        if (ea >= lo_th) { hi = mid; p_f = P; e_f = ea; }
-        else { lo = mid + 1u; s_run = P + 1u; base = ea; }
-    }
-    uint32_t e1;
-    uint32_t k1 = solve_out_run(s_run, base, lo_th, (n_pv && pp >= s_run) ? pp : NOT_FOUND, sh_out, wp, e1);
-    if (p_f != NOT_FOUND && k1 >= p_f) { k1 = p_f; e1 = e_f; }
-    if (k1 < d && e1 >= hi_th) return k1;
-    // every j < k1 has c_j < r; the chain reaches r at the latest where E >= hi_th, and E grows by >= 1 per element
-    const uint64_t km = (uint64_t)k1 + (uint64_t)(hi_th > lo_th ? hi_th - lo_th : 0u) + 2ull;
-    ls.kmax = km < d ? (uint32_t)km : d;
-    return LANE_AMBIGUOUS;
-}
+// (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
 
 // ---- wave-cooperative float32 chain for one lane's step ---------------------------------------------------------
 // Same arithmetic as sample_step_unit_lazy's fallback (walk_sparse.hip.h): mask of the common neighbours among
@@ -172,7 +124,7 @@ walk_lanes_kernel(LanesArgs a) {
     uint64_t soff = 0;
     uint32_t s0 = 0, d = 0, n_in = 0, pp = NOT_FOUND;
     uint64_t coff = 0;
-    unsigned long long n_steps = 0, n_dead = 0;
+    unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0;
 
     for (;;) {
         // ---- refill idle lanes from the job counter -------------------------------------------------------
@@ -206,12 +158,14 @@ walk_lanes_kernel(LanesArgs a) {
 
         // ---- one step for every active lane ---------------------------------------------------------------------
         uint32_t choice = 0;
-        LaneStep ls{1.0f, 0u};
+        LaneStep ls{1.0f, 0u, 0u};
         double r = 0.0;
         const float wo = j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
         if (active) {
             r = a.rng[soff + (j - 1)];
             choice = lane_decide(d, n_in, pp, r, wo, w_prev, a.clist + coff, ls);
+            n_probes += ls.probes;
+            if (choice == LANE_AMBIGUOUS) { n_amb++; n_probes += n_in < ls.kmax ? n_in : ls.kmax; }
         }
         // ambiguous steps: the whole wave runs the float32 chain for one lane at a time
         uint64_t amb = ballot(active && choice == LANE_AMBIGUOUS);
@@ -258,10 +212,14 @@ walk_lanes_kernel(LanesArgs a) {
     for (int off = 32; off > 0; off >>= 1) {
         n_steps += (unsigned long long)__shfl_down((long long)n_steps, (unsigned)off, WAVE);
         n_dead += (unsigned long long)__shfl_down((long long)n_dead, (unsigned)off, WAVE);
+        n_probes += (unsigned long long)__shfl_down((long long)n_probes, (unsigned)off, WAVE);
+        n_amb += (unsigned long long)__shfl_down((long long)n_amb, (unsigned)off, WAVE);
     }
     if (lane == 0) {
         if (n_steps) atomicAdd(a.stats + 0, n_steps);
         if (n_dead) atomicAdd(a.stats + 3, n_dead);
+        if (n_probes) atomicAdd(a.stats + 6, n_probes);
+        if (n_amb) atomicAdd(a.stats + 7, n_amb);
     }
 }
 

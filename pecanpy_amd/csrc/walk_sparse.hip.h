@@ -996,25 +996,7 @@ __device__ __forceinline__ uint32_t unit_search_units(const UnitRow &ur, uint32_
 }
 
 // Vertex context carried by the walk loop: row start/degree plus the offsets of the row's filter and
-// adjacency index (one vrec load when the vertex is entered).
-// First position k >= s of a run without common neighbours whose exact mass reaches th:
-//   E(k) = base + (#"out" elements in [s, k]) << sh_out + (prev inside [s, k] ? wp : 0)
-// (prev_pos == NOT_FOUND: prev is not in the row).  Returns k, its mass through e_k.  Scalar arithmetic.
-__device__ __forceinline__ uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t prev_pos,
-                                                  uint32_t sh_out, uint32_t wp, uint32_t &e_k) {
-    const uint32_t wo_m1 = (1u << sh_out) - 1u;
-    const uint32_t need = th > base ? th - base : 0u;
-    uint32_t k = need ? s + ((need + wo_m1) >> sh_out) - 1u : s;   // first k with (k - s + 1) << sh_out >= need
-    e_k = base + ((k - s + 1u) << sh_out);
-    if (prev_pos != NOT_FOUND && prev_pos >= s && k >= prev_pos) {   // every k < prev_pos stays below th
-        const uint32_t need2 = need > wp ? need - wp : 0u;
-        k = s + ((need2 + wo_m1) >> sh_out);                         // first k with ((k - s) << sh_out) + wp >= need
-        if (k < prev_pos) k = prev_pos;
-        e_k = base + ((k - s) << sh_out) + wp;
-    }
-    return k;
-}
-
+// adjacency index (one vrec load when the vertex is entered).  (solve_out_run: seqscan.h)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct VertexCtx {

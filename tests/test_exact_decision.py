@@ -122,3 +122,72 @@ def test_float64_flavour_of_the_dense_kernel(w_out, w_prev):
         ok = exact != AMBIGUOUS
         assert np.array_equal(exact[ok], chain[ok]), (n, w_out, w_prev)
         assert ok[:300].mean() > 0.99             # float64 drift is far below one unit: practically always decided
+
+
+# ---- the lane kernel's per-thread form of the same decision (seqscan.h: lane_decide) ---------------------------
+LANE_AMBIGUOUS = 0xFFFFFFFD
+LANE_REDO = 0xFFFFFFFC
+
+
+def lane_decide(cls, w_out, w_prev, r):
+    lib = _lib.load()
+    cls = np.ascontiguousarray(cls, dtype=np.uint8)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    chain = np.empty(r.size, dtype=np.uint32)
+    lane = np.empty(r.size, dtype=np.uint32)
+    kmax = np.empty(r.size, dtype=np.uint32)
+    _lib.check(lib.pw_selftest_lane_decide(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
+                                           r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
+                                           lane.ctypes.data_as(C.c_void_p), kmax.ctypes.data_as(C.c_void_p)))
+    return chain, lane, kmax
+
+
+@pytest.mark.parametrize("w_out,w_prev", BIASES)
+def test_lane_decision_from_common_neighbour_positions(w_out, w_prev):
+    """One thread, bisection over the positions of the common neighbours + closed-form "out" runs: decided
+    indices equal the float32 chain; undecided ones need no more than kmax leading positions; and the
+    decision agrees with the wave kernel's rank-search form on which targets are decided."""
+    rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 7)
+    decided = total = 0
+    for n in (1, 2, 3, 7, 40, 64, 65, 300, 1500, 6000):
+        for p_common in (0.0, 0.02, 0.3, 0.9, 1.0):
+            for with_prev in (False, True):
+                cls = random_row(rng, n, p_common, with_prev)
+                c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
+                cd = c32.astype(np.float64)
+                targets = [rng.random(300), cd, np.nextafter(cd, 0.0), np.nextafter(cd, 2.0), exact_cdf,
+                           np.nextafter(exact_cdf, 0.0), np.nextafter(exact_cdf, 2.0),
+                           np.array([0.0, 1e-300, 1 - 2.0 ** -53])]
+                r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
+                chain, lane, kmax = lane_decide(cls, w_out, w_prev, r)
+                assert not (lane == LANE_REDO).any()
+                ok = lane != LANE_AMBIGUOUS
+                assert np.array_equal(lane[ok], chain[ok]), (n, p_common, with_prev, w_out, w_prev)
+                amb = ~ok
+                assert ((chain[amb] < kmax[amb]) | (chain[amb] == n)).all()
+                assert (kmax[amb] <= n).all()
+                _, exact = decide(cls, w_out, w_prev, r)
+                assert np.array_equal(exact != AMBIGUOUS, ok)      # same bound, same verdicts
+                decided += int(ok[:300].sum())
+                total += 300
+    assert decided / total > 0.5
+
+
+def test_lane_decision_first_step_row():
+    """First step of a walk: no prev, every neighbour weighs 1 (w_out passed as 1.0)."""
+    rng = np.random.default_rng(11)
+    for n in (1, 5, 64, 1000, 70000):
+        cls = np.zeros(n, dtype=np.uint8)
+        r = np.concatenate([rng.random(2000), (np.arange(1, min(n, 500) + 1) / n)])
+        r = np.clip(r, 0.0, np.nextafter(1.0, 0.0))
+        chain, lane, kmax = lane_decide(cls, 1.0, 2.0, r)
+        ok = lane != LANE_AMBIGUOUS
+        assert np.array_equal(lane[ok], chain[ok])
+        assert ((chain[~ok] < kmax[~ok]) | (chain[~ok] == n)).all()
+
+
+def test_lane_decision_row_outside_exact_range_is_redone():
+    cls = np.zeros(40, dtype=np.uint8)
+    cls[3] = 2
+    _, lane, _ = lane_decide(cls, 2.0 ** -30, 1.0, np.array([0.3]))   # total 39 * 2^-30 + 1 is not a float32
+    assert lane[0] == LANE_REDO
