@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- walk-generation throughput of the MI355X engine (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--scale S]
+    python bench.py --gpus N --steps K --warmup W [--config headline|C2|C3|C4|C5] [--scale S]
 
-One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels + for
-N > 1 the one gather of the walk shards on rank 0) over the whole job array of the workload: RMAT-S (default S = 22, the
-configuration the BASELINE metric is quoted on), SparseOTF p = 0.5 q = 2, 10 walks x 80 steps per
-vertex, seed 0.  Graph, shuffled start array and output buffers are resident in HBM before the
-timed region.  N > 1: one process per GPU (torchrun), graph replicated, job array sharded, strong
-scaling (total work fixed); the walk shards are gathered once on rank 0 over RCCL/xGMI inside the
-timed region (BASELINE's north star); --no-gather leaves every shard in the HBM of the GPU that
-produced it (the jobs are independent: no data-path collective is needed to use them shard-locally).
-Rank 0 prints ONE JSON line.
+One "step" = one full pass of the hot path (MT19937 stream expansion + all walk kernels + for N > 1 the one
+gather of the walk shards on rank 0) over the whole job array of the workload.  Default workload = the
+configuration the BASELINE metric is quoted on: RMAT-22, SparseOTF p = 0.5 q = 2, 10 walks x 80 steps per
+vertex, seed 0.  --config selects the other BASELINE.json configurations:
+    C2  RMAT-18 SparseOTF p=0.5 q=2          C3  RMAT-22 SparseOTF p=0.25 q=4
+    C4  ER N=100k density 0.25 DenseOTF p=0.5 q=2 (generated on the device as packed adjacency bits)
+    C5  weighted RMAT-20, node2vec+ (--extend, gamma 0), SparseOTF p=0.5 q=2
+Graph, shuffled start array and output buffers are resident in HBM before the timed region.  N > 1: one process
+per GPU; when WORLD_SIZE is not set the script launches the N ranks itself (torch.distributed.run, 127.0.0.1).
+Graph replicated, job array sharded, strong scaling (total work fixed); the walk shards are gathered once on rank 0
+over RCCL/xGMI inside the timed region (--no-gather leaves every shard on the GPU that produced it).  Rank 0 prints
+ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -24,7 +28,16 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RANDOM_SECTOR_GBS = 3100.0     # measured: scattered 64-byte sectors, profiles/r02_fetch_calibration.txt
+
+CONFIGS = {
+    "headline": dict(graph="rmat", scale=22, p=0.5, q=2.0, mode="SparseOTF", weighted=False, extend=False),
+    "C2": dict(graph="rmat", scale=18, p=0.5, q=2.0, mode="SparseOTF", weighted=False, extend=False),
+    "C3": dict(graph="rmat", scale=22, p=0.25, q=4.0, mode="SparseOTF", weighted=False, extend=False),
+    "C4": dict(graph="er", n=100000, density=0.25, p=0.5, q=2.0, mode="DenseOTF", weighted=False, extend=False),
+    "C5": dict(graph="rmat", scale=20, p=0.5, q=2.0, mode="SparseOTF", weighted=True, extend=True),
+}
 
 
 def parse():
@@ -32,13 +45,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scale", type=int, default=22, help="RMAT scale (22 = headline config)")
-    ap.add_argument("--p", type=float, default=0.5)
-    ap.add_argument("--q", type=float, default=2.0)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline")
+    ap.add_argument("--scale", type=int, default=None, help="RMAT scale (overrides the config's)")
+    ap.add_argument("--er-nodes", type=int, default=None, help="ER vertex count (overrides C4's 100000)")
+    ap.add_argument("--p", type=float, default=None)
+    ap.add_argument("--q", type=float, default=None)
     ap.add_argument("--num-walks", type=int, default=10)
     ap.add_argument("--walk-length", type=int, default=80)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--weighted", action="store_true")
+    ap.add_argument("--weighted", action="store_true", help="hashed U(0,1] edge weights (RMAT configs)")
+    ap.add_argument("--extend", action="store_true", help="node2vec+ (weighted graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-chunks", type=int, default=4,
@@ -48,9 +64,21 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(walks, deg, L):
-    """Exact algorithmic bytes of a walk matrix: per sampled step
-    8*d_cur + 4*d_prev + 28 (first step of a walk: 8*d_cur + 20)."""
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def reference_format_bytes(walks, deg, L):
+    """bytes the REFERENCE's data layout moves for these walks -- per sampled step
+    8*d_cur + 4*d_prev + 28 (first step of a walk: 8*d_cur + 20).  Reported for comparison only: the lane kernel
+    does not stream rows, so this figure is not what its roofline is computed from."""
     import torch
 
     total = 0
@@ -58,33 +86,61 @@ def algorithmic_bytes(walks, deg, L):
     chunk = 1 << 20
     for lo in range(0, n, chunk):
         w = walks[lo:lo + chunk].long() & 0xFFFFFFFF
-        ln = w[:, L + 1]                       # effective length (nodes)
-        steps = (ln - 1).clamp(min=0)          # sampled transitions
+        ln = w[:, L + 1]
+        steps = (ln - 1).clamp(min=0)
         idx = torch.arange(L, device=w.device).unsqueeze(0)
-        valid = idx < steps.unsqueeze(1)       # step j+1 sampled from node w[:, j]
+        valid = idx < steps.unsqueeze(1)
         d_cur = deg[w[:, :L]] * valid
         total += int((8 * d_cur).sum().item())
         total += int((28 * valid).sum().item())
-        first = valid[:, 0].sum().item()
-        total -= int(8 * first)                # first step: +20 instead of +28
-        # d_prev of step j+1 (j >= 1) is the degree of w[:, j-1]
+        total -= int(8 * valid[:, 0].sum().item())
         d_prev = deg[w[:, : L - 1]] * valid[:, 1:]
         total += int((4 * d_prev).sum().item())
     return total
 
 
+def er_bits_gpu(n, density, dev, seed=1):
+    """Packed adjacency (int64 words, bit x of row u <=> edge u-x) of an undirected ER graph, built on the GPU."""
+    import torch
+
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    wpr = (n + 63) // 64
+    adj = torch.zeros((n, wpr * 64), dtype=torch.bool, device=dev)
+    rows_per = max(1, (1 << 28) // n)
+    cols = torch.arange(n, device=dev)
+    for lo in range(0, n, rows_per):
+        hi = min(n, lo + rows_per)
+        u = torch.rand((hi - lo, n), generator=gen, device=dev) < density
+        u &= cols.unsqueeze(0) > torch.arange(lo, hi, device=dev).unsqueeze(1)   # strict upper triangle
+        adj[lo:hi, :n] = u
+    adj[:, :n] |= adj[:, :n].t().clone()
+    w32 = (adj.view(n, wpr * 2, 32).to(torch.int64) * (1 << torch.arange(32, device=dev, dtype=torch.int64))).sum(-1)
+    bits = w32[:, 0::2] | (w32[:, 1::2] << 32)
+    deg = adj[:, :n].sum(1)
+    return bits.contiguous(), deg
+
+
+def load_pmc(key):
+    """HBM-side traffic and issue counters of this exact workload from the committed rocprofv3 --pmc passes
+    (profiles/r02_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
+    inside a timed run."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as f:
+            return json.load(f)["workloads"].get(key)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)   # does not return
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torchrun with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
     # PECANPY_BENCH_BACKEND=gloo + PECANPY_BENCH_ONE_GPU=1: dry-run of the multi-rank path on a box
     # with a single GPU (RCCL refuses two ranks on one device); the driver's runs use nccl (= RCCL).
     backend = os.environ.get("PECANPY_BENCH_BACKEND", "nccl")
@@ -103,23 +159,62 @@ def main():
     from pecanpy_amd.engine import WalkEngine, shard_bounds
     from pecanpy_amd.synth import rmat_csr
 
+    cfg = dict(CONFIGS[args.config])
+    if args.scale is not None:
+        cfg["scale"] = args.scale
+    if args.er_nodes is not None:
+        cfg["n"] = args.er_nodes
+    if args.p is not None:
+        cfg["p"] = args.p
+    if args.q is not None:
+        cfg["q"] = args.q
+    if args.weighted:
+        cfg["weighted"] = True
+    if args.extend:
+        cfg["extend"] = cfg["weighted"] = True
+    p, q, mode, extend = cfg["p"], cfg["q"], cfg["mode"], cfg["extend"]
     L, W = args.walk_length, args.num_walks
+
     t0 = time.time()
-    indptr, indices, data = rmat_csr(args.scale, seed=1, weighted=args.weighted)
-    n_nodes = indptr.size - 1
-    t_graph = time.time() - t0
+    indptr = indices = data = None
+    if cfg["graph"] == "rmat":
+        indptr, indices, data = rmat_csr(cfg["scale"], seed=1, weighted=cfg["weighted"])
+        n_nodes = indptr.size - 1
+        t_graph = time.time() - t0
+        eng = WalkEngine.from_csr(indptr, indices, data, device=local_rank)
+        if extend:
+            from pecanpy_amd import pecanpy as node2vec
+
+            g = node2vec.SparseOTF.from_csr(indptr, indices, data, extend=True, gamma=0)
+            with np.errstate(all="ignore"):
+                eng.set_thresholds(np.nan_to_num(g.get_noise_thresholds(), nan=0.0))
+        has_nbr = indptr[1:] != indptr[:-1]
+        nnz = int(indices.size)
+        gdesc = (f"RMAT-{cfg['scale']} (Graph500 a,b,c=.57,.19,.19, edge factor 8, symmetrised"
+                 f"{', hashed U(0,1] weights' if cfg['weighted'] else ', unweighted'})")
+        key_graph = f"rmat{cfg['scale']}{'w' if cfg['weighted'] else ''}"
+    else:
+        n_nodes = cfg["n"]
+        bits, deg_t = er_bits_gpu(n_nodes, cfg["density"], dev)
+        torch.cuda.synchronize()
+        t_graph = time.time() - t0
+        eng = WalkEngine.from_dense_bits(bits, n_nodes, device=local_rank)
+        del bits
+        has_nbr = (deg_t > 0).cpu().numpy()
+        nnz = int(deg_t.sum().item())
+        gdesc = f"Erdos-Renyi N={n_nodes} density {cfg['density']} (undirected, unweighted, packed adjacency bits)"
+        key_graph = f"er{n_nodes}"
+    info = eng.index_info()
     nodes = np.arange(n_nodes, dtype=np.uint32)
     starts = np.concatenate([nodes] * W)
     np.random.RandomState(args.seed).shuffle(starts)   # legacy seeded shuffle, as the reference
     n_jobs = starts.size
     t_prep = time.time() - t0
 
-    eng = WalkEngine.from_csr(indptr, indices, data, device=local_rank)
     lo, hi = shard_bounds(n_jobs, world)[rank]
     d_starts = torch.from_numpy(starts[lo:hi].view(np.int32)).to(dev)
     d_out = torch.empty((hi - lo, L + 2), dtype=torch.int32, device=dev)
     # stream address of this shard (undirected graph: nominal counts are exact)
-    has_nbr = (indptr[1:] != indptr[:-1])
     skip = int(has_nbr[starts[:lo]].sum()) * L
     do_gather = world > 1 and not args.no_gather
     # N > 1 with gather: the shard is walked in a few chunks and the gather of chunk c (async, on RCCL's
@@ -137,26 +232,24 @@ def main():
             pads.append(pad)
             parts.append([torch.empty_like(pad) for _ in range(world)] if rank == 0 else None)
 
-    kernel_ms, rng_ms, pass_steps = [], [], []
+    acc = {k: [] for k in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "total_steps", "list_entries_read",
+                           "ambiguous_steps", "redo_walks", "overflow_reads")}
 
     def one_pass():
-        k_ms = r_ms = 0.0
-        steps = 0
+        tot = {k: 0 for k in acc}
         works = []
         for c, (a, b) in enumerate(chunk_bounds):
-            eng.simulate_device("SparseOTF", args.p, args.q, False, d_starts[a:b], L, seed=args.seed,
+            eng.simulate_device(mode, p, q, extend, d_starts[a:b], L, seed=args.seed,
                                 stream_skip=chunk_skip[c], out=d_out[a:b])
-            k_ms += eng.last_stats["walk_kernel_ms"]
-            r_ms += eng.last_stats["rng_kernel_ms"]
-            steps += eng.last_stats["total_steps"]
+            for k in tot:
+                tot[k] += eng.last_stats[k]
             if do_gather:  # gather of this chunk over RCCL/xGMI while the next chunk is walked
                 pads[c][: b - a] = d_out[a:b].to(cdev)
                 works.append(dist.gather(pads[c], parts[c], dst=0, async_op=True))
         for w in works:
             w.wait()
-        kernel_ms.append(k_ms)
-        rng_ms.append(r_ms)
-        pass_steps.append(steps)
+        for k in tot:
+            acc[k].append(tot[k])
 
     def fence():
         torch.cuda.synchronize()
@@ -166,8 +259,8 @@ def main():
 
     for _ in range(args.warmup):
         one_pass()
-    kernel_ms.clear()
-    rng_ms.clear()
+    for k in acc:
+        acc[k].clear()
     fence()
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,9 +273,14 @@ def main():
         elapsed = float(tmax.item())
 
     st = eng.last_stats
-    shard_steps = torch.tensor([pass_steps[-1]], dtype=torch.int64, device=cdev)
+    shard_steps = torch.tensor([acc["total_steps"][-1]], dtype=torch.int64, device=cdev)
+    per_rank_ms = torch.tensor([float(np.mean(acc["walk_kernel_ms"]))], dtype=torch.float64, device=cdev)
+    rank_ms = [float(per_rank_ms.item())]
     if world > 1:
         dist.all_reduce(shard_steps)
+        outs = [torch.zeros_like(per_rank_ms) for _ in range(world)]
+        dist.all_gather(outs, per_rank_ms)
+        rank_ms = [float(o.item()) for o in outs]
     total_steps = int(shard_steps.item())           # sampled transitions of the whole job array
     sec_per_step = elapsed / max(args.steps, 1)
     value = total_steps / sec_per_step / 1e6
@@ -200,43 +298,65 @@ def main():
             cb = shard_bounds(b_all[r][1] - b_all[r][0], n_chunks)
             rows_of.append(torch.cat([parts[c][r][: cb[c][1] - cb[c][0]] for c in range(n_chunks)], dim=0))
         gathered = torch.cat(rows_of, dim=0).to(dev)
-        whole = eng.simulate_device("SparseOTF", args.p, args.q, False,
-                                    torch.from_numpy(starts.view(np.int32)).to(dev), L, seed=args.seed)
+        whole = eng.simulate_device(mode, p, q, extend, torch.from_numpy(starts.view(np.int32)).to(dev), L, seed=args.seed)
         assert torch.equal(gathered, whole), "gathered shards differ from the single-stream matrix"
         print("bench.py: gathered shards verified against a whole-array run", file=sys.stderr)
 
-    # roofline of the dominant kernel (walk_sparse_kernel), rank 0's shard
-    deg_t = torch.from_numpy(np.diff(indptr.astype(np.int64))).to(dev)
-    alg_bytes = algorithmic_bytes(d_out, deg_t, L)
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE), when this
-    # exact workload was profiled (profiles/r01_traffic.json); PMC cannot be collected in a timed run
-    traffic = None
-    traffic_note = "no PMC pass committed for this workload"
-    key = f"rmat{args.scale}_p{args.p:g}_q{args.q:g}_w{W}_l{L}_seed{args.seed}"
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f)["workloads"].get(key)
-        if tj and world == 1 and not args.weighted:
-            traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
-            traffic_note = ("FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch "
-                            "(profiles/r01_rmat22_pmc_v13.txt), uncorrected (scattered 4-8 B/lane probes)")
-    except (OSError, KeyError, ValueError):
-        pass
+    # ---- roofline of the dominant kernel (rank 0's shard) ------------------------------------------------------
+    lane = bool(st["lane_kernel"])
+    k_ms = float(np.mean(acc["lane_kernel_ms"] if lane else acc["walk_kernel_ms"]))
+    steps0 = int(acc["total_steps"][-1])
+    walks0 = int(has_nbr[starts[lo:hi]].sum())
+    ref_bytes = None
+    if cfg["graph"] == "rmat":
+        deg_t = torch.from_numpy(np.diff(indptr.astype(np.int64))).to(dev)
+        ref_bytes = reference_format_bytes(d_out, deg_t, L)
+    if lane:
+        # declared format of the lane kernel: per sampled step one 32-byte edge record, one
+        # 8-byte draw, one 4-byte output cell, 4 bytes per common-neighbour list entry actually read (counted in
+        # the kernel); per walk: start 4 + stream offset 8 + vertex record 16 + header/length cells 8
+        entries = int(acc["list_entries_read"][-1])
+        declared = steps0 * (32 + 8 + 4) + entries * 4 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) + (hi - lo - walks0) * 8
+        kernel = "walk_lanes_kernel"
+        fmt = ("32 B edge record + 8 B draw + 4 B output per step, 4 B per common-neighbour list entry read "
+               "(in-kernel counter), 36 B per walk")
+    elif cfg["graph"] == "er":
+        wpr = (n_nodes + 63) // 64
+        declared = steps0 * (3 * wpr * 8 + 12)
+        kernel = "walk_dense_bits_kernel"
+        fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
+    else:
+        # the wave-per-walk kernel streams rows (keys of the shorter row, weights of cur's row): SURVEY 8(d)'s
+        # figure in the reference's element sizes is its declared format
+        declared = ref_bytes
+        kernel = "walk_kernel<float,false,%s,%s>" % ("true" if not cfg["weighted"] else "false", "true" if extend else "false")
+        fmt = "SURVEY 8(d): 8*d_cur + 4*d_prev + 28 per step (rows are streamed by this kernel)"
+    achieved = declared / (k_ms * 1e-3) / 1e9
+    key = f"{key_graph}_{mode}_p{p:g}_q{q:g}{'_ext' if extend else ''}_w{W}_l{L}_seed{args.seed}"
+    pmc = load_pmc(key) if world == 1 else None
+    traffic = int(pmc["fetch_bytes"] + pmc["write_bytes"]) if pmc else None
     roofline = {
-        "bound": "hbm", "kernel": "walk_kernel<float,false,true,false>", "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
-        "avg_launch_ms": round(k_ms, 3), "rng_expand_ms": round(float(np.mean(rng_ms)), 3),
-        "note": "algorithmic bytes = sum over sampled steps of 8*d_cur+4*d_prev+28 (SURVEY 8(d)); "
-                "the kernel never streams whole rows (lazy membership through Bloom filter + hash index "
-                "probes, per-edge common-neighbour counts, closed-form CDF search), so the HBM counters "
-                "show a fraction of the algorithmic bytes and frac exceeds 1",
+        "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "declared_bytes_per_launch": int(declared), "declared_format": fmt,
+        "avg_launch_ms": round(k_ms, 3), "rng_expand_ms": round(float(np.mean(acc["rng_kernel_ms"])), 3),
+        "traffic_note": (pmc["note"] if pmc else "no PMC pass committed for this workload (profiles/r02_traffic.json)"),
+        "random_sector_peak_GBps": RANDOM_SECTOR_GBS,
+        "reference_format_bytes": ref_bytes,
     }
+    if traffic:
+        roofline["traffic_GBps"] = round(traffic / (k_ms * 1e-3) / 1e9, 1)
+        roofline["traffic_frac_of_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["traffic_frac_of_random_sector_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / RANDOM_SECTOR_GBS, 4)
+    if pmc and "issue" in pmc:
+        roofline["issue_bound"] = pmc["issue"]
+    if lane:
+        roofline["ambiguous_step_frac"] = round(acc["ambiguous_steps"][-1] / max(steps0, 1), 5)
+        roofline["list_entries_per_step"] = round(acc["list_entries_read"][-1] / max(steps0, 1), 2)
+        roofline["redo_walks"] = int(acc["redo_walks"][-1])
 
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and cfg["graph"] == "rmat" and not extend:
         from oracle import pyoracle as orc
 
         # thread count: the box may expose more logical CPUs than the container can run on (affinity mask,
@@ -261,7 +381,7 @@ def main():
         probed = {}
         for c in cand:
             t = time.perf_counter()
-            s, _ = orc.cpu_baseline_walks(indptr, indices, data, args.p, args.q, probe, L, args.seed,
+            s, _ = orc.cpu_baseline_walks(indptr, indices, data, p, q, probe, L, args.seed,
                                           n_threads=c, faithful=True)
             probed[c] = max(s, 1) / (time.perf_counter() - t)
         cores = max(probed, key=probed.get)
@@ -269,11 +389,11 @@ def main():
         n_sample = int(min(n_jobs, max(20000, rate * args.cpu_seconds / max(s / probe.size, 1e-9))))
         sample = starts[:n_sample]
         t = time.perf_counter()
-        s_f, _ = orc.cpu_baseline_walks(indptr, indices, data, args.p, args.q, sample, L, args.seed,
+        s_f, _ = orc.cpu_baseline_walks(indptr, indices, data, p, q, sample, L, args.seed,
                                         n_threads=cores, faithful=True)
         dt_f = time.perf_counter() - t
         t = time.perf_counter()
-        s_t, _ = orc.cpu_baseline_walks(indptr, indices, data, args.p, args.q, sample, L, args.seed,
+        s_t, _ = orc.cpu_baseline_walks(indptr, indices, data, p, q, sample, L, args.seed,
                                         n_threads=cores, faithful=False)
         dt_t = time.perf_counter() - t
         cpu_model = ""
@@ -295,8 +415,10 @@ def main():
             "probe_msteps_per_s_by_threads": {str(c): round(v / 1e6, 3) for c, v in probed.items()},
         }
 
+    build_s = info["build_ms"] * 1e-3
     result = {
-        "metric": f"million walk-steps/sec on RMAT-{args.scale} SparseOTF p={args.p:g} q={args.q:g}",
+        "metric": f"million walk-steps/sec on {gdesc.split(' (')[0]} {mode} p={p:g} q={q:g}"
+                  f"{' node2vec+' if extend else ''}",
         "value": round(value, 3),
         "unit": "million walk-steps/s",
         "n_gpus": world,
@@ -306,19 +428,27 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f64" if mode == "DenseOTF" else "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"RMAT-{args.scale} (Graph500 a,b,c=.57,.19,.19, edge factor 8, symmetrised"
-                        f"{', hashed U(0,1] weights' if args.weighted else ', unweighted'}) SparseOTF "
-                        f"p={args.p:g} q={args.q:g}, {W} walks x {L} steps per vertex, random_state={args.seed}",
-            "n_nodes": int(n_nodes), "nnz": int(indices.size), "n_jobs": int(n_jobs),
+            "workload": f"{gdesc} {mode}{' node2vec+ (extend, gamma 0)' if extend else ''} "
+                        f"p={p:g} q={q:g}, {W} walks x {L} steps per vertex, random_state={args.seed}",
+            "baseline_config": args.config,
+            "n_nodes": int(n_nodes), "nnz": nnz, "n_jobs": int(n_jobs),
             "effective_steps_per_pass": total_steps, "nominal_steps_per_pass": int(n_jobs) * L,
             "nominal_value": round(int(n_jobs) * L / sec_per_step / 1e6, 3),
             "parallelism": f"jobs sharded over {world} GPU(s), graph replicated",
             "gather_on_rank0": bool(do_gather), "gather_chunks": n_chunks if do_gather else 0,
+            "per_rank_walk_kernel_ms": [round(x, 3) for x in rank_ms],
             "overflow_reads": st["overflow_reads"], "host_prep_s": round(t_prep, 1),
             "graph_gen_s": round(t_graph, 1),
+            # per-graph index built once by pw_csr_create (membership filters, adjacency index, per-edge
+            # common-neighbour lists and records); NOT in the timed region -- the second figure charges it to
+            # ONE pass of 10 x 80 walks (every rank builds its own replica)
+            "graph_index_build_ms": round(info["build_ms"], 1),
+            "graph_index_bytes": info["index_bytes"],
+            "lane_list_entries": info["lane_list_entries"],
+            "value_incl_index_build": round(total_steps / (sec_per_step + build_s) / 1e6, 3),
         },
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -227,6 +227,13 @@ vrec_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restric
     vrec[v] = make_uint4(indptr[v], v < n_nodes ? indptr[v + 1] - indptr[v] : 0u, foff[v], (uint32_t)(tab_off[v] >> 1));
 }
 
+// flag = index of the first start vertex that is not a vertex of the graph (atomicMin, ~0 = none)
+__global__ void __launch_bounds__(256)
+starts_check_kernel(const uint32_t *__restrict__ starts, uint64_t n_jobs, uint32_t n_nodes, unsigned long long *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_jobs && starts[i] >= n_nodes) atomicMin(flag, (unsigned long long)i);
+}
+
 __global__ void csr_edge_rows_kernel(const uint32_t *__restrict__ indptr, uint32_t n_nodes, uint32_t *edge_row) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
     const uint32_t n_waves = (gridDim.x * blockDim.x) / 64;

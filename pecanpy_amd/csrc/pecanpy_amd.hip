@@ -555,6 +555,20 @@ static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t
     return 0;
 }
 
+// every start must be a vertex (the kernels index indptr / the vertex records with it)
+static int check_starts(pw_graph *g, const uint32_t *d_starts, uint64_t n_jobs) {
+    if (!n_jobs) return 0;
+    unsigned long long bad = ~0ull;
+    HIP_TRY(hipMemcpyAsync(g->counters.p + 9, &bad, sizeof(bad), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(pw::starts_check_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, g->stream, d_starts,
+                       n_jobs, g->n_nodes, g->counters.p + 9);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&bad, g->counters.p + 9, sizeof(bad), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (bad != ~0ull) return fail(PW_ERR_INVALID, "start vertex out of range at job " + std::to_string(bad));
+    return 0;
+}
+
 PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
                                     uint32_t walk_length, uint64_t *out_draws) {
     if (!g || !starts || !out_draws) return fail(PW_ERR_INVALID, "null pointer");
@@ -566,6 +580,7 @@ PW_EXPORT int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_
     int rc = 0;
     uint64_t tot = 0;
     if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    if (!rc) rc = check_starts(g, d_starts, n_jobs);
     if (!rc && n_jobs) rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, 0, false, &tot, nullptr);
     (void)hipFree(d_starts);
     *out_draws = tot;
@@ -844,6 +859,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (n_jobs == 0) { if (stats) *stats = st; return PW_OK; }
     if (!has_seed) seed = os_seed();
     if (g->counters.ensure(N_COUNTERS)) return PW_ERR_NOMEM;
+    { int rcs = check_starts(g, d_starts, n_jobs); if (rcs) return rcs; }
     if (mode >= PW_MODE_PRECOMP) {
         if (stream_skip) return fail(PW_ERR_UNSUPPORTED, "alias / first-order modes consume a variable number of "
                                                          "words per step: the stream cannot be sharded");

@@ -85,6 +85,13 @@ class WalkEngine:
             raise ValueError("threshold array must have one entry per node")
         _lib.check(self._lib.pw_graph_set_thresholds(self._h, _np_ptr(thr)))
 
+    def index_info(self):
+        """Device time (ms) and bytes of the per-graph index built at creation, and the number of entries of the
+        lane kernel's common-neighbour lists (0 when that index was not built)."""
+        ms, nbytes, entries = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.pw_graph_index_info(self._h, C.byref(ms), C.byref(nbytes), C.byref(entries)))
+        return {"build_ms": float(ms.value), "index_bytes": int(nbytes.value), "lane_list_entries": int(entries.value)}
+
     def close(self):
         if self._h is not None and self._h.value:
             self._lib.pw_graph_destroy(self._h)

@@ -72,6 +72,8 @@ class Base(BaseGraph):
         self._preprocessed = False
         self._engine = None
         self._engine_key = None
+        self._thr_key = None
+        self._run_seed = None
         self.device = None  # GPU index; None -> LOCAL_RANK / 0
         self.last_stats = None
 
@@ -96,8 +98,10 @@ class Base(BaseGraph):
                 self._engine.close()
             self._engine = self._make_engine(self._device_index())
             self._engine_key = key
-            if self.extend:
-                self._engine.set_thresholds(self.get_noise_thresholds())
+            self._thr_key = None
+        if self.extend and self._thr_key != (self.gamma,):   # gamma may change between calls
+            self._engine.set_thresholds(self.get_noise_thresholds())
+            self._thr_key = (self.gamma,)
         return self._engine
 
     # ---- reference API ---------------------------------------------------------------------
@@ -107,11 +111,36 @@ class Base(BaseGraph):
         ids = self.nodes
         return [ids[i] for i in walk_idx_ary[:n].tolist()]
 
-    def _start_array(self, num_walks):
+    @staticmethod
+    def _dist():
+        """``torch.distributed`` when this process is one rank of a multi-rank job, else ``None`` (torch is only
+        needed for the multi-GPU path)."""
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+        return None
+
+    def _call_seed(self):
+        """Seed of this ``simulate_walks`` call.  ``random_state=None`` means entropy from the OS (reference:
+        ``np.random.seed(None)``); across the ranks of a multi-GPU job that entropy must be the same, or every rank
+        would shuffle -- and then shard -- a different job array: rank 0 draws it and broadcasts it."""
+        if self.random_state is not None:
+            return self.random_state
+        dist = self._dist()
+        if dist is None:
+            return None
+        box = [int(np.random.SeedSequence().generate_state(1)[0])]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def _start_array(self, num_walks, seed=None):
         """Each node ``num_walks`` times, then NumPy's legacy seeded shuffle (pecanpy.py:135-141)."""
         nodes = np.arange(self.num_nodes, dtype=np.uint32)
         starts = np.concatenate([nodes] * num_walks)
-        np.random.seed(self.random_state)
+        np.random.seed(self.random_state if seed is None else seed)
         np.random.shuffle(starts)
         return starts
 
@@ -121,7 +150,8 @@ class Base(BaseGraph):
         ``torch.distributed`` with ``gather=False`` every rank gets ``(rows, (lo, hi))``: its own
         slice [lo, hi) of that matrix, without the final collective."""
         self._preprocess_transition_probs()
-        starts = self._start_array(num_walks)
+        self._run_seed = self._call_seed()
+        starts = self._start_array(num_walks, self._run_seed)
         return self._random_walks(starts, walk_length, gather=gather)
 
     def simulate_walks_corpus(self, num_walks, walk_length):
@@ -133,38 +163,37 @@ class Base(BaseGraph):
         mat = self.simulate_walks_array(num_walks, walk_length)
         return [self._map_walk(row) for row in mat]
 
+    def _note_stats(self, stats):
+        self.last_stats = stats
+        if stats and stats.get("stream_addressing") == 1:
+            import warnings
+
+            warnings.warn(
+                "walks on this sink-heavy directed graph were generated with NOMINAL stream addressing (one fixed "
+                "slot of walk_length draws per walk) after 32 re-addressing passes: reproducible under the seed, "
+                "but not the reference's draw-for-draw assignment (see DESIGN.md section 3)", RuntimeWarning, stacklevel=3)
+
     def _random_walks(self, starts, walk_length, gather=True):
         """GPU replacement of the reference's njit ``_random_walks`` (pecanpy.py:164-210)."""
         eng = self._get_engine()
-        import torch.distributed as dist
-
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        seed = self._run_seed if self.random_state is None else self.random_state
+        if self._dist() is not None:
             if self._mode not in ("SparseOTF", "DenseOTF"):
                 raise NotImplementedError(
                     f"{self._mode} draws a variable number of random words per step; its seeded "
                     "stream cannot be sharded across GPUs -- run it in a single process")
-            return self._random_walks_sharded(eng, starts, walk_length, gather)
-        mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length,
-                           seed=self.random_state)
-        self.last_stats = eng.last_stats
+            return self._random_walks_sharded(eng, starts, walk_length, seed, gather)
+        mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length, seed=seed)
+        self._note_stats(eng.last_stats)
         return mat
 
-    def _random_walks_sharded(self, eng, starts, walk_length, gather=True):
+    def _random_walks_sharded(self, eng, starts, walk_length, seed, gather=True):
         import torch
+        import torch.distributed as dist
 
         from .sharding import sharded_walk_matrix, to_uint32_numpy
 
         dev = torch.device("cuda", eng.device)
-        seed = self.random_state
-        if seed is None:  # every rank must address the same stream
-            import torch.distributed as dist
-
-            box = [int(np.random.SeedSequence().generate_state(1)[0])]
-            dist.broadcast_object_list(box, src=0)
-            seed = box[0]
-
-        import torch.distributed as dist
-
         host_comm = dist.get_backend() == "gloo"  # gloo moves CPU tensors; nccl (= RCCL) device tensors
 
         def run_shard(sl, skip):
@@ -172,11 +201,14 @@ class Base(BaseGraph):
             out = eng.simulate_device(self._mode, self.p, self.q, self.extend, d_starts,
                                       walk_length, seed=seed, stream_skip=skip)
             steps = eng.last_stats["total_steps"] if d_starts.numel() else 0
+            if d_starts.numel() and eng.last_stats["stream_addressing"] == 1:
+                # nominal slots: the shard owns walk_length draws per walk with neighbours, used or not
+                steps = eng.count_stream_draws(sl, walk_length)
             return (out.cpu() if host_comm else out), steps
 
         full = sharded_walk_matrix(run_shard, lambda sl: eng.count_stream_draws(sl, walk_length),
                                    starts, walk_length, gather=gather)
-        self.last_stats = eng.last_stats
+        self._note_stats(eng.last_stats)
         if not gather:
             rows, bounds = full
             return to_uint32_numpy(rows), bounds

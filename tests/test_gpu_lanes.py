@@ -1,0 +1,169 @@
+"""Lane kernel (one walk per lane, csrc/walk_lanes.hip.h) and the input checks of pw_csr_create.
+
+The lane kernel serves unit-weight CSR graphs with power-of-two 1/p, 1/q; every other GPU parity test with such
+parameters already runs on it (the default).  Here: that it IS the kernel that ran, that it equals the
+wave-per-walk kernel and the oracle on cases built to hit its branches (hub rows beyond the LDS window, directed
+graphs with dead ends and missing reverse edges, first steps, overflow reads handed back), and the C-ABI checks."""
+import os
+import socket
+import subprocess
+import sys
+import json
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from pecanpy_amd.engine import PwError, WalkEngine
+from pecanpy_amd.synth import csr_from_edges, rmat_csr
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _wave_engine(indptr, indices, data, monkeypatch):
+    monkeypatch.setenv("PECANPY_AMD_NO_LANES", "1")
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    monkeypatch.delenv("PECANPY_AMD_NO_LANES")
+    return eng
+
+
+@pytest.mark.parametrize("scale,p,q", [(12, 0.5, 2), (13, 0.25, 4), (12, 2, 0.5), (12, 1, 1), (11, 4, 0.125), (12, 1, 0.25)])
+def test_lane_kernel_runs_and_equals_oracle_and_wave_kernel(scale, p, q, monkeypatch):
+    indptr, indices, data = rmat_csr(scale, seed=scale + 20)
+    starts = orc.shuffled_starts(indptr.size - 1, 3, 5)
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 40, 5, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    assert eng.index_info()["lane_list_entries"] > 0
+    got = eng.simulate("SparseOTF", p, q, False, starts, 40, seed=5)
+    st = dict(eng.last_stats)
+    assert st["lane_kernel"] == 1
+    assert np.array_equal(got, want)
+    assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
+    assert st["redo_walks"] >= st["overflow_reads"] > 0 or st["overflow_reads"] == 0
+    wave = _wave_engine(indptr, indices, data, monkeypatch)
+    got_w = wave.simulate("SparseOTF", p, q, False, starts, 40, seed=5)
+    assert wave.last_stats["lane_kernel"] == 0
+    assert np.array_equal(got_w, want)
+
+
+def test_lane_kernel_not_used_outside_its_regime():
+    indptr, indices, data = rmat_csr(10, seed=3)
+    starts = orc.shuffled_starts(indptr.size - 1, 2, 1)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    eng.simulate("SparseOTF", 0.3, 1.7, False, starts, 20, seed=1)          # non-dyadic biases: float chain only
+    assert eng.last_stats["lane_kernel"] == 0
+    _, _, wdata = rmat_csr(10, seed=3, weighted=True)
+    weng = WalkEngine.from_csr(indptr, indices, wdata)
+    weng.simulate("SparseOTF", 0.5, 2, False, starts, 20, seed=1)
+    assert weng.last_stats["lane_kernel"] == 0 and weng.index_info()["lane_list_entries"] == 0
+
+
+def test_lane_kernel_hub_rows_beyond_the_lds_window(monkeypatch):
+    """A 40k-degree hub with thousands of common neighbours: long bisections, ambiguous steps whose float chain
+    slides the 16384-position LDS window, first steps on the hub."""
+    rng = np.random.default_rng(3)
+    n = 60000
+    hub = np.arange(1, 40001)
+    src = [np.zeros(hub.size, dtype=np.int64), rng.integers(1, n, 300000), np.full(3000, 7, dtype=np.int64)]
+    dst = [hub, rng.integers(1, n, 300000), rng.integers(1, n, 3000)]
+    s, d = np.concatenate(src), np.concatenate(dst)
+    keep = s != d
+    s, d = s[keep], d[keep]
+    indptr, indices, data = csr_from_edges(np.concatenate([s, d]), np.concatenate([d, s]), n)
+    starts = np.concatenate([np.zeros(64, dtype=np.uint32), rng.integers(0, n, 2000).astype(np.uint32)])
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 30, 9, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, 30, seed=9)
+    assert eng.last_stats["lane_kernel"] == 1 and eng.last_stats["ambiguous_steps"] > 0
+    assert np.array_equal(got, want)
+    assert eng.last_stats["overflow_reads"] == ost.overflow_reads
+
+
+def test_lane_kernel_directed_graph_with_dead_ends(monkeypatch):
+    """Directed: reverse edges mostly missing (rev_pos = not found), sinks end walks early, the stream is
+    re-addressed in repair passes that run the lane kernel on job lists."""
+    rng = np.random.default_rng(8)
+    n = 3000
+    src = rng.integers(0, n, 24000)
+    dst = rng.integers(0, n, 24000)
+    keep = (src != dst) & (src % 50 != 0)            # 2 % of the vertices have no out-edges
+    indptr, indices, data = csr_from_edges(src[keep], dst[keep], n)
+    starts = orc.shuffled_starts(n, 2, 3)
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
+    st = eng.last_stats
+    assert st["lane_kernel"] == 1 and st["dead_end_walks"] > 0
+    if st["stream_addressing"] == 0:
+        assert np.array_equal(got, want)
+        assert st["total_steps"] == ost.total_steps
+    wave = _wave_engine(indptr, indices, data, monkeypatch)
+    got_w = wave.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
+    assert wave.last_stats["stream_addressing"] == st["stream_addressing"]
+    assert np.array_equal(got, got_w)
+
+
+def test_lane_kernel_equals_wave_kernel_at_rmat18(monkeypatch):
+    import torch
+
+    indptr, indices, data = rmat_csr(18, seed=1)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 4)
+    np.random.RandomState(1).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    lanes = WalkEngine.from_csr(indptr, indices, None)
+    wave = _wave_engine(indptr, indices, None, monkeypatch)
+    for p, q in ((0.5, 2.0), (4.0, 0.25)):
+        a = lanes.simulate_device("SparseOTF", p, q, False, d_starts, 80, seed=2)
+        sa = dict(lanes.last_stats)
+        b = wave.simulate_device("SparseOTF", p, q, False, d_starts, 80, seed=2)
+        assert sa["lane_kernel"] == 1 and wave.last_stats["lane_kernel"] == 0
+        assert torch.equal(a, b)
+        assert sa["total_steps"] == wave.last_stats["total_steps"]
+        assert sa["overflow_reads"] == wave.last_stats["overflow_reads"]
+
+
+# ---- input validation at the C ABI --------------------------------------------------------------
+def test_csr_create_rejects_unsorted_duplicate_and_out_of_range_rows():
+    indptr = np.array([0, 3, 5, 6], dtype=np.uint32)
+    good = np.array([0, 1, 2, 0, 2, 1], dtype=np.uint32)
+    WalkEngine.from_csr(indptr, good, None).close()
+    unsorted = good.copy()
+    unsorted[[0, 1]] = unsorted[[1, 0]]
+    with pytest.raises(PwError, match="strictly ascending"):
+        WalkEngine.from_csr(indptr, unsorted, None)
+    dup = good.copy()
+    dup[4] = 0                                            # row 1 = [0, 0]
+    with pytest.raises(PwError, match="row 1"):
+        WalkEngine.from_csr(indptr, dup, None)
+    oob = good.copy()
+    oob[5] = 3                                            # == n_nodes
+    with pytest.raises(PwError, match="column index >= n_nodes"):
+        WalkEngine.from_csr(indptr, oob, None)
+
+
+def test_simulate_rejects_start_vertices_out_of_range():
+    indptr, indices, data = rmat_csr(8, seed=1)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    starts = np.array([0, 5, indptr.size - 1], dtype=np.uint32)       # last one == n_nodes
+    with pytest.raises(PwError, match="start vertex"):
+        eng.simulate("SparseOTF", 0.5, 2, False, starts, 10, seed=0)
+
+
+# ---- bench.py launches its own ranks --------------------------------------------------------------------------
+def test_bench_self_launches_two_ranks_and_gathers():
+    """`python bench.py --gpus 2` without a launcher (the driver's command line): two ranks are started, walk
+    their shards on the one GPU of the box (gloo for the gather), and the gathered matrix equals a whole-array
+    run (PECANPY_BENCH_VERIFY)."""
+    env = dict(os.environ, PECANPY_BENCH_BACKEND="gloo", PECANPY_BENCH_ONE_GPU="1", PECANPY_BENCH_VERIFY="1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--scale", "16", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "gathered shards verified" in res.stderr
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["gather_on_rank0"] is True
+    assert len(rec["config"]["per_rank_walk_kernel_ms"]) == 2
+    assert rec["roofline"]["frac"] <= 1.0

@@ -98,3 +98,152 @@ def test_full_size_lazy_step_equals_eager_step(run, monkeypatch):
         a = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
         b = eager.simulate_device("SparseOTF", p, q, False, run["d_starts"][: 1 << 21].contiguous(), L, seed=3)
         assert torch.equal(a, b), (p, q)
+
+
+@pytest.mark.parametrize("p,q", [(0.5, 2.0), (0.25, 4.0)])
+def test_full_size_oracle_prefix(run, p, q):
+    """BASELINE size against the oracle itself: the first 20 000 jobs of the shuffled job array (stream offset 0,
+    so they are exactly the head of the whole run) -- bit-exact walks and the same mirrored overflow reads."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    n = 20000
+    data = np.ones(run["indices"].size, dtype=np.float32)
+    want, ost = orc.walks_sparse_otf(run["indptr"], run["indices"], data, p, q, run["starts"][:n], L, SEED, return_stats=True)
+    got = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"][:n].contiguous(), L, seed=SEED)
+    st = dict(run["eng"].last_stats)
+    got = got.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want)
+    assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
+    if (p, q) == (0.5, 2.0):
+        assert np.array_equal(run["out"][:n].cpu().numpy().view(np.uint32), want)
+
+
+# ---- BASELINE C5: weighted RMAT-20, node2vec+ ------------------------------------------------------------------------
+C5_SCALE = int(os.environ.get("PECANPY_TEST_C5_SCALE", "20"))
+
+
+@pytest.fixture(scope="module")
+def c5():
+    import torch
+
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, data = rmat_csr(C5_SCALE, seed=1, weighted=True)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * W)
+    np.random.RandomState(SEED).shuffle(starts)
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, extend=True, gamma=0)
+    with np.errstate(all="ignore"):
+        thr = np.nan_to_num(g.get_noise_thresholds(), nan=0.0)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    eng.set_thresholds(thr)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    out = eng.simulate_device("SparseOTF", 0.5, 2, True, d_starts, L, seed=SEED)
+    return dict(indptr=indptr, indices=indices, data=data, thr=thr, starts=starts, eng=eng, d_starts=d_starts, out=out,
+                stats=dict(eng.last_stats))
+
+
+def test_c5_full_size_properties_and_oracle_prefix(c5):
+    """Weighted RMAT-20 with --extend at its named size: determinism, bookkeeping, every transition an edge, shard
+    invariance, and the first 5 000 jobs bit-exact against the oracle."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    eng, out = c5["eng"], c5["out"]
+    again = eng.simulate_device("SparseOTF", 0.5, 2, True, c5["d_starts"], L, seed=SEED)
+    assert torch.equal(out, again)
+    w = out.long() & 0xFFFFFFFF
+    n = c5["indptr"].size - 1
+    deg = torch.from_numpy(np.diff(c5["indptr"].astype(np.int64))).cuda()
+    st = torch.from_numpy(c5["starts"].astype(np.int64)).cuda()
+    isolated = deg[st] == 0
+    assert torch.equal(w[:, 0], st)
+    assert torch.all(w[isolated, L + 1] == 1) and torch.all(w[~isolated, L + 1] == L + 1)
+    assert int((w[:, L + 1] - 1).sum().item()) == c5["stats"]["total_steps"]
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(c5["indptr"].astype(np.int64)))
+    keys = torch.from_numpy(rows * n + c5["indices"].astype(np.int64)).cuda()
+    bad = 0
+    for lo in range(0, w.shape[0], 1 << 19):
+        blk = w[lo:lo + (1 << 19)]
+        blk = blk[blk[:, L + 1] == L + 1]
+        qk = (blk[:, :L] * n + blk[:, 1:L + 1]).reshape(-1)
+        pos = torch.searchsorted(keys, qk).clamp(max=keys.numel() - 1)
+        bad += int((keys[pos] != qk).sum().item())
+    assert bad <= c5["stats"]["overflow_reads"]
+    n_jobs = c5["starts"].size
+    lo, hi = (5 * n_jobs) // 8, (6 * n_jobs) // 8
+    skip = eng.count_stream_draws(c5["starts"][:lo], L)
+    shard = eng.simulate_device("SparseOTF", 0.5, 2, True, c5["d_starts"][lo:hi].contiguous(), L, seed=SEED, stream_skip=skip)
+    assert torch.equal(shard, out[lo:hi])
+    m = 5000
+    want = orc.walks_sparse_otf(c5["indptr"], c5["indices"], c5["data"], 0.5, 2, c5["starts"][:m], L, SEED, thr=c5["thr"])
+    assert np.array_equal(out[:m].cpu().numpy().view(np.uint32), want)
+
+
+# ---- BASELINE C4: Erdos-Renyi N = 100 000, density 0.25, DenseOTF --------------------------------------------------
+def _er_bits(n, density, seed=1):
+    import torch
+
+    sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from bench import er_bits_gpu
+
+    return er_bits_gpu(n, density, torch.device("cuda", 0), seed=seed)
+
+
+def test_c4_full_size_properties():
+    """ER-100k DenseOTF at its named size through the packed-bits kernel: determinism, bookkeeping, every
+    transition a set adjacency bit, shard invariance."""
+    import torch
+
+    n = int(os.environ.get("PECANPY_TEST_C4_NODES", "100000"))
+    bits, deg = _er_bits(n, 0.25)
+    eng = WalkEngine.from_dense_bits(bits, n)
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * W)
+    np.random.RandomState(SEED).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    out = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts, L, seed=SEED)
+    stats = dict(eng.last_stats)
+    again = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts, L, seed=SEED)
+    assert torch.equal(out, again)
+    w = out.long() & 0xFFFFFFFF
+    assert torch.equal(w[:, 0], torch.from_numpy(starts.astype(np.int64)).cuda())
+    assert torch.all(w[:, L + 1] == L + 1) and int(deg.min().item()) > 0
+    assert stats["total_steps"] == starts.size * L
+    bad = 0
+    for lo in range(0, w.shape[0], 1 << 18):
+        blk = w[lo:lo + (1 << 18)]
+        u, v = blk[:, :L].reshape(-1), blk[:, 1:L + 1].reshape(-1)
+        word = bits.view(-1)[u * bits.shape[1] + (v >> 6)]
+        bad += int((((word >> (v & 63)) & 1) == 0).sum().item())
+    assert bad <= stats["overflow_reads"] + stats["clamped_reads"]
+    lo, hi = (2 * starts.size) // 8, (3 * starts.size) // 8
+    shard = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts[lo:hi].contiguous(), L, seed=SEED, stream_skip=lo * L)
+    assert torch.equal(shard, out[lo:hi])
+
+
+def test_c4_density_oracle_prefix_on_a_20k_slice():
+    """The same generator and kernel at N = 20 000, density 0.25 (rows of ~5 000 neighbours): the first 200 jobs
+    bit-exact against the dense oracle on the unpacked float64 matrix."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    n = 20000
+    bits, _ = _er_bits(n, 0.25, seed=3)
+    eng = WalkEngine.from_dense_bits(bits, n)
+    hb = bits.cpu().numpy().view(np.uint64)
+    adj = np.unpackbits(hb.view(np.uint8), bitorder="little").reshape(n, -1)[:, :n]
+    mat = adj.astype(np.float64)
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 2)
+    np.random.RandomState(5).shuffle(starts)
+    starts = starts[:200]
+    want = orc.walks_dense_otf(mat, 0.5, 2, starts, 40, 5, nonzero=adj.astype(bool))
+    got = eng.simulate("DenseOTF", 0.5, 2, False, starts, 40, seed=5)
+    assert np.array_equal(got, want)

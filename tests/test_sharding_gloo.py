@@ -97,3 +97,30 @@ def test_shard_bounds_cover_the_job_array():
         assert b[0][0] == 0 and b[-1][1] == n
         assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def _unseeded_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, data = rmat_csr(8, seed=2)
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, p=0.5, q=2, random_state=None)
+    seed = g._call_seed()
+    ret[f"seed{rank}"] = seed
+    ret[f"starts{rank}"] = g._start_array(3, seed)
+    dist.destroy_process_group()
+
+
+def test_unseeded_ranks_shuffle_the_same_job_array():
+    """random_state=None (the CLI default) under torch.distributed: every rank must shard the SAME shuffled job
+    array and address the same stream, or nodes get too many / too few walks."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_unseeded_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret["seed0"] is not None and ret["seed0"] == ret["seed1"]
+        assert np.array_equal(ret["starts0"], ret["starts1"])
+        n = ret["starts0"].size // 3
+        assert np.array_equal(np.bincount(ret["starts0"], minlength=n), np.full(n, 3))
