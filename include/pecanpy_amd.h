@@ -72,6 +72,7 @@ typedef struct {
     uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
     uint64_t ambiguous_steps;   /* steps decided by the float32 chain instead of exact integer arithmetic */
     double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
+    uint64_t wave_chain_steps;  /* of the ambiguous steps, those the per-lane chain left to the wave-cooperative chain */
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */
@@ -202,9 +203,15 @@ int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, floa
 /* The same decision as one thread of the lane kernel takes it (csrc/seqscan.h: lane_decide), from the ascending
  * positions of the common neighbours: lane[i] = decided index, 0xfffffffd when the float chain has to decide (then
  * kmax[i] = number of leading positions the chain may need: chain[i] < kmax[i] or chain[i] == n), 0xfffffffc when
- * the row is outside the exact range. */
+ * the row is outside the exact range.  chain_lane (may be NULL) = the float32 chain as ONE thread evaluates it
+ * (csrc/seqscan.h: lane_chain) over the first kmax[i] positions (the whole row when lane[i] is decided):
+ * position, 0xfffffffb when that prefix never reaches r[i], 0xfffffffa on a rounding tie the thread cannot afford
+ * (the walk is then redone by the wavefront kernel).  use_hints != 0: both searches start from the per-list hint
+ * table (csrc/seqscan.h: build_list_hints) -- same results, fewer list reads; probes (may be NULL) = list / hint
+ * entries read per target. */
 int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
-                            uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax);
+                            uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
+                            int use_hints, uint32_t *probes);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

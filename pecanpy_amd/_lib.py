@@ -29,6 +29,7 @@ class PwStats(C.Structure):
         ("list_entries_read", C.c_uint64),
         ("ambiguous_steps", C.c_uint64),
         ("lane_kernel_ms", C.c_double),
+        ("wave_chain_steps", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -76,7 +77,7 @@ SYMBOLS = {
     "pw_selftest_exact_decision": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
                                              C.c_void_p, C.c_void_p]),
     "pw_selftest_lane_decide": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pw_selftest_exact_decision_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p,
                                                  C.c_uint32, C.c_void_p, C.c_void_p]),
     "pw_selftest_seqscan_f32": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32,

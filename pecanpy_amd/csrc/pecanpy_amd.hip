@@ -33,7 +33,8 @@ namespace {
 thread_local std::string g_err;
 
 // pw_graph::counters layout: [0] job counter [1..4] stats [5] changed count [6] redo count [7] list entries read
-// by the lane kernel [8] ambiguous steps (float chain) of the lane kernel
+// by the lane kernel [8] ambiguous steps (float chain) of the lane kernel [9] first bad start [10] ambiguous steps the
+// per-lane chain left to the wave-cooperative chain (rounding ties)
 constexpr int N_COUNTERS = 16;
 
 int fail(int code, const std::string &msg) {
@@ -90,6 +91,10 @@ struct pw_graph {
     uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
     pw::ERec *d_erec = nullptr;                         // lane kernel (walk_lanes.hip.h): 32-byte record per CSR entry
     uint32_t *d_clist = nullptr;                        // lane kernel: per-edge positions of the common neighbours
+    uint32_t *d_hint = nullptr;                         // lane kernel: hint words of the guided list search
+    int hint_in = -1, hint_out = -1;                    // mass units the hints were built for (-1: none yet)
+    bool hint_failed = false;                           // no memory for the hints: plain bisection
+    double hint_build_ms = 0;
     uint64_t n_clist = 0;
     double index_build_ms = 0;                          // device time of all index kernels of pw_csr_create
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
@@ -197,6 +202,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_vrec) (void)hipFree(g->d_vrec);
     if (g->d_erec) (void)hipFree(g->d_erec);
     if (g->d_clist) (void)hipFree(g->d_clist);
+    if (g->d_hint) (void)hipFree(g->d_hint);
     g->redo.release();
     g->stream_off.release();
     g->tile_sums.release();
@@ -261,7 +267,7 @@ static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t need = total * sizeof(uint32_t) + (uint64_t)nnz * sizeof(pw::ERec);
     if (need > free_b / 2) { cleanup(); return 0; }   // leave room for the stream and the walk matrix
-    e = hipMalloc((void **)&g->d_clist, sizeof(uint32_t) * (size_t)(total ? total : 1));
+    e = hipMalloc((void **)&g->d_clist, sizeof(uint32_t) * (size_t)(total + 4));   // + the reach of one search window
     if (e == hipSuccess) e = hipMalloc((void **)&g->d_erec, sizeof(pw::ERec) * (size_t)nnz);
     if (e == hipSuccess) {
         pw::CsrDev c = csr_dev(g);
@@ -273,6 +279,7 @@ static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
     cleanup();
     if (e != hipSuccess) {
         if (g->d_clist) (void)hipFree(g->d_clist);
+    if (g->d_hint) (void)hipFree(g->d_hint);
         if (g->d_erec) (void)hipFree(g->d_erec);
         g->d_clist = nullptr;
         g->d_erec = nullptr;
@@ -785,7 +792,38 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
+    // hint table of the guided list search, for this call's ratio of the "in" and "out" weights
+    int ea = 0;
+    (void)std::frexp(wa.w_out, &ea);   // w_out = 2^(ea - 1)
+    const int hs_out = ea - 1 > 0 ? ea - 1 : 0, hs_in = ea - 1 < 0 ? 1 - ea : 0;
+    // (off unless PECANPY_AMD_HINTS=1: the guided search removes a third of the list reads but the kernel is bound
+    //  by the instructions of the float chains, not by those reads -- DESIGN.md section 9)
+    const bool want_hints = getenv("PECANPY_AMD_HINTS") != nullptr;
+    if (want_hints && !g->hint_failed && g->n_clist && (g->hint_in != hs_in || g->hint_out != hs_out)) {
+        if (!g->d_hint && hipMalloc((void **)&g->d_hint, sizeof(uint32_t) * (size_t)g->n_clist) != hipSuccess) {
+            g->d_hint = nullptr;
+            g->hint_failed = true;
+            (void)hipGetLastError();
+        }
+        if (g->d_hint) {
+            HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+            hipLaunchKernelGGL(pw::hint_build_kernel, dim3((unsigned)(((uint64_t)g->nnz + 255) / 256)), dim3(256), 0, g->stream,
+                               g->d_erec, g->d_clist, g->nnz, (uint32_t)hs_in, (uint32_t)hs_out, g->d_hint);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            float hms = 0;
+            HIP_TRY(hipEventElapsedTime(&hms, g->ev[4], g->ev[5]));
+            g->hint_build_ms = hms;
+            g->hint_in = hs_in;
+            g->hint_out = hs_out;
+        }
+    }
+    const bool use_hints = want_hints && g->d_hint && g->hint_in == hs_in && g->hint_out == hs_out;
     pw::LanesArgs la;
+    la.hint = use_hints ? g->d_hint : nullptr;
+    la.hs_in = (uint32_t)hs_in;
+    la.hs_out = (uint32_t)hs_out;
     la.erec = g->d_erec;
     la.clist = g->d_clist;
     la.vrec = g->d_vrec;
@@ -821,6 +859,23 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     unsigned long long nr = 0;
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+#ifdef PW_PROF_LANES
+    {
+        unsigned long long hp[16], zero[16] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(pw::g_lprof), sizeof(hp)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pw::g_lprof), zero, sizeof(zero)));
+        static const char *names[4] = {"refill", "draw + exact decision", "float chains", "edge record + store"};
+        double tot = 0;
+        for (int i = 0; i < 4; i++) tot += (double)hp[i];
+        for (int i = 0; i < 4; i++)
+            fprintf(stderr, "[lane_prof] %-22s %6.2f%%  %.0f cycles per iteration\n", names[i], 100.0 * hp[i] / tot, (double)hp[i] / (double)hp[8]);
+        for (int bk = 0; bk < 4; bk++)
+            fprintf(stderr, "[lane_prof] chain passes with %s lanes: %llu, %.0f cycles each\n", bk == 0 ? "1-2" : (bk == 1 ? "3-4" : (bk == 2 ? "5-8" : "9+")),
+                    hp[4 + bk], hp[4 + bk] ? (double)hp[12 + bk] / (double)hp[4 + bk] : 0.0);
+        fprintf(stderr, "[lane_prof] iterations %llu  chain passes %llu (%.1f lanes each)  runnable lanes per iteration %.1f\n", hp[8], hp[9],
+                hp[9] ? (double)hp[10] / (double)hp[9] : 0.0, (double)hp[11] / (double)hp[8]);
+    }
+#endif
     float lms = 0;
     HIP_TRY(hipEventElapsedTime(&lms, g->ev[4], g->ev[5]));
     g->lane_ms += lms;
@@ -1040,6 +1095,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.redo_walks = redo_total;
     st.list_entries_read = h[7];
     st.ambiguous_steps = h[8];
+    st.wave_chain_steps = h[10];
     st.lane_kernel_ms = g->lane_ms;
     if (stats) *stats = st;
     return PW_OK;
@@ -1158,7 +1214,8 @@ PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, dou
 
 // ---- host self test of the lane kernel's per-thread decision (seqscan.h: lane_decide) ----------------------------
 PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
-                                      uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax) {
+                                      uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
+                                      int use_hints, uint32_t *probes) {
     if (!cls || !r || !chain || !lane || !kmax || n == 0) return fail(PW_ERR_INVALID, "bad argument");
     auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
     if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
@@ -1174,6 +1231,16 @@ PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_ou
     const double td = (double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev;
     const float tot = (float)td;
     const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
+    // hint table of this list, as the device builds it (units: the smaller of w_out and 1)
+    int ea = 0;
+    (void)std::frexp(w_out, &ea);   // w_out = 2^(ea - 1)
+    const uint32_t hs_out = ea - 1 > 0 ? (uint32_t)(ea - 1) : 0u, hs_in = ea - 1 < 0 ? (uint32_t)(1 - ea) : 0u;
+    const uint32_t n_cl = (uint32_t)cl.size();
+    std::vector<uint32_t> hints(n_cl ? n_cl : 1, 0u);
+    cl.resize((size_t)n_cl + 4, 0xffffffffu);   // the search window may read up to 3 entries past the list end
+    if (use_hints) pw::build_list_hints(cl.data(), n_cl, n, hs_in, hs_out, hints.data());
+    const uint32_t *hp = use_hints ? hints.data() : nullptr;
+    const uint32_t wd = pw::hint_bucket_width(n, n_cl, hs_in, hs_out);
     for (uint32_t i = 0; i < n_r; i++) {
         float c = 0.0f;
         uint32_t kc = n;
@@ -1183,9 +1250,26 @@ PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_ou
         }
         chain[i] = kc;
         pw::LaneStep ls{0.0f, 0u, 0u};
-        lane[i] = pw::lane_decide(n, (uint32_t)cl.size(), pp, r[i], w_out, w_prev, cl.data(), ls);
+        lane[i] = pw::lane_decide(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls, hp, hs_in, hs_out, wd);
+        if (probes) probes[i] = ls.probes;
         kmax[i] = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : 0u;
         if (lane[i] != pw::LANE_REDO && ls.tot != tot) return fail(PW_ERR_INVALID, "row total mismatch");
+        if (chain_lane) {   // the per-thread float chain: over the ambiguous prefix, or the whole row when decided
+            const uint32_t kend = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : n;
+            uint32_t reads = 0;
+            uint32_t pf[5 * pw::LANE_PF];
+            chain_lane[i] = pw::lane_chain(kend, n_cl, pp, r[i], x_in, x_out, x_prev, cl.data(), reads, hp, hs_in, hs_out, wd,
+                                           use_hints ? pf : nullptr, 1u);
+            if (probes) probes[i] += reads;
+#if !defined(__HIP_DEVICE_COMPILE__)
+            if (getenv("PW_LANE_STATS")) {
+                fprintf(stderr, "chain n=%u kend=%u seq=%llu binades=%llu res=%u\n", n, kend, (unsigned long long)pw::g_lane_seq_elems,
+                        (unsigned long long)pw::g_lane_binades, chain_lane[i]);
+                pw::g_lane_seq_elems = 0;
+                pw::g_lane_binades = 0;
+            }
+#endif
+        }
     }
     return PW_OK;
 }

@@ -227,6 +227,166 @@ PW_HD uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t pr
     return k;
 }
 
+// ---- guided search over a common-neighbour list ---------------------------------------------------------------
+// Both per-thread routines below look for the first list entry whose (monotone) partial mass reaches a target.  A
+// plain bisection costs log2(n) DEPENDENT scattered loads -- the lane kernel's critical path -- so the search starts
+// from a guess: one unaligned 16-byte load fetches entries [g - 1, g + 3) around the guessed index g, and when the
+// guess is right (entry g - 1 below the target, one of the next three at or above it) the search is over after that
+// single access.  Whatever the window does not settle is finished by bisection, so a wrong guess costs time, never
+// correctness.  The guesses come from a per-edge HINT table (csrc/walk_lanes.hip.h: hint_build_kernel): bucket b
+// of width Wd holds the first index whose prev-less mass m_i = ((P_i - i) << hs_out) + ((i + 1) << hs_in) reaches
+// b * Wd, Wd = M / n + 1, M = ((d - n) << hs_out) + (n << hs_in); one 4-byte word packs hint[b] | hint[b+1] << 16.
+struct ListWin {
+    uint32_t v[4];
+};
+struct __attribute__((packed, aligned(4))) ListWinRaw {
+    uint32_t v[4];
+};
+PW_HD ListWin load_list_window(const uint32_t *p) {
+    const ListWinRaw raw = *(const ListWinRaw *)p;   // one 16-byte load, 4-byte aligned
+    ListWin w;
+    w.v[0] = raw.v[0]; w.v[1] = raw.v[1]; w.v[2] = raw.v[2]; w.v[3] = raw.v[3];
+    return w;
+}
+
+// floor(a / b) for a, b < 2^52, b > 0, through one float64 division (a 64-bit integer division costs ~200
+// instructions on the GPU; this is ~35)
+PW_HD uint64_t div_floor_small(uint64_t a, uint64_t b) {
+    uint64_t q = (uint64_t)((double)a / (double)b);   // correctly rounded quotient: off by at most one
+    if (q * b > a) q--;
+    else if ((q + 1u) * b <= a) q++;
+    return q;
+}
+PW_HD uint32_t hint_bucket_width(uint32_t d, uint32_t n, uint32_t hs_in, uint32_t hs_out) {
+    const uint64_t m = ((uint64_t)(d - n) << hs_out) + ((uint64_t)n << hs_in);
+    return n ? (uint32_t)div_floor_small(m, n) + 1u : 1u;
+}
+
+struct ListHints {
+    const uint32_t *h;    // this edge's hint words (nullptr: none)
+    uint32_t hs_in, hs_out;
+    float wd;             // bucket width in hint units
+    // index the search should start from for mass tau (float arithmetic: the bucket may be off by one now and
+    // then -- the search verifies its guess)
+    PW_HD uint32_t guess(float tau, uint32_t n, uint32_t &reads) const {
+        if (!h) return 0xffffffffu;
+        const float bf = tau / wd;
+        uint32_t b = bf >= (float)(n - 1u) ? n - 1u : (bf > 0.0f ? (uint32_t)bf : 0u);
+        reads++;
+        return h[b] & 0xffffu;
+    }
+};
+// wd = the bucket width the table was built with (hint_bucket_width; the lane kernel keeps it in the edge record)
+PW_HD ListHints make_hints(const uint32_t *h, uint32_t hs_in, uint32_t hs_out, uint32_t wd, uint32_t n) {
+    ListHints lh;
+    lh.h = (h && n > 0 && n <= 0xffffu && wd) ? h : nullptr;
+    lh.hs_in = hs_in;
+    lh.hs_out = hs_out;
+    lh.wd = (float)wd;
+    return lh;
+}
+
+// Hint words of one list (n entries at positions cl[], row degree d): out[b] = hint[b] | hint[b + 1] << 16 for
+// b in [0, n), hint[b] = number of entries whose prev-less mass is below b * Wd (hint[n] = n).  Lists longer than
+// 65535 entries get no hints (make_hints ignores the table for them); out[] is left untouched.
+PW_HD void build_list_hints(const uint32_t *cl, uint32_t n, uint32_t d, uint32_t hs_in, uint32_t hs_out, uint32_t *out) {
+    if (n == 0 || n > 0xffffu) return;
+    const uint64_t wd = hint_bucket_width(d, n, hs_in, hs_out);
+    uint32_t i = 0, prev = 0;   // prev = hint[b - 1]
+    for (uint32_t b = 1; b <= n; b++) {
+        uint32_t hb = n;
+        if (b < n) {
+            const uint64_t lim = (uint64_t)b * wd;
+            while (i < n && (((uint64_t)(cl[i] - i) << hs_out) + ((uint64_t)(i + 1u) << hs_in)) < lim) i++;
+            hb = i;
+        }
+        out[b - 1] = prev | (hb << 16);
+        prev = hb;
+    }
+}
+
+// First index f in [lo_min, n) with ev(f, P_f) >= target (n when none); ev monotone non-decreasing in the index.
+// below: entry f - 1 and its value (has_below == false when f == lo_min); at: entry f and its value (p_at ==
+// 0xffffffff when f == n).  g = guessed index (0xffffffff: none).
+struct SearchResult {
+    uint32_t f;
+    uint32_t p_below, p_at;
+    uint64_t v_below, v_at;
+    bool has_below;
+    ListWin win;     // the window the search loaded: entries [w0, w0 + 4), w0 == 0xffffffff: none
+    uint32_t w0;
+};
+template <class Eval>
+PW_HD SearchResult guided_search(const uint32_t *cl, uint32_t lo_min, uint32_t n, uint32_t g, const Eval &ev, uint64_t target,
+                                 uint32_t &reads, const ListWin *pre = nullptr, uint32_t pre_w0 = 0xffffffffu) {
+    SearchResult r;
+    r.p_below = 0; r.v_below = 0; r.has_below = false; r.p_at = 0xffffffffu; r.v_at = 0;
+    r.w0 = 0xffffffffu;
+    r.win = ListWin{{0, 0, 0, 0}};
+    uint32_t lo = lo_min, hi = n;
+    if (lo < hi && (g != 0xffffffffu || pre_w0 != 0xffffffffu)) {
+        uint32_t w0;
+        ListWin w;
+        if (pre_w0 != 0xffffffffu) {   // window fetched ahead of time (lane_chain's prefetch)
+            w0 = pre_w0;
+            w = *pre;
+        } else {
+            if (g < lo_min) g = lo_min;
+            if (g > n) g = n;
+            w0 = g > lo_min ? g - 1u : g;
+            if (w0 >= n) w0 = n - 1u;
+            w = load_list_window(cl + w0);   // may run past the list end: the lists are padded
+            reads += 4;
+        }
+        r.win = w;
+        r.w0 = w0;
+        bool any_below = false, any_at = false;
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t idx = w0 + t;
+            if (idx < hi && idx >= lo) {
+                const uint64_t v = ev(idx, w.v[t]);
+                if (v >= target) { hi = idx; r.p_at = w.v[t]; r.v_at = v; any_at = true; }
+                else { lo = idx + 1u; r.p_below = w.v[t]; r.v_below = v; r.has_below = true; any_below = true; }
+            }
+        }
+        // a near miss is finished by galloping away from the window instead of bisecting the whole list
+        if (lo < hi && any_below && !any_at) {          // guess too low: probe lo + 3, lo + 11, lo + 27, ...
+            uint32_t step = 4;
+            while (lo < hi) {
+                const uint32_t idx = hi - lo > step ? lo + step - 1u : hi - 1u;
+                const uint32_t P = cl[idx];
+                reads++;
+                const uint64_t v = ev(idx, P);
+                if (v >= target) { hi = idx; r.p_at = P; r.v_at = v; break; }
+                lo = idx + 1u; r.p_below = P; r.v_below = v; r.has_below = true;
+                step <<= 1;
+            }
+        } else if (lo < hi && any_at && !any_below) {   // guess too high: probe hi - 4, hi - 12, ...
+            uint32_t step = 4;
+            while (lo < hi) {
+                const uint32_t idx = hi - lo > step ? hi - step : lo;
+                const uint32_t P = cl[idx];
+                reads++;
+                const uint64_t v = ev(idx, P);
+                if (v < target) { lo = idx + 1u; r.p_below = P; r.v_below = v; r.has_below = true; break; }
+                hi = idx; r.p_at = P; r.v_at = v;
+                step <<= 1;
+            }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t P = cl[mid];
+        reads++;
+        const uint64_t v = ev(mid, P);
+        if (v >= target) { hi = mid; r.p_at = P; r.v_at = v; }
+        else { lo = mid + 1u; r.p_below = P; r.v_below = v; r.has_below = true; }
+    }
+    r.f = lo;
+    return r;
+}
+
 // ---- the exact decision evaluated by ONE thread from the positions of the common neighbours (lane kernel) ------
 // Row of d neighbours; cl[0..n_in) = ascending positions of the common neighbours of prev and cur ("in", weight
 // 1), pp = position of prev (weight w_prev; 0xffffffff: prev is not a neighbour), everything else "out" (weight
@@ -235,19 +395,29 @@ PW_HD uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t pr
 // (the float chain then needs the first `kmax` positions at most); LANE_REDO when the row is outside the exact
 // range.  The run structure: the i-th common neighbour sits at P_i with exact mass
 //   E(P_i) = ((P_i - i - [pp < P_i]) << sh_out) + ((i + 1) << sh_in) + ([pp < P_i] << sh_prev),
-// monotone in i, so the first i with E(P_i) >= lo is found by bisection; between P_{i-1} and P_i the row consists
-// of "out" positions (and possibly prev), where the first position reaching lo is a closed form (solve_out_run).
+// monotone in i, so the first i with E(P_i) >= lo is found by a (guided) search; between P_{i-1} and P_i the row
+// consists of "out" positions (and possibly prev), where the first position reaching lo is a closed form
+// (solve_out_run).
 constexpr uint32_t LANE_AMBIGUOUS = 0xfffffffdu;
 constexpr uint32_t LANE_REDO = 0xfffffffcu;
 
 struct LaneStep {
     float tot;        // exact row total (float32)
     uint32_t kmax;    // ambiguous steps: leading positions the float chain can need
-    uint32_t probes;  // list entries read by the bisection
+    uint32_t probes;  // list / hint entries read
+};
+
+struct MassEval {   // E(P_i) in units of the smallest weight
+    uint32_t pp, sh_in, sh_out, sh_prev;
+    PW_HD uint64_t operator()(uint32_t i, uint32_t P) const {
+        const uint32_t pv = pp < P ? 1u : 0u;   // 0xffffffff compares greater than any position
+        return (uint64_t)(((P - i - pv) << sh_out) + ((i + 1u) << sh_in) + (pv << sh_prev));
+    }
 };
 
 PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
-                           const uint32_t *cl, LaneStep &ls) {
+                           const uint32_t *cl, LaneStep &ls, const uint32_t *hint = nullptr, uint32_t hs_in = 0,
+                           uint32_t hs_out = 0, uint32_t hint_wd = 0) {
     const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
     ls.probes = 0;
     if (n_in + n_pv > d) return LANE_REDO;
@@ -268,15 +438,18 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     const ExactThresholds th = exact_thresholds_f32(r * units, d, 1u << sh_max);
     const uint32_t lo_th = th.lo, hi_th = th.hi;
     const uint32_t wp = 1u << sh_prev;
-    uint32_t lo = 0, hi = n_in, s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0;
-    while (lo < hi) {
-        ls.probes++;
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t P = cl[mid];
-        const uint32_t pv = pp < P ? 1u : 0u;   // 0xffffffff compares greater than any position
-        const uint32_t ea = ((P - mid - pv) << sh_out) + ((mid + 1u) << sh_in) + (pv << sh_prev);   // E(P)
-        if (ea >= lo_th) { hi = mid; p_f = P; e_f = ea; }
-        else { lo = mid + 1u; s_run = P + 1u; base = ea; }
+    // first common neighbour whose exact mass reaches lo_th
+    uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0;
+    if (n_in) {
+        uint32_t g = 0xffffffffu;
+        if (hint && sh_in >= hs_in) {   // hint units are 2^(sh_in - hs_in) of this step's units
+            const ListHints lh = make_hints(hint, hs_in, hs_out, hint_wd, n_in);
+            g = lh.guess((float)(lo_th >> (sh_in - hs_in)), n_in, ls.probes);
+        }
+        const MassEval ev{pp, sh_in, sh_out, sh_prev};
+        const SearchResult sr = guided_search(cl, 0u, n_in, g, ev, (uint64_t)lo_th, ls.probes);
+        if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
+        if (sr.f < n_in) { p_f = sr.p_at; e_f = (uint32_t)sr.v_at; }
     }
     uint32_t e1;
     uint32_t k1 = solve_out_run(s_run, base, lo_th, (n_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, wp, e1);
@@ -286,6 +459,256 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     const uint64_t km = (uint64_t)k1 + (uint64_t)(hi_th > lo_th ? hi_th - lo_th : 0u) + 2ull;
     ls.kmax = km < d ? (uint32_t)km : d;
     return LANE_AMBIGUOUS;
+}
+
+// ---- the float32 chain itself, evaluated by ONE thread (lane kernel, ambiguous steps) ---------------------------
+// c_k = c_{k-1} + x_class(k), sequential float32 additions (np.cumsum), first k with (double)c_k >= r
+// (np.searchsorted, reference src/pecanpy/pecanpy.py:556-557).  Same arithmetic as the wavefront version
+// (walk_sparse.hip.h: unit_chain): while the sum stays inside one binade it advances by a fixed integer number of
+// ulps per class, so the first position whose sum reaches the target / the binade top is found in closed form --
+// here by a bisection over the positions of the common neighbours (the only irregular class) and a division inside
+// the run of "out" neighbours that holds it; the one addition per binade that crosses the top is a real float add.
+// Rows: cl[0..n_in) ascending positions of the common neighbours (value x_in), pp = position of prev (x_prev,
+// 0xffffffff: none), everything else x_out.  Only the first kend positions are examined.
+// Returns the position, LANE_CHAIN_END when no partial sum of the first kend elements reaches r, LANE_TIE when a
+// value sits exactly half way between two representable sums in some binade (parity dependent rounding: left to
+// the wavefront chain, which implements it).
+constexpr uint32_t LANE_CHAIN_END = 0xfffffffbu;
+constexpr uint32_t LANE_TIE = 0xfffffffau;
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host-side instrumentation of lane_chain (self test): elements added one by one after the head, binade iterations
+static thread_local uint64_t g_lane_seq_elems = 0, g_lane_binades = 0;
+#define PW_LANE_STAT(x) x
+#else
+#define PW_LANE_STAT(x)
+#endif
+constexpr uint32_t LANE_HEAD = 32;        // leading elements added one by one
+constexpr uint32_t LANE_PF = 6;           // binades whose list window is fetched ahead of time (5 words each)
+constexpr uint32_t LANE_TIE_BUDGET = 4096;  // runs walked one by one inside binades with a rounding tie
+
+struct ChainEval {   // partial sum (in ulps of the current binade) after common neighbour i at position P
+    uint64_t C, ii, io;
+    uint32_t k, i0, lim;
+    PW_HD uint64_t operator()(uint32_t i, uint32_t P) const {
+        if (P >= lim) return ~0ull;   // outside the examined prefix
+        const uint32_t cin = i - i0 + 1u;
+        return C + (uint64_t)cin * ii + (uint64_t)((P - k + 1u) - cin) * io;
+    }
+};
+
+PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
+                          const uint32_t *cl, uint32_t &reads, const uint32_t *hint = nullptr, uint32_t hs_in = 0,
+                          uint32_t hs_out = 0, uint32_t hint_wd = 0, uint32_t *pf = nullptr, uint32_t pf_stride = 1) {
+    using B = Binade<float>;
+    const ListHints lh = make_hints(hint, hs_in, hs_out, hint_wd, n_in);
+    const float hint_units_per_one = ldexpf(1.0f / x_in, (int)hs_in);   // hint units of mass per unit of the sum
+    // Prefetch.  The chain is a sequence of binades, each ending with a search of the list -- a chain of dependent
+    // scattered loads (hint word -> window -> cursor), ~60 memory round trips per chain.  Where the sum leaves a
+    // binade hardly depends on the roundings before it: the top of binade eb is the value 2^(eb - 126), so the hint
+    // word and the list window every binade will need can be requested NOW, all at once (two rounds of independent
+    // loads); the windows wait in `pf` (LDS on the device: slot j = words [5 j, 5 j + 5) = {w0, entries}) and the
+    // searches below only touch memory again when a window does not settle them.
+    const int eb_t = B::eb_of((float)r);                 // binade of the target
+    const int eb_lo = eb_t - (int)LANE_PF + 1;
+    if (pf && lh.h) {
+        uint32_t g[LANE_PF];
+#pragma unroll
+        for (int j = 0; j < (int)LANE_PF; j++) {
+            const int eb = eb_lo + j;
+            g[j] = 0xffffffffu;
+            if (eb >= 1) g[j] = lh.guess((eb == eb_t ? (float)r : ldexpf(1.0f, eb - 126)) * hint_units_per_one, n_in, reads);
+        }
+#pragma unroll
+        for (int j = 0; j < (int)LANE_PF; j++) {
+            uint32_t w0 = 0xffffffffu;
+            ListWin w = ListWin{{0, 0, 0, 0}};
+            if (g[j] != 0xffffffffu) {
+                w0 = g[j] > 0 ? g[j] - 1u : 0u;
+                if (w0 >= n_in) w0 = n_in - 1u;
+                w = load_list_window(cl + w0);
+                reads += 4;
+            }
+            uint32_t *slot = pf + (size_t)(5 * j) * pf_stride;
+            slot[0] = w0;
+            slot[pf_stride] = w.v[0]; slot[2 * pf_stride] = w.v[1]; slot[3 * pf_stride] = w.v[2]; slot[4 * pf_stride] = w.v[3];
+        }
+    }
+    float c = 0.0f;
+    uint32_t k = 0;    // next element to add
+    uint32_t i0 = 0;   // number of common neighbours before k
+    // cursor over the list: position of common neighbour i0, served from a cached 4-entry window so that walking
+    // the list costs one (dependent) load per four entries instead of one per entry
+    ListWin cw = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
+    uint32_t cw0 = 0, next_in = 0xffffffffu;
+    reads = 0;   // list entries read (statistics)
+#define PW_LANE_CURSOR()                                                              \
+    do {                                                                              \
+        if (i0 >= n_in) next_in = 0xffffffffu;                                        \
+        else {                                                                        \
+            if (i0 < cw0 || i0 - cw0 >= 4u) { cw = load_list_window(cl + i0); cw0 = i0; reads += 4; } \
+            const uint32_t o_ = i0 - cw0;                                             \
+            next_in = o_ == 0 ? cw.v[0] : (o_ == 1 ? cw.v[1] : (o_ == 2 ? cw.v[2] : cw.v[3])); \
+        }                                                                             \
+    } while (0)
+    if (n_in) { cw = load_list_window(cl); reads += 4; }
+    PW_LANE_CURSOR();
+    // PW_LANE_SEQ(n, stay): n elements one by one (real float32 additions); stops early when the sum leaves binade
+    // `stay` (0: never); `hit` = the target was reached at element k.  (A macro, not a lambda: state captured by
+    // reference ends up in scratch memory on the device.)
+#define PW_LANE_SEQ(n_, stay_)                                                        \
+    do {                                                                              \
+        for (uint32_t t_ = 0; t_ < (n_) && k < kend; t_++) {                          \
+            float x_ = x_out;                                                         \
+            if (k == next_in) {                                                       \
+                x_ = x_in;                                                            \
+                i0++;                                                                 \
+                PW_LANE_CURSOR();                                                     \
+            } else if (k == pp) x_ = x_prev;                                          \
+            c = c + x_;                                                               \
+            if ((double)c >= r) { hit = true; break; }                                \
+            k++;                                                                      \
+            if ((stay_) && B::eb_of(c) != (stay_)) break;                             \
+        }                                                                             \
+    } while (0)
+    bool hit = false;
+    // the sum changes binade every few elements at first (and the values tie there half of the time)
+    PW_LANE_SEQ(LANE_HEAD, 0);
+    if (hit) return k;
+    uint32_t tie_budget = LANE_TIE_BUDGET;
+    while (k < kend) {
+        if (k == pp) {   // prev is a single element: always a real addition (no closed form, no tie question)
+            PW_LANE_SEQ(1u, 0);
+            if (hit) return k;
+            continue;
+        }
+        const uint32_t lim = (pp != 0xffffffffu && pp > k && pp < kend) ? pp : kend;   // closed form over [k, lim)
+        const int eb = B::eb_of(c);
+        const uint64_t C = B::sig_of(c);
+        const uint64_t Tt = B::threshold(r, eb);   // <= TOP
+        const Inc<float> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb);
+        if ((qi.a0 != qi.a1 && next_in < lim) || qo.a0 != qo.a1) {
+            // A value sits exactly half way between two sums of this binade: its increment depends on the parity of
+            // the running sum (round half to even), so the counts alone no longer determine the sum.  Walk the
+            // binade RUN BY RUN instead: a run of m "out" neighbours adds (C odd ? a1 : a0) once and -- the sum being
+            // even after a tying addition -- a0 for each further element (no tie: a0 == a1 throughout); a common
+            // neighbour adds its own parity-selected increment.  Cost: one iteration per common neighbour inside the
+            // binade instead of one per element.
+            bool leave = false;   // the sum left the binade (or reached the target) at element kf
+            uint32_t kf = 0;
+            uint64_t Cc = C, Cprev = C;
+            float xf = 0.0f;
+            while (k < lim) {
+                if (tie_budget == 0) return LANE_TIE;
+                tie_budget--;
+                const uint32_t stop = next_in < lim ? next_in : lim;   // end of the "out" run that starts at k
+                const uint32_t m = stop - k;
+                if (m) {
+                    const uint64_t first = (Cc & 1ull) ? qo.a1 : qo.a0;
+                    const uint64_t each = qo.a0;   // no tie: a0 == a1; after a tying addition the sum is even
+                    // smallest t in [1, m] with Cc + first + (t - 1) * each >= Tt
+                    uint64_t t = 1;
+                    if (Cc + first < Tt) t = each ? 2ull + div_floor_small(Tt - (Cc + first) - 1ull, each) : 0xffffffffull;
+                    if (t <= m) {
+                        kf = k + (uint32_t)t - 1u;
+                        const uint64_t Cf = Cc + first + (t - 1ull) * each;
+                        Cprev = t == 1 ? Cc : Cf - each;
+                        Cc = Cf;
+                        xf = x_out;
+                        leave = true;
+                        break;
+                    }
+                    Cc += first + (uint64_t)(m - 1u) * each;
+                    k = stop;
+                    if (k >= lim) break;
+                }
+                // the common neighbour at k
+                const uint64_t inc = (Cc & 1ull) ? qi.a1 : qi.a0;
+                i0++;
+                PW_LANE_CURSOR();
+                if (Cc + inc >= Tt) {
+                    kf = k;
+                    Cprev = Cc;
+                    Cc += inc;
+                    xf = x_in;
+                    leave = true;
+                    break;
+                }
+                Cc += inc;
+                k++;
+            }
+            PW_LANE_STAT(g_lane_seq_elems++);
+            if (!leave) {   // [k_start, lim) stays inside the binade and below the target
+                if (lim == kend) return LANE_CHAIN_END;
+                c = B::make((uint32_t)Cc, eb);
+                continue;   // k == lim == pp: prev is added next
+            }
+            if (Cc < (uint64_t)B::TOP) return kf;   // target reached inside the binade
+            c = B::make((uint32_t)Cprev, eb) + xf;
+            if ((double)c >= r) return kf;
+            k = kf + 1u;   // (the list cursor already points behind kf)
+            continue;
+        }
+        const uint64_t ii = qi.a0, io = qo.a0;
+        PW_LANE_STAT(g_lane_binades++);
+        // first common neighbour in [k, lim) whose partial sum reaches Tt; the run of "out" neighbours before it
+        // starts at s_run with partial sum `base`.  Guess from the hint table: the exact mass at which the sum
+        // equals Tt ulps (the float drift only shifts the true index by a few entries, which the window absorbs).
+        uint32_t g = 0xffffffffu, pre_w0 = 0xffffffffu;
+        ListWin pre = ListWin{{0, 0, 0, 0}};
+        if (lh.h) {
+            const int slot = eb - eb_lo;
+            if (pf && slot >= 0 && slot < (int)LANE_PF) {
+                const uint32_t *sp = pf + (size_t)(5 * slot) * pf_stride;
+                pre_w0 = sp[0];
+                pre.v[0] = sp[pf_stride]; pre.v[1] = sp[2 * pf_stride]; pre.v[2] = sp[3 * pf_stride]; pre.v[3] = sp[4 * pf_stride];
+            }
+            if (pre_w0 == 0xffffffffu) g = lh.guess(ldexpf((float)Tt, eb - 150) * hint_units_per_one, n_in, reads);
+        }
+        const ChainEval ev{C, ii, io, k, i0, lim};
+        const SearchResult sr = guided_search(cl, i0, n_in, g, ev, Tt, reads, &pre, pre_w0);
+        const uint32_t lo = sr.f;
+        uint32_t s_run = k, p_f = 0xffffffffu;
+        uint64_t base = C, g_f = 0;
+        if (sr.has_below) { s_run = sr.p_below + 1u; base = sr.v_below; }
+        if (sr.f < n_in && sr.v_at != ~0ull) { p_f = sr.p_at; g_f = sr.v_at; }
+        const uint32_t run_end = p_f != 0xffffffffu ? p_f : lim;
+        const uint64_t need = Tt > base ? Tt - base : 0ull;
+        uint64_t cnt = io ? div_floor_small(need + io - 1ull, io) : 0xffffffffull;   // "out" elements needed
+        if (cnt == 0) cnt = 1;
+        const uint64_t j = (uint64_t)s_run + cnt - 1ull;
+        uint32_t kf;
+        uint64_t Cf, incf;
+        float xf;
+        if (j >= run_end) {
+            if (p_f == 0xffffffffu) {
+                // [k, lim) stays below the target and inside the binade: its exact closed-form sum
+                if (lim == kend) return LANE_CHAIN_END;
+                c = B::make((uint32_t)(base + (uint64_t)(lim - s_run) * io), eb);
+                k = lim;
+                i0 = lo;
+                if (sr.w0 != 0xffffffffu) { cw = sr.win; cw0 = sr.w0; }
+                PW_LANE_CURSOR();
+                continue;
+            }
+            kf = p_f; Cf = g_f; incf = ii; xf = x_in;
+        } else {
+            kf = (uint32_t)j;
+            Cf = base + (uint64_t)(kf - s_run + 1u) * io;
+            incf = io; xf = x_out;
+        }
+        if (Cf < (uint64_t)B::TOP) return kf;   // the target lies inside this binade and element kf reaches it
+        // element kf takes the sum over the binade top: one real float32 addition, then the next binade
+        c = B::make((uint32_t)(Cf - incf), eb) + xf;
+        if ((double)c >= r) return kf;
+        k = kf + 1u;
+        i0 = lo + (kf == p_f ? 1u : 0u);
+        if (sr.w0 != 0xffffffffu) { cw = sr.win; cw0 = sr.w0; }
+        PW_LANE_CURSOR();
+    }
+    return LANE_CHAIN_END;
+#undef PW_LANE_SEQ
+#undef PW_LANE_CURSOR
 }
 
 }  // namespace pw

@@ -37,7 +37,7 @@ struct ERec {
     uint32_t s0;        // indptr[v]
     uint32_t coff_lo;   // clist offset of this edge's list (64 bit)
     uint32_t coff_hi;
-    uint32_t pad;
+    uint32_t hint_wd;   // bucket width of this edge's hint words (seqscan.h: hint_bucket_width), 0: no hints built
 };
 static_assert(sizeof(ERec) == 32, "edge record is two 16-byte loads");
 
@@ -58,168 +58,201 @@ struct LanesArgs {
     unsigned long long *job_counter;
     unsigned long long *stats;                // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
                                               // [6] list entries read [7] ambiguous steps (float chain)
+                                              // [9] ambiguous steps left to the wave-cooperative chain
     uint32_t *redo_list;                      // jobs handed to walk_kernel
     unsigned long long *redo_count;
     float w_out, w_prev;                      // fl32(1/q), fl32(1/p): powers of two (host checked)
+    const uint32_t *__restrict__ hint;        // per-edge hint words of the guided search (seqscan.h), or nullptr
+    uint32_t hs_in, hs_out;                   // mass units the hints were built for
 };
 
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
 
-// ---- wave-cooperative float32 chain for one lane's step ---------------------------------------------------------
-// Same arithmetic as sample_step_unit_lazy's fallback (walk_sparse.hip.h): mask of the common neighbours among
-// the first kmax positions (scattered from the edge's list), rank array, 64-element head, closed-form binade
-// chain.  All arguments wave-uniform.  Returns the position, or d when the float CDF never reaches r.
-__device__ __forceinline__ uint32_t wave_chain_step(uint32_t *mask, uint16_t *rank, uint32_t d, uint32_t kmax, uint32_t n_in,
-                                                    uint32_t pp, const uint32_t *__restrict__ cl, double r, float tot,
-                                                    float w_out, float w_prev) {
-    const int lane = lane_id();
-    const float x_in = uni(1.0f / tot), x_out = uni(x_in * w_out), x_prev = uni(x_in * w_prev);
-    float c = 0.0f;
-    uint32_t k = 0, found = NOT_FOUND;
-    for (uint32_t wb = 0; wb < kmax; wb += SEG) {
-        const uint32_t wend = kmax - wb < SEG ? kmax : wb + SEG;
-        const uint32_t nw = (wend - wb + 31) >> 5;
-        for (uint32_t w = lane; w < nw; w += WAVE) mask[w] = 0;
-        wave_lds_fence();
-        // the list ascends: stop at the first chunk that starts beyond the window
-        for (uint32_t i0 = 0; i0 < n_in; i0 += WAVE) {
-            const uint32_t i = i0 + lane;
-            const uint32_t P = i < n_in ? cl[i] : NOT_FOUND;
-            if (P >= wb && P < wend) atomicOr(&mask[(P - wb) >> 5], 1u << ((P - wb) & 31));
-            if (readlane_u32(P, 0) >= wend) break;
-        }
-        wave_lds_fence();
-        build_rank(mask, rank, nw);
-        const UnitRow ur{mask, rank, wb, wend - wb, pp, true};
-        const RowVals<float, true> rv = make_unit_vals<float>(mask, wb, wend, pp, true, x_in, x_out, x_prev);
-        if (k == 0 && seq_head<float, true>(c, k, wend, r, rv, WAVE, found)) return found;
-        if (k < wend && unit_chain<float, true>(c, k, wend, r, ur, rv, x_in, x_out, x_prev, found) == SCAN_FOUND) return found;
-    }
-    // kmax < d: by construction of kmax the chain has reached r before; reaching this point with kmax < d would
-    // contradict the drift bound -- report "never reached" and let the caller hand the walk to walk_kernel
-    return d;
-}
+// Optional section timing of the lane kernel (-DPW_PROF_LANES builds; tools/prof_lanes.sh): wave-level cycle sums
+//   [0] refill [1] draw + exact decision [2] float chains [3] edge record + store   and counts
+//   [8] loop iterations [9] chain passes [10] lanes in chain passes [11] runnable lanes summed over iterations
+#ifdef PW_PROF_LANES
+__device__ unsigned long long g_lprof[16];
+#define LPROF_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) lp[i] += now_ - lp_last; lp_last = __builtin_readcyclecounter(); } while (0)
+#define LPROF_C(i, n) do { if (lane == 0) lp[i] += (n); } while (0)
+#else
+#define LPROF_T(i)
+#define LPROF_C(i, n)
+#endif
 
 #ifndef PW_LANES_MIN_WAVES
-#define PW_LANES_MIN_WAVES 8
+#define PW_LANES_MIN_WAVES 6   // 80 VGPRs: the per-lane chain spills heavily at 64
 #endif
+#ifndef PW_LANES_WAIT
+#define PW_LANES_WAIT 16   // ambiguous lanes that gather before their float chains run
+#endif
+
+// Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
+// otherwise one 32-byte record names the next vertex and everything the next step needs.
+#define PW_LANE_APPLY()                                                                         \
+    do {                                                                                        \
+        if (choice >= A.d) {                                                                    \
+            const unsigned long long slot_ = atomicAdd(a.redo_count, 1ull);                     \
+            a.redo_list[slot_] = A.job;                                                         \
+            n_steps -= (A.j - 1);                                                               \
+            A.flags = 0;                                                                        \
+        } else {                                                                                \
+            const uint4 *rp_ = (const uint4 *)(a.erec + ((uint64_t)A.s0 + choice));             \
+            const uint4 r0_ = rp_[0], r1_ = rp_[1];                                             \
+            a.out[(uint64_t)A.job * W + A.j] = r0_.x;                                           \
+            A.n_in = r0_.y; A.pp = r0_.z; A.d = r0_.w;                                          \
+            A.s0 = r1_.x; A.coff = ((uint64_t)r1_.z << 32) | r1_.y; A.wd = r1_.w;               \
+            n_steps++;                                                                          \
+            A.j++;                                                                              \
+            if (A.j > L || A.d == 0) {                                                          \
+                uint32_t *row_ = a.out + (uint64_t)A.job * W;                                   \
+                row_[L + 1] = A.j;               /* effective length (pecanpy.py:196-206) */    \
+                if (A.j <= L) {                  /* dead end: the remaining cells are 0 */      \
+                    n_dead++;                                                                   \
+                    for (uint32_t z_ = A.j; z_ <= L; z_++) row_[z_] = 0;                        \
+                }                                                                               \
+                A.flags = 0;                                                                    \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
 
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_LANES_MIN_WAVES)
 walk_lanes_kernel(LanesArgs a) {
-    __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
-    __shared__ uint16_t s_rank[WAVES_PER_BLOCK][MASK_WORDS + 2];
     const int lane = lane_id();
-    const int wave = threadIdx.x / WAVE;
-    uint32_t *mask = s_mask[wave];
-    uint16_t *rank = s_rank[wave];
+#ifdef PW_LANES_PREFETCH
+    // per-lane slots of lane_chain's prefetched list windows (seqscan.h), lane-interleaved: conflict free
+    __shared__ uint32_t s_pf[WAVES_PER_BLOCK][5 * LANE_PF][WAVE];
+    uint32_t *const pf = &s_pf[threadIdx.x / WAVE][0][lane];
+#else
+    uint32_t *const pf = nullptr;   // (measured: no gain)
+#endif
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
     const float w_out = a.w_out, w_prev = a.w_prev;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
+#ifdef PW_PROF_LANES
+    unsigned long long lp[16] = {0};
+    unsigned long long lp_last = __builtin_readcyclecounter();
+#endif
 
-    // per-lane walk state
-    bool active = false, exhausted = false;
-    uint32_t job = 0, j = 1;            // j = index of the step being sampled (1..L)
-    uint64_t soff = 0;
-    uint32_t s0 = 0, d = 0, n_in = 0, pp = NOT_FOUND;
-    uint64_t coff = 0;
-    unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0;
+    // per-lane walk state (prefix A: the macro PW_LANE_APPLY works on it)
+    struct Walk {
+        uint32_t job, j;                 // j = index of the step being sampled (1..L)
+        uint64_t soff;
+        uint32_t s0, d, n_in, pp;        // row of the current vertex; edge it was entered by
+        uint64_t coff;
+        uint32_t wd;                     // hint bucket width of that edge's list
+        uint32_t flags;                  // bit 0: active, bit 1: waiting for the float chain
+    };
+    constexpr uint32_t F_ACTIVE = 1u, F_WAIT = 2u;
+    Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
+    bool exhausted = false;
+    unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0, n_wave = 0;
+    // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
+    double r = 0.0;
+    float tot = 1.0f, wo = 1.0f;
+    uint32_t kmax = 0;
+    const uint32_t *const hint = a.hint;
+    const uint32_t hs_in = a.hs_in, hs_out = a.hs_out;
 
     for (;;) {
         // ---- refill idle lanes from the job counter -------------------------------------------------------
         for (;;) {
-            const uint64_t need = ballot(!active && !exhausted);
+            const uint64_t need = ballot(!(A.flags & F_ACTIVE) && !exhausted);
             if (!need) break;
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(a.job_counter, (unsigned long long)__popcll(need));
             base = readfirst_u64(base);
-            if (!active && !exhausted) {
+            if (!(A.flags & F_ACTIVE) && !exhausted) {
                 const uint64_t widx = base + (uint64_t)__popcll(need & lane_lt);
                 if (widx >= n_work) exhausted = true;
                 else {
-                    job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
-                    const uint32_t start = a.starts[job];
+                    A.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
+                    const uint32_t start = a.starts[A.job];
                     const uint4 vr = a.vrec[start];
-                    uint32_t *row = a.out + (uint64_t)job * W;
+                    uint32_t *row = a.out + (uint64_t)A.job * W;
                     row[0] = start;
                     if (vr.y == 0) {
                         row[L + 1] = 1;          // start without neighbours (pecanpy.py:190-193); cells 1..L stay 0
-                        for (uint32_t z = 1; z <= L; z++) row[z] = 0;   // (a repaired row may hold an older walk)
+                        if (a.job_list)          // a repaired row may hold an older walk
+                            for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                     } else {
-                        soff = a.stream_off[job] - a.rng_base;
-                        s0 = vr.x; d = vr.y; n_in = 0; pp = NOT_FOUND; coff = 0; j = 1;
-                        active = true;
+                        A.soff = a.stream_off[A.job] - a.rng_base;
+                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.coff = 0; A.wd = 0; A.j = 1;
+                        A.flags = F_ACTIVE;
                     }
                 }
             }
         }
-        if (!ballot(active)) break;
+        if (!ballot(A.flags & F_ACTIVE)) break;
+        LPROF_T(0);
+        LPROF_C(8, 1);
 
-        // ---- one step for every active lane ---------------------------------------------------------------------
-        uint32_t choice = 0;
-        LaneStep ls{1.0f, 0u, 0u};
-        double r = 0.0;
-        const float wo = j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
-        if (active) {
-            r = a.rng[soff + (j - 1)];
-            choice = lane_decide(d, n_in, pp, r, wo, w_prev, a.clist + coff, ls);
+        // ---- one step for every runnable lane ------------------------------------------------------------------
+        // A lane whose step the exact decision cannot settle WAITS (keeps its draw and thresholds) while the other
+        // lanes go on stepping; the float32 chains run once PW_LANES_WAIT lanes wait (or nothing else can run), so
+        // the long, divergent chain code executes with several lanes enabled instead of one or two.
+        uint32_t choice = LANE_AMBIGUOUS;
+        const bool runnable = A.flags == F_ACTIVE;
+        if (runnable) {
+            wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
+            r = a.rng[A.soff + (A.j - 1)];
+            LaneStep ls{1.0f, 0u, 0u};
+            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd);
             n_probes += ls.probes;
-            if (choice == LANE_AMBIGUOUS) { n_amb++; n_probes += n_in < ls.kmax ? n_in : ls.kmax; }
+            if (choice == LANE_AMBIGUOUS) { A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax; n_amb++; }
         }
-        // ambiguous steps: the whole wave runs the float32 chain for one lane at a time
-        uint64_t amb = ballot(active && choice == LANE_AMBIGUOUS);
-        while (amb) {
-            const int l = __builtin_ctzll(amb);
-            amb &= amb - 1ull;
-            const uint32_t c_d = readlane_u32(d, l), c_kmax = readlane_u32(ls.kmax, l), c_nin = readlane_u32(n_in, l),
-                           c_pp = readlane_u32(pp, l);
-            const uint64_t c_coff = readlane_u64(coff, l);
-            const double c_r = readlane_f64(r, l);
-            const float c_tot = readlane_f32(ls.tot, l), c_wo = readlane_f32(wo, l);
-            const uint32_t res = wave_chain_step(mask, rank, c_d, c_kmax, c_nin, c_pp, a.clist + c_coff, c_r, c_tot, c_wo, w_prev);
-            if (lane == l) choice = res;
-        }
-        if (active) {
-            if (choice >= d) {
-                // overflow read / failed precondition: walk_kernel redoes this job from its start
-                const unsigned long long slot = atomicAdd(a.redo_count, 1ull);
-                a.redo_list[slot] = job;
-                n_steps -= (j - 1);
-                active = false;
-            } else {
-                const uint64_t pos = (uint64_t)s0 + choice;
-                const uint4 *rp = (const uint4 *)(a.erec + pos);
-                const uint4 r0 = rp[0], r1 = rp[1];
-                a.out[(uint64_t)job * W + j] = r0.x;
-                n_in = r0.y; pp = r0.z; d = r0.w;
-                s0 = r1.x; coff = ((uint64_t)r1.z << 32) | r1.y;
-                n_steps++;
-                j++;
-                if (j > L || d == 0) {
-                    uint32_t *row = a.out + (uint64_t)job * W;
-                    row[L + 1] = j;              // effective length (pecanpy.py:196-206)
-                    if (j <= L) {                // dead end: the remaining cells are 0
-                        n_dead++;
-                        for (uint32_t z = j; z <= L; z++) row[z] = 0;
-                    }
-                    active = false;
-                }
+        LPROF_T(1);
+        const uint64_t wait_mask = ballot((A.flags & F_WAIT) != 0);
+        if (wait_mask != 0 && ((uint32_t)__popcll(wait_mask) >= PW_LANES_WAIT || ballot(runnable && choice != LANE_AMBIGUOUS) == 0)) {
+            LPROF_C(9, 1);
+            LPROF_C(10, __popcll(wait_mask));
+            if (A.flags & F_WAIT) {
+                // the float32 chain over the first kmax positions, by this lane alone (seqscan.h: lane_chain)
+                const float x_in = 1.0f / tot;
+                uint32_t reads = 0;
+                const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, a.clist + A.coff, reads,
+                                                hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd, pf, (uint32_t)WAVE);
+                n_probes += reads;
+                choice = res;
+                if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
+                if (res == LANE_TIE) { choice = A.d; n_wave++; }        // tie binade too long for one lane -> redo
+                A.flags = F_ACTIVE;
             }
+#ifdef PW_PROF_LANES
+            {   // pass duration by number of lanes in the pass: buckets 1-2, 3-4, 5-8, 9+ -> [12..15] cycles, [4..7] passes
+                const unsigned long long now_ = __builtin_readcyclecounter();
+                const int nl_ = __popcll(wait_mask);
+                const int bk_ = nl_ <= 2 ? 0 : (nl_ <= 4 ? 1 : (nl_ <= 8 ? 2 : 3));
+                if (lane == 0) { lp[12 + bk_] += now_ - lp_last; lp[4 + bk_] += 1; }
+            }
+#endif
+            LPROF_T(2);
         }
+        if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {
+            PW_LANE_APPLY();
+        }
+        LPROF_T(3);
     }
+#undef PW_LANE_APPLY
+#ifdef PW_PROF_LANES
+    if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
+#endif
     // wave totals
     for (int off = 32; off > 0; off >>= 1) {
         n_steps += (unsigned long long)__shfl_down((long long)n_steps, (unsigned)off, WAVE);
         n_dead += (unsigned long long)__shfl_down((long long)n_dead, (unsigned)off, WAVE);
         n_probes += (unsigned long long)__shfl_down((long long)n_probes, (unsigned)off, WAVE);
         n_amb += (unsigned long long)__shfl_down((long long)n_amb, (unsigned)off, WAVE);
+        n_wave += (unsigned long long)__shfl_down((long long)n_wave, (unsigned)off, WAVE);
     }
     if (lane == 0) {
         if (n_steps) atomicAdd(a.stats + 0, n_steps);
         if (n_dead) atomicAdd(a.stats + 3, n_dead);
         if (n_probes) atomicAdd(a.stats + 6, n_probes);
         if (n_amb) atomicAdd(a.stats + 7, n_amb);
+        if (n_wave) atomicAdd(a.stats + 9, n_wave);
     }
 }
 
@@ -311,8 +344,21 @@ clist_fill_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const uint64_
     r.s0 = sv;
     r.coff_lo = (uint32_t)c0;
     r.coff_hi = (uint32_t)(c0 >> 32);
-    r.pad = 0;
+    r.hint_wd = 0;
     erec[e] = r;
+}
+
+// Hint words of every edge's list for the mass units (hs_in, hs_out) (seqscan.h: build_list_hints): one lane per
+// CSR entry.  Rebuilt when q changes the ratio of the "in" and "out" weights.
+__global__ void __launch_bounds__(256)
+hint_build_kernel(ERec *erec, const uint32_t *__restrict__ clist, uint32_t nnz, uint32_t hs_in, uint32_t hs_out,
+                  uint32_t *hint) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const ERec r = erec[e];
+    const uint64_t c0 = ((uint64_t)r.coff_hi << 32) | r.coff_lo;
+    build_list_hints(clist + c0, r.n_in, r.deg, hs_in, hs_out, hint + c0);
+    erec[e].hint_wd = (r.n_in && r.n_in <= 0xffffu) ? hint_bucket_width(r.deg, r.n_in, hs_in, hs_out) : 0u;
 }
 
 }  // namespace pw

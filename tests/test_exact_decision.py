@@ -127,18 +127,26 @@ def test_float64_flavour_of_the_dense_kernel(w_out, w_prev):
 # ---- the lane kernel's per-thread form of the same decision (seqscan.h: lane_decide) ---------------------------
 LANE_AMBIGUOUS = 0xFFFFFFFD
 LANE_REDO = 0xFFFFFFFC
+LANE_CHAIN_END = 0xFFFFFFFB
+LANE_TIE = 0xFFFFFFFA
 
 
-def lane_decide(cls, w_out, w_prev, r):
+def lane_decide(cls, w_out, w_prev, r, use_hints=False):
     lib = _lib.load()
     cls = np.ascontiguousarray(cls, dtype=np.uint8)
     r = np.ascontiguousarray(r, dtype=np.float64)
     chain = np.empty(r.size, dtype=np.uint32)
     lane = np.empty(r.size, dtype=np.uint32)
     kmax = np.empty(r.size, dtype=np.uint32)
+    chain_lane = np.empty(r.size, dtype=np.uint32)
+    probes = np.empty(r.size, dtype=np.uint32)
     _lib.check(lib.pw_selftest_lane_decide(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
                                            r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
-                                           lane.ctypes.data_as(C.c_void_p), kmax.ctypes.data_as(C.c_void_p)))
+                                           lane.ctypes.data_as(C.c_void_p), kmax.ctypes.data_as(C.c_void_p),
+                                           chain_lane.ctypes.data_as(C.c_void_p), int(use_hints),
+                                           probes.ctypes.data_as(C.c_void_p)))
+    lane_decide.chain_lane = chain_lane
+    lane_decide.probes = probes
     return chain, lane, kmax
 
 
@@ -148,7 +156,7 @@ def test_lane_decision_from_common_neighbour_positions(w_out, w_prev):
     indices equal the float32 chain; undecided ones need no more than kmax leading positions; and the
     decision agrees with the wave kernel's rank-search form on which targets are decided."""
     rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 7)
-    decided = total = 0
+    decided = total = ties = chained = reads_plain = reads_hint = 0
     for n in (1, 2, 3, 7, 40, 64, 65, 300, 1500, 6000):
         for p_common in (0.0, 0.02, 0.3, 0.9, 1.0):
             for with_prev in (False, True):
@@ -168,9 +176,27 @@ def test_lane_decision_from_common_neighbour_positions(w_out, w_prev):
                 assert (kmax[amb] <= n).all()
                 _, exact = decide(cls, w_out, w_prev, r)
                 assert np.array_equal(exact != AMBIGUOUS, ok)      # same bound, same verdicts
+                # the per-thread float chain (lane_chain): over the ambiguous prefix / the whole row it returns
+                # the reference's index, "never reached", or declines on a rounding tie
+                cl_ = lane_decide.chain_lane
+                tie = cl_ == LANE_TIE
+                end = cl_ == LANE_CHAIN_END
+                assert np.array_equal(cl_[~tie & ~end], chain[~tie & ~end]), (n, p_common, with_prev, w_out, w_prev)
+                assert (chain[end] == n).all()
+                ties += int(tie.sum())
+                chained += int(tie.size)
+                # guided by the hint table: identical answers from fewer list reads
+                plain_reads = int(lane_decide.probes[:300].sum())
+                chain_h, lane_h, kmax_h = lane_decide(cls, w_out, w_prev, r, use_hints=True)
+                assert np.array_equal(lane_h, lane) and np.array_equal(kmax_h, kmax)
+                assert np.array_equal(lane_decide.chain_lane, cl_)
+                reads_plain += plain_reads
+                reads_hint += int(lane_decide.probes[:300].sum())
                 decided += int(ok[:300].sum())
                 total += 300
     assert decided / total > 0.5
+    assert ties / chained < 0.2          # the per-thread chain rarely has to decline
+    assert reads_hint < reads_plain      # (entries read; a 4-entry window counts 4 but is ONE access)
 
 
 def test_lane_decision_first_step_row():
