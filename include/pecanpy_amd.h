@@ -72,7 +72,9 @@ typedef struct {
     uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
     uint64_t ambiguous_steps;   /* steps decided by the float32 chain instead of exact integer arithmetic */
     double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
-    uint64_t wave_chain_steps;  /* of the ambiguous steps, those the per-lane chain left to the wave-cooperative chain */
+    uint64_t wave_chain_steps;  /* of the ambiguous steps, those the per-lane chain could not afford (walk redone) */
+    double param_index_ms;      /* device time spent in THIS call building an index that depends on (p, q, extend):
+                                   per-edge normalisers of weighted graphs, hint tables; 0 when cached in the handle */
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */

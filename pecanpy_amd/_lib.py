@@ -30,6 +30,7 @@ class PwStats(C.Structure):
         ("ambiguous_steps", C.c_uint64),
         ("lane_kernel_ms", C.c_double),
         ("wave_chain_steps", C.c_uint64),
+        ("param_index_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -5,6 +5,7 @@
 // bit-exact float chain depends on separately rounded operations.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -95,6 +96,13 @@ struct pw_graph {
     int hint_in = -1, hint_out = -1;                    // mass units the hints were built for (-1: none yet)
     bool hint_failed = false;                           // no memory for the hints: plain bisection
     double hint_build_ms = 0;
+    float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
+    double tot_p = 0, tot_q = 0;                        // ... built for these parameters
+    int tot_extend = -1;                                // -1: none yet
+    uint64_t tot_thr_version = 0, thr_version = 0;      // thresholds uploaded since the table was built?
+    bool tot_failed = false;
+    double tot_build_ms = 0;
+    double param_ms_call = 0;                           // (p, q)-dependent index time of the current call
     uint64_t n_clist = 0;
     double index_build_ms = 0;                          // device time of all index kernels of pw_csr_create
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
@@ -203,6 +211,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_erec) (void)hipFree(g->d_erec);
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_hint) (void)hipFree(g->d_hint);
+    if (g->d_tot_e) (void)hipFree(g->d_tot_e);
+    if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     g->redo.release();
     g->stream_off.release();
     g->tile_sums.release();
@@ -280,6 +290,8 @@ static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
     if (e != hipSuccess) {
         if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_hint) (void)hipFree(g->d_hint);
+    if (g->d_tot_e) (void)hipFree(g->d_tot_e);
+    if (g->d_tot_v) (void)hipFree(g->d_tot_v);
         if (g->d_erec) (void)hipFree(g->d_erec);
         g->d_clist = nullptr;
         g->d_erec = nullptr;
@@ -532,6 +544,7 @@ PW_EXPORT int pw_graph_set_thresholds(pw_graph *g, const float *thr) {
     if (set_device(g)) return PW_ERR_HIP;
     if (!g->d_thr) HIP_TRY(hipMalloc((void **)&g->d_thr, sizeof(float) * (size_t)g->n_nodes));
     HIP_TRY(hipMemcpy(g->d_thr, thr, sizeof(float) * (size_t)g->n_nodes, hipMemcpyHostToDevice));
+    g->thr_version++;
     return PW_OK;
 }
 
@@ -764,6 +777,68 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
     return 0;
 }
 
+// Per-edge normaliser table of a weighted CSR graph (walk_sparse.hip.h: tot_build_kernel), built on the first call
+// with a given (p, q, extend, thresholds) and kept in the handle.  PECANPY_AMD_NO_TOT=1 disables it.
+static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
+    wa.tot_e = nullptr;
+    wa.tot_v = nullptr;
+    if (g->kind != 0 || g->unit || !g->nnz || g->tot_failed || getenv("PECANPY_AMD_NO_TOT")) return 0;
+    const bool fresh = g->tot_extend == (extend ? 1 : 0) && g->tot_p == wa.p && g->tot_q == wa.q &&
+                       (!extend || g->tot_thr_version == g->thr_version);
+    if (!fresh) {
+        if (!g->d_tot_e) {
+            hipError_t e = hipMalloc((void **)&g->d_tot_e, sizeof(float) * (size_t)g->nnz);
+            if (e == hipSuccess) e = hipMalloc((void **)&g->d_tot_v, sizeof(float) * (size_t)(g->n_nodes ? g->n_nodes : 1));
+            if (e != hipSuccess) { g->tot_failed = true; (void)hipGetLastError(); return 0; }
+        }
+        uint32_t *d_edge_row = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)g->nnz));
+        hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, d_edge_row);
+        pw::WalkArgs ba = wa;
+        ba.job_counter = g->counters.p + 11;
+        ba.L = getenv("PW_DEBUG_TOT_MODE") ? (uint32_t)atoi(getenv("PW_DEBUG_TOT_MODE")) : 0u;
+        hipError_t e = hipMemsetAsync(g->counters.p + 11, 0, sizeof(unsigned long long), g->stream);
+        if (e == hipSuccess) e = hipEventRecord(g->ev[4], g->stream);
+        if (e == hipSuccess) {
+            const unsigned grid = (unsigned)(g->n_cu * 8);
+            if (extend) hipLaunchKernelGGL(pw::tot_build_kernel<true>, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, ba, d_edge_row, g->d_tot_e, g->d_tot_v);
+            else hipLaunchKernelGGL(pw::tot_build_kernel<false>, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, ba, d_edge_row, g->d_tot_e, g->d_tot_v);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(g->ev[5], g->stream);
+        if (e == hipSuccess && getenv("PW_DEBUG_TOT")) {   // watchdog: report progress instead of hanging
+            for (int w = 0; w < 300 && hipEventQuery(g->ev[5]) == hipErrorNotReady; w++) usleep(10000);
+            if (hipEventQuery(g->ev[5]) == hipErrorNotReady) {
+                unsigned long long c = 0;
+                (void)hipMemcpy(&c, g->counters.p + 11, sizeof(c), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[tot] build kernel stuck: item counter %llu of %llu items (+ %d waves)\n", c,
+                        (unsigned long long)g->nnz + g->n_nodes, g->n_cu * 8 * 4);
+                _exit(3);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        (void)hipFree(d_edge_row);
+        if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("normaliser table: ") + hipGetErrorString(e));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, g->ev[4], g->ev[5]));
+        g->tot_build_ms = ms;
+        g->param_ms_call += ms;
+        g->tot_extend = extend ? 1 : 0;
+        g->tot_p = wa.p;
+        g->tot_q = wa.q;
+        g->tot_thr_version = g->thr_version;
+        if (getenv("PW_DEBUG_TOT")) {
+            float he[8] = {0}, hv[8] = {0};
+            (void)hipMemcpy(he, g->d_tot_e, sizeof(float) * (g->nnz < 8 ? g->nnz : 8), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hv, g->d_tot_v, sizeof(float) * (g->n_nodes < 8 ? g->n_nodes : 8), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[tot] built in %.3f ms: tot_e %g %g %g %g %g %g  tot_v %g %g %g %g\n", ms, he[0], he[1], he[2], he[3], he[4], he[5], hv[0], hv[1], hv[2], hv[3]);
+        }
+    }
+    wa.tot_e = g->d_tot_e;
+    wa.tot_v = g->d_tot_v;
+    return 0;
+}
+
 static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
@@ -815,6 +890,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
             float hms = 0;
             HIP_TRY(hipEventElapsedTime(&hms, g->ev[4], g->ev[5]));
             g->hint_build_ms = hms;
+            g->param_ms_call += hms;
             g->hint_in = hs_in;
             g->hint_out = hs_out;
         }
@@ -995,6 +1071,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.out = d_out;
     wa.job_counter = g->counters.p;
     wa.stats = g->counters.p + 1;
+    wa.tot_e = nullptr;
+    wa.tot_v = nullptr;
     {
         // unit-weight biases exactly as the kernels form them: fl32(f64(1.0f) / q) (sparse_rw.py:59-62)
         wa.w_out = (float)(1.0 / q);
@@ -1005,6 +1083,9 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         };
         wa.lazy_ok = (pow2_ok(wa.w_out) && pow2_ok(wa.w_prev)) ? 1u : 0u;
     }
+    g->param_ms_call = 0;
+    rc = ensure_tot_table(g, wa, extend != 0);   // (before the timed walk region: a per-(p, q) index, reported apart)
+    if (rc) return rc;
     uint64_t redo_total = 0;
     const bool lanes = lanes_eligible(g, wa);
     g->lane_ms = 0;
@@ -1096,6 +1177,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.list_entries_read = h[7];
     st.ambiguous_steps = h[8];
     st.wave_chain_steps = h[10];
+    st.param_index_ms = g->param_ms_call;
     st.lane_kernel_ms = g->lane_ms;
     if (stats) *stats = st;
     return PW_OK;

@@ -117,6 +117,11 @@ struct WalkArgs {
     unsigned long long *stats;  // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
     float w_out, w_prev;        // fl32(1/q), fl32(1/p): the unit-weight biases (host computed)
     uint32_t lazy_ok;           // both are powers of two in a safe exponent range (lazy path precondition)
+    // weighted CSR graphs: the normaliser of every transition, precomputed per (p, q, extend) by tot_build_kernel
+    // with the very code of the walk step (tot_e[e] = sequential float32 sum of the biased weights of row v for a
+    // walker that arrived by CSR entry e = (u -> v); tot_v[v] = the unbiased row sum of a first step), or nullptr
+    const float *__restrict__ tot_e;
+    const float *__restrict__ tot_v;
 };
 #define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
 
@@ -155,6 +160,8 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.w_out = PW_KARG(float, w_out);
     a.w_prev = PW_KARG(float, w_prev);
     a.lazy_ok = PW_KARG(uint32_t, lazy_ok);
+    a.tot_e = (const float *)PW_KARG(uint64_t, tot_e);
+    a.tot_v = (const float *)PW_KARG(uint64_t, tot_v);
     return a;
 }
 
@@ -1205,10 +1212,12 @@ __device__ __forceinline__ uint32_t sample_step_unit_lazy(uint32_t *mask, uint16
 // ---- general (weighted) transition -------------------------------------------------------------------
 // Returns the sampled neighbour *position* k in [0, d] (d == "CDF never reached r").
 template <typename T, bool DENSE>
+// known_tot (may be nullptr): the row's normaliser from the per-edge table -- pass 1 is skipped.  tot_out (may be
+// nullptr): only the normaliser is wanted (table build) -- pass 2 is skipped and the return value is meaningless.
 __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, uint32_t *in_mask,
                                                          uint32_t *queue, uint32_t cur, bool has_prev, uint32_t prev,
                                                          uint32_t t0, uint32_t dp, double r, uint32_t s0,
-                                                         uint32_t d) {
+                                                         uint32_t d, const T *known_tot = nullptr, T *tot_out = nullptr) {
     const uint32_t *__restrict__ indices = a.g.indices;
     const T *__restrict__ data = (const T *)a.g.data;
     const bool extend = in_mask != nullptr;
@@ -1247,16 +1256,22 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     // pass 1: tot
     T tot = (T)0;
     rv.normalize = false;
-    for (uint32_t sa = 0; sa < d; sa += SEG) {
-        uint32_t len = d - sa < SEG ? d - sa : SEG;
-        if (has_prev) {
-            uint32_t pp = segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);
-            if (!multi) rv.prev_pos = pp;
+    if (known_tot) {
+        tot = *known_tot;
+        if (has_prev && !multi) rv.prev_pos = segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, 0, d, t0, dp, prev);
+    } else {
+        for (uint32_t sa = 0; sa < d; sa += SEG) {
+            uint32_t len = d - sa < SEG ? d - sa : SEG;
+            if (has_prev) {
+                uint32_t pp = segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);
+                if (!multi) rv.prev_pos = pp;
+            }
+            rv.seg_a = sa;
+            rv.kend = sa + len;
+            seq_scan<T, false>(tot, sa, sa + len, 0.0, rv, sa == 0 ? WAVE : 0);
         }
-        rv.seg_a = sa;
-        rv.kend = sa + len;
-        seq_scan<T, false>(tot, sa, sa + len, 0.0, rv, sa == 0 ? WAVE : 0);
     }
+    if (tot_out) { *tot_out = tot; return 0; }
 
     // pass 2: cdf search
     rv.normalize = true;
@@ -1341,6 +1356,7 @@ walk_kernel(WalkArgs a) {
         bool keys_pre = false;     // the first 64 keys of the next step were requested with that record
         uint64_t kfw_pre = 0;
         uint32_t len_out = L + 1;
+        uint32_t prev_edge = NOT_FOUND;   // CSR entry the walker arrived by (NOT_FOUND: first step / mirrored overflow read)
         uint32_t j = 1;
         for (; j <= L; j++) {
             const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
@@ -1367,8 +1383,16 @@ walk_kernel(WalkArgs a) {
             }
             else {
                 const WalkArgs la = reload_walk_args();   // arguments are not kept live across the loop
+                // normaliser of this transition from the per-edge table (float32 CSR graphs), when the walker
+                // arrived by a real CSR entry
+                T ktot = (T)0;
+                bool have_tot = false;
+                if (!DENSE && la.tot_e) {
+                    if (j == 1) { ktot = (T)as_scalar<float>((uint64_t)la.tot_v)[cur]; have_tot = true; }
+                    else if (prev_edge != NOT_FOUND) { ktot = (T)as_scalar<float>((uint64_t)la.tot_e)[prev_edge]; have_tot = true; }
+                }
                 choice = sample_step_weighted<T, DENSE>(la, mask, EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, queue, cur,
-                                                        j >= 2, prev, t0, dp, r, s0, d);
+                                                        j >= 2, prev, t0, dp, r, s0, d, have_tot ? &ktot : nullptr);
             }
             choice = uni(choice);
             bool clamped = false;
@@ -1381,6 +1405,7 @@ walk_kernel(WalkArgs a) {
             const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
             if (pos >= nnz) { pos = nnz - 1; clamped = true; }
             if (clamped && lane == 0) stat[2]++;
+            prev_edge = (real_edge && !clamped) ? (uint32_t)pos : NOT_FOUND;
             // The edge just taken: one 16-byte record names the next vertex, its degree, the number of
             // common neighbours and where cur sits in the next vertex's row.  When cur's row is the
             // shorter one it supplies the keys of the next step: request the first 64 right away, together
@@ -1424,6 +1449,51 @@ walk_kernel(WalkArgs a) {
     if (lane < 16) atomicAdd(&g_prof[lane], pf.acc[lane]);
 #endif
     if (lane < 4 && stat[lane]) atomicAdd((unsigned long long *)PW_KARG(uint64_t, stats) + lane, stat[lane]);
+}
+
+// Per-edge normalisers of a weighted CSR graph for one (p, q, extend): work item e < nnz = CSR entry (u -> v):
+// tot_e[e] = pass 1 of sample_step_weighted for cur = v, prev = u; item nnz + v: tot_v[v] = the unbiased row sum of v.
+// One wavefront per item (persistent grid); bit-identical to what the walk step would compute, because it IS the
+// walk step's code.  Cost: sum over edges of the row length of the head = sum of squared degrees -- one pass of
+// ~E[d_visit] elements per CSR entry, against E[d_visit] elements TWICE per sampled step without the table.
+template <bool EXTEND>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, EXTEND ? PW_MIN_WAVES - 1 : PW_MIN_WAVES)
+tot_build_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused, float *tot_e_unused, float *tot_v_unused) {
+    // (like walk_kernel, every argument is re-read from the kernarg segment at its point of use: values kept live
+    //  across the step code would be spilled, and the allocator's SGPR spill slots do not survive this loop)
+    __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
+    __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue[WAVES_PER_BLOCK][2 * QCAP];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;   // edge_row, tot_e, tot_v follow the struct
+    for (;;) {
+        unsigned long long item = 0;
+        if (lane == 0) item = atomicAdd((unsigned long long *)PW_KARG(uint64_t, job_counter), 1ull);
+        item = readfirst_u64(item);
+        const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
+        if (item >= (uint64_t)nnz + PW_KARG(uint32_t, g.n_nodes)) break;
+        const bool is_edge = item < nnz;
+        const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+        uint32_t cur = (uint32_t)(item - nnz), prev = 0;
+        const uint32_t dbg = PW_KARG(uint32_t, L);   // debug switches: 1 no edge_row load, 2 no stores, 4 no compute
+        if (is_edge) {
+            cur = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[item];
+            if (!(dbg & 1u)) prev = as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[item];
+        }
+        const uint32_t s0 = indptr[cur], d = indptr[cur + 1] - s0;
+        const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
+        float tot = 0.0f;
+        if (d && !(dbg & 4u)) {
+            const WalkArgs la = reload_walk_args();
+            (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur,
+                                                     is_edge, prev, t0, dp, 0.0, s0, d, nullptr, &tot);
+        }
+        if (lane == 0 && !(dbg & 2u)) {
+            if (is_edge) ((gptr_mut<float>)kernarg<uint64_t>(XARG + 8))[item] = tot;
+            else ((gptr_mut<float>)kernarg<uint64_t>(XARG + 16))[item - nnz] = tot;
+        }
+    }
 }
 
 }  // namespace pw

@@ -167,3 +167,37 @@ def test_bench_self_launches_two_ranks_and_gathers():
     assert rec["n_gpus"] == 2 and rec["config"]["gather_on_rank0"] is True
     assert len(rec["config"]["per_rank_walk_kernel_ms"]) == 2
     assert rec["roofline"]["frac"] <= 1.0
+
+
+def test_weighted_normaliser_table_equals_the_two_pass_step(monkeypatch):
+    """Weighted graphs: the per-edge normaliser table (built by the walk step's own pass 1) must not change a
+    single transition -- node2vec and node2vec+, incl. rows longer than the mask segment."""
+    import torch
+
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, data = rmat_csr(15, seed=4, weighted=True)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 3)
+    np.random.RandomState(2).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, extend=True, gamma=0)
+    with np.errstate(all="ignore"):
+        thr = np.nan_to_num(g.get_noise_thresholds(), nan=0.0)
+    table = WalkEngine.from_csr(indptr, indices, data)
+    table.set_thresholds(thr)
+    monkeypatch.setenv("PECANPY_AMD_NO_TOT", "1")
+    plain = WalkEngine.from_csr(indptr, indices, data)
+    plain.set_thresholds(thr)
+    for extend, p, q in ((False, 0.5, 2.0), (True, 0.5, 2.0), (False, 0.3, 1.7), (True, 3.0, 0.4)):
+        monkeypatch.setenv("PECANPY_AMD_NO_TOT", "1")
+        b = plain.simulate_device("SparseOTF", p, q, extend, d_starts, 40, seed=7)
+        assert plain.last_stats["param_index_ms"] == 0
+        monkeypatch.delenv("PECANPY_AMD_NO_TOT")
+        a = table.simulate_device("SparseOTF", p, q, extend, d_starts, 40, seed=7)
+        assert table.last_stats["param_index_ms"] > 0                      # built for these parameters ...
+        a2 = table.simulate_device("SparseOTF", p, q, extend, d_starts, 40, seed=7)
+        assert table.last_stats["param_index_ms"] == 0                     # ... and cached
+        assert torch.equal(a, b) and torch.equal(a, a2), (extend, p, q)
+        assert table.last_stats["total_steps"] == plain.last_stats["total_steps"]
+        assert table.last_stats["overflow_reads"] == plain.last_stats["overflow_reads"]
