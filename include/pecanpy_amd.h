@@ -136,6 +136,21 @@ int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
                        int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
                        pw_stats *stats);
 
+/* One transition of the on-the-fly modes for a given (cur, prev) -- the operator boundary of the reference's
+ * callbacks: move_forward(cur, prev) (pecanpy.py:543-559 / 597-612) with the uniform draw r in [0, 1) supplied by the
+ * caller (the reference draws it with np.random.random() inside), and get_normalized_probs(cur, prev)
+ * (rw/sparse_rw.py:51-130, rw/dense_rw.py:34-118).  has_prev = 0: first step of a walk (prev ignored).
+ *   pw_step : *next = sampled neighbour, *position (may be NULL) = its index in cur's row (== degree when the float
+ *             CDF never reached r: the reference's overflow read, mirrored)
+ *   pw_probs: probs = float32[degree(cur)] for CSR handles, float64[degree(cur)] for dense handles (room for the
+ *             maximum degree of the graph), *n = degree(cur)
+ * The same device code as the walk kernels' eager step; one launch per call (API compatibility and tests, not a
+ * throughput path). */
+int pw_step(pw_graph *g, int mode, double p, double q, int extend, uint32_t cur, int has_prev, uint32_t prev, double r,
+            uint32_t *next, uint32_t *position);
+int pw_probs(pw_graph *g, int mode, double p, double q, int extend, uint32_t cur, int has_prev, uint32_t prev, void *probs,
+             uint32_t *n);
+
 /* Alias tables of the PreComp modes, built on the device and kept in the handle.
  *   first_order = 0: PreComp.preprocess_transition_probs (pecanpy.py:442-507): sum(deg^2) entries,
  *                    table of (v, k-th neighbour as prev) at alias_indptr[v] + deg(v) * k

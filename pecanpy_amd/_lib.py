@@ -64,6 +64,10 @@ SYMBOLS = {
     "pw_graph_destroy": (None, [C.c_void_p]),
     "pw_simulate": (C.c_int, _SIM_ARGS),
     "pw_simulate_device": (C.c_int, _SIM_ARGS),
+    "pw_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_double,
+                          _u32p, _u32p]),
+    "pw_probs": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p,
+                           _u32p]),
     "pw_precomp_build": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int]),
     "pw_precomp_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "pw_count_stream_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,

@@ -1213,6 +1213,89 @@ PW_EXPORT int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, do
     return PW_OK;
 }
 
+// ---- single-step probe (Base.get_move_forward of the drop-in API; probability vectors for the parity tests) --------
+typedef void (*probe_kernel_fn)(pw::WalkArgs, const pw::ProbeArgs *);
+
+static int run_probe(pw_graph *g, int mode, double p, double q, int extend, uint32_t cur, int has_prev, uint32_t prev, double r,
+                     void *probs_host, uint32_t *out_host) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (mode == PW_MODE_SPARSE_OTF && g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph handle");
+    if (mode == PW_MODE_DENSE_OTF && g->kind != 1) return fail(PW_ERR_UNSUPPORTED, "DenseOTF needs a dense graph handle");
+    if (mode != PW_MODE_SPARSE_OTF && mode != PW_MODE_DENSE_OTF) return fail(PW_ERR_UNSUPPORTED, "single steps are provided for the on-the-fly modes");
+    if (g->bits_only) return fail(PW_ERR_UNSUPPORTED, "dense graph created from packed bits has no compressed rows");
+    if (!(p > 0) || !(q > 0)) return fail(PW_ERR_INVALID, "p and q must be positive");
+    if (cur >= g->n_nodes || (has_prev && prev >= g->n_nodes)) return fail(PW_ERR_INVALID, "vertex out of range");
+    if (extend && !g->unit && !g->d_thr) return fail(PW_ERR_INVALID, "extend: call pw_graph_set_thresholds() first");
+    if (set_device(g)) return PW_ERR_HIP;
+    const bool ext = extend && !g->unit;
+    const size_t elem = g->kind == 0 ? sizeof(float) : sizeof(double);
+    pw::ProbeArgs *d_pa = nullptr;
+    uint32_t *d_out = nullptr;
+    void *d_probs = nullptr;
+    auto cleanup = [&]() {
+        if (d_pa) (void)hipFree(d_pa);
+        if (d_out) (void)hipFree(d_out);
+        if (d_probs) (void)hipFree(d_probs);
+    };
+    hipError_t e = hipMalloc((void **)&d_pa, sizeof(pw::ProbeArgs));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * sizeof(uint32_t));
+    if (e == hipSuccess && probs_host) e = hipMalloc(&d_probs, elem * ((size_t)g->max_degree + 1));
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_NOMEM, hipGetErrorString(e)); }
+    pw::ProbeArgs pa;
+    pa.cur = cur; pa.has_prev = has_prev ? 1u : 0u; pa.prev = has_prev ? prev : 0u; pa.want_probs = probs_host ? 1u : 0u;
+    pa.r = r; pa.probs = d_probs; pa.out = d_out;
+    pw::WalkArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.g = csr_dev(g);
+    wa.p = p;
+    wa.q = q;
+    wa.L = 1;
+    wa.w_out = (float)(1.0 / q);
+    wa.w_prev = (float)(1.0 / p);
+    probe_kernel_fn fn;
+    if (g->kind == 0) fn = g->unit ? pw::step_probe_kernel<float, false, true, false>
+                                    : (ext ? pw::step_probe_kernel<float, false, false, true> : pw::step_probe_kernel<float, false, false, false>);
+    else fn = g->unit ? pw::step_probe_kernel<double, true, true, false>
+                      : (ext ? pw::step_probe_kernel<double, true, false, true> : pw::step_probe_kernel<double, true, false, false>);
+    uint32_t zero[4] = {0, 0, 0, 0};
+    e = hipMemcpyAsync(d_pa, &pa, sizeof(pa), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out, zero, sizeof(zero), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fn, dim3(1), dim3(pw::WAVE), 0, g->stream, wa, (const pw::ProbeArgs *)d_pa);
+        e = hipGetLastError();
+    }
+    uint32_t out[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess && probs_host && out[2]) e = hipMemcpy(probs_host, d_probs, elem * out[2], hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("single-step probe: ") + hipGetErrorString(e));
+    out_host[0] = out[0]; out_host[1] = out[1]; out_host[2] = out[2];
+    return PW_OK;
+}
+
+PW_EXPORT int pw_step(pw_graph *g, int mode, double p, double q, int extend, uint32_t cur, int has_prev, uint32_t prev, double r,
+                      uint32_t *next, uint32_t *position) {
+    if (!next) return fail(PW_ERR_INVALID, "null pointer");
+    uint32_t out[3];
+    int rc = run_probe(g, mode, p, q, extend, cur, has_prev, prev, r, nullptr, out);
+    if (rc) return rc;
+    if (out[2] == 0) return fail(PW_ERR_INVALID, "vertex has no neighbours");
+    *next = out[1];
+    if (position) *position = out[0];
+    return PW_OK;
+}
+
+PW_EXPORT int pw_probs(pw_graph *g, int mode, double p, double q, int extend, uint32_t cur, int has_prev, uint32_t prev, void *probs,
+                       uint32_t *n) {
+    if (!probs || !n) return fail(PW_ERR_INVALID, "null pointer");
+    uint32_t out[3];
+    int rc = run_probe(g, mode, p, q, extend, cur, has_prev, prev, 0.5, probs, out);
+    if (rc) return rc;
+    *n = out[2];
+    return PW_OK;
+}
+
 // ---- host self test of the exact-arithmetic decision ---------------------------------------------------
 PW_EXPORT int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                          uint32_t n_r, uint32_t *chain, uint32_t *exact) {

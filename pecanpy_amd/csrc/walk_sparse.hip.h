@@ -1496,4 +1496,118 @@ tot_build_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused
     }
 }
 
+// ---- single-step probe: the reference's move_forward / get_normalized_probs for ONE (cur, prev) ----------------------
+// Backs pw_step / pw_probs (include/pecanpy_amd.h): Base.get_move_forward() of the drop-in API and the bitwise
+// comparison of the HIP path's probability vectors with the reference-generated fixtures.  One wavefront; the
+// sampling is the walk kernels' own eager step, the probabilities are the values that step sums: w_k / tot with the
+// same membership mask, the same biased weights and the same sequential float sum.
+struct ProbeArgs {
+    uint32_t cur, has_prev, prev, want_probs;
+    double r;
+    void *probs;        // T[degree(cur)] (float32 CSR graphs, float64 dense graphs), or nullptr
+    uint32_t *out;      // [0] sampled position (== degree: the CDF never reached r) [1] next vertex [2] degree(cur)
+};
+
+template <typename T, bool DENSE, bool UNIT, bool EXTEND>
+__global__ void __launch_bounds__(WAVE)
+step_probe_kernel(WalkArgs a_unused, const ProbeArgs *pa_unused) {
+    __shared__ uint32_t s_mask[MASK_WORDS];
+    __shared__ uint16_t s_rank[MASK_WORDS + 2];
+    __shared__ uint32_t s_in[EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue[2 * QCAP];
+    const int lane = lane_id();
+    constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
+    const ProbeArgs pa = *(const ProbeArgs *)kernarg<uint64_t>(XARG);
+    const WalkArgs la = reload_walk_args();
+    const uint32_t cur = uni(pa.cur), prev = uni(pa.prev);
+    const bool has_prev = uni(pa.has_prev) != 0u;
+    const uint32_t s0 = uni(la.g.indptr[cur]), d = uni(la.g.indptr[cur + 1]) - s0;
+    const uint32_t t0 = has_prev ? uni(la.g.indptr[prev]) : 0u, dp = has_prev ? uni(la.g.indptr[prev + 1]) - t0 : 0u;
+    if (lane == 0) pa.out[2] = d;
+    if (d == 0) return;
+    uint32_t choice;
+    if (UNIT) choice = sample_step_unit<T, DENSE>(la, s_mask, s_rank, s_queue, cur, has_prev, prev, t0, dp, pa.r, s0, d);
+    else choice = sample_step_weighted<T, DENSE>(la, s_mask, EXTEND ? s_in : nullptr, s_queue, cur, has_prev, prev, t0, dp, pa.r, s0, d);
+    choice = uni(choice);
+    if (lane == 0) {
+        uint32_t c = choice;
+        if (DENSE && c >= d) c = d - 1;   // dense rows: the reference reads past a temporary, clamped (walk kernel)
+        uint64_t pos = (uint64_t)s0 + c;
+        if (pos >= la.g.nnz) pos = la.g.nnz - 1;
+        pa.out[0] = choice;
+        pa.out[1] = la.g.indices[pos];
+    }
+    if (!pa.want_probs) return;
+    T *probs = (T *)pa.probs;
+    const T *__restrict__ data = (const T *)la.g.data;
+    // the step's value view (identical set-up to sample_step_unit / sample_step_weighted)
+    RowVals<T, UNIT> rv;
+    rv.drow = UNIT ? nullptr : data + s0;
+    rv.mask = s_mask;
+    rv.has_prev = has_prev;
+    rv.p = la.p;
+    rv.q = la.q;
+    rv.tot = (T)1;
+    rv.prev_pos = NOT_FOUND;
+    rv.normalize = false;
+    rv.extend = EXTEND;
+    rv.setup_bias();
+    if (UNIT) {
+        rv.u_in = (T)1;
+        rv.u_out = has_prev ? uni(Arith<T>::bias_div((T)1, la.q)) : (T)1;
+        rv.u_prev = uni(Arith<T>::bias_div((T)1, la.p));
+    }
+    if (EXTEND) {
+        rv.in_mask = s_in;
+        rv.crow = la.g.indices + s0;
+        rv.prow = la.g.indices + t0;
+        rv.pdata = data + t0;
+        rv.thr = la.g.thr;
+        rv.dp = dp;
+        if (!DENSE && has_prev) {
+            const uint64_t tb0 = readfirst_u64(la.g.tab_off[prev]);
+            rv.ptmask = (uint32_t)(readfirst_u64(la.g.tab_off[prev + 1]) - tb0) - 1u;
+            rv.ptab = la.g.slots + tb0;
+        }
+        rv.thr_cur = __uint_as_float(uni(__float_as_uint(la.g.thr[cur])));
+    }
+    const bool multi = has_prev && d > SEG;
+    if (multi) {
+        const uint32_t pos = uni(lower_bound_u32(la.g.indices + s0, d, prev));
+        if (pos < d && uni(la.g.indices[s0 + pos]) == prev) rv.prev_pos = pos;
+    }
+    T tot = (T)0;
+    for (int pass = 0; pass < 2; pass++) {   // pass 0: tot, pass 1: normalised values
+        for (uint32_t sa = 0; sa < d; sa += SEG) {
+            const uint32_t len = d - sa < SEG ? d - sa : SEG;
+            if (has_prev && (multi || pass == 0)) {
+                const uint32_t pp = segment_mask<T, DENSE>(la.g, s_mask, EXTEND ? s_in : nullptr, s_queue, cur, s0, sa, len, t0, dp, prev);
+                if (!multi) rv.prev_pos = pp;
+                if (UNIT && rv.prev_pos != NOT_FOUND && rv.prev_pos >= sa && rv.prev_pos < sa + len) {
+                    const uint32_t rr = rv.prev_pos - sa;   // unit rows keep prev's own bit clear (three disjoint classes)
+                    if (lane == 0) s_mask[rr >> 5] &= ~(1u << (rr & 31));
+                    wave_lds_fence();
+                }
+            }
+            rv.seg_a = sa;
+            rv.kend = sa + len;
+            if (pass == 0) seq_scan<T, false>(tot, sa, sa + len, 0.0, rv, sa == 0 ? WAVE : 0);
+            else
+                for (uint32_t kb = sa; kb < sa + len; kb += WAVE) {   // (value_ext votes across the wave: uniform trip count)
+                    const uint32_t k = kb + (uint32_t)lane;
+                    const bool valid = k < sa + len;
+                    T v = (T)0;
+                    if (!UNIT && EXTEND) v = rv.value_ext(k, valid);
+                    else if (valid) v = rv.one(k);
+                    if (valid) probs[k] = v;
+                }
+        }
+        if (pass == 0) {
+            tot = uni(tot);
+            if (UNIT) { rv.u_in = rv.u_in / tot; rv.u_out = rv.u_out / tot; rv.u_prev = rv.u_prev / tot; }
+            else { rv.normalize = true; rv.tot = tot; }
+        }
+    }
+}
+
 }  // namespace pw

@@ -34,6 +34,7 @@ class WalkEngine:
         self.n_nodes = n_nodes
         self.device = device
         self.last_stats = None
+        self._max_degree = n_nodes   # upper bound; from_csr / from_dense narrow it
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
@@ -46,7 +47,9 @@ class WalkEngine:
         h = C.c_void_p()
         _lib.check(lib.pw_csr_create(_np_ptr(indptr), _np_ptr(indices), _np_ptr(data),
                                      indptr.size - 1, indices.size, int(device), C.byref(h)))
-        return cls(h, lib, "csr", indptr.size - 1, int(device))
+        eng = cls(h, lib, "csr", indptr.size - 1, int(device))
+        eng._max_degree = int(np.diff(indptr.astype(np.int64)).max()) if indptr.size > 1 else 0
+        return eng
 
     @classmethod
     def from_dense(cls, data, device=0):
@@ -134,6 +137,30 @@ class WalkEngine:
             int(seed or 0) & 0xFFFFFFFF, int(stream_skip), C.c_void_p(out.data_ptr()), C.byref(st)))
         self.last_stats = st.as_dict()
         return out
+
+    # ---- single transitions (the reference's move_forward / get_normalized_probs callbacks) ---------------
+    def step(self, mode, p, q, extend, cur, prev=None, r=None):
+        """``move_forward(cur, prev)`` on the device with the uniform draw ``r`` (default: ``np.random.random()``,
+        as the reference draws it); returns the next vertex index."""
+        if r is None:
+            r = np.random.random()
+        nxt, pos = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(self._lib.pw_step(self._h, MODE_IDS[mode], float(p), float(q), int(bool(extend)), int(cur),
+                                     int(prev is not None), int(prev or 0), float(r), C.byref(nxt), C.byref(pos)))
+        return int(nxt.value)
+
+    def probs(self, mode, p, q, extend, cur, prev=None):
+        """``get_normalized_probs(cur, prev)`` computed by the walk kernels' own step code: float32 (CSR) or
+        float64 (dense) vector over ``cur``'s neighbours."""
+        dt = np.float32 if self.kind == "csr" else np.float64
+        buf = np.zeros(self.max_degree() + 1, dtype=dt)
+        n = C.c_uint32(0)
+        _lib.check(self._lib.pw_probs(self._h, MODE_IDS[mode], float(p), float(q), int(bool(extend)), int(cur),
+                                      int(prev is not None), int(prev or 0), _np_ptr(buf), C.byref(n)))
+        return buf[: int(n.value)].copy()
+
+    def max_degree(self):
+        return int(self._max_degree)
 
     def precomp_build(self, p, q, extend, first_order):
         """Alias tables on the device (PreComp / PreCompFirstOrder preprocessing)."""

@@ -214,10 +214,38 @@ class Base(BaseGraph):
             return to_uint32_numpy(rows), bounds
         return to_uint32_numpy(full)
 
+    def get_move_forward(self):
+        """``move_forward(cur_idx, prev_idx=None) -> next_idx`` of the on-the-fly modes (pecanpy.py:522-561, 576-614),
+        evaluated on the GPU by the walk kernels' own step code (``pw_step``); the uniform draw comes from
+        ``np.random.random()`` as in the reference.  One kernel launch per call: for API compatibility and
+        inspection -- ``simulate_walks`` is the throughput path."""
+        if self._mode not in ("SparseOTF", "DenseOTF"):
+            raise NotImplementedError(f"{self._mode}: single steps are provided for the on-the-fly modes")
+        eng = self._get_engine()
+        mode, p, q, extend = self._mode, self.p, self.q, self.extend
+
+        def move_forward(cur_idx, prev_idx=None):
+            return eng.step(mode, p, q, extend, cur_idx, prev_idx)
+
+        return move_forward
+
     def setup_get_normalized_probs(self):
-        """Kept for API compatibility: returns ``(None, thresholds-or-None)``; the transition
-        probabilities themselves are computed inside the HIP kernels."""
-        return None, (self.get_noise_thresholds() if self.extend else None)
+        """``(get_normalized_probs, noise_thresholds)`` as the reference returns them (pecanpy.py:212-229).  The
+        callable keeps the reference's signature ``(data, indices, indptr, p, q, cur_idx, prev_idx=None,
+        average_weight_ary=None)`` but computes on the GPU from the graph this object holds (``pw_probs``: the
+        probabilities the walk kernels sample from, bit for bit)."""
+        thr = self.get_noise_thresholds() if self.extend else None
+        if self._mode == "DenseOTF":
+            mode = "DenseOTF"
+        else:
+            mode = "SparseOTF"      # the alias modes precompute exactly these vectors (pecanpy.py:442-507)
+        eng = self._get_engine()
+        extend = self.extend
+
+        def get_normalized_probs(data, indices, indptr, p, q, cur_idx, prev_idx=None, average_weight_ary=None):
+            return eng.probs(mode, p, q, extend, cur_idx, prev_idx)
+
+        return get_normalized_probs, thr
 
     def preprocess_transition_probs(self):
         """No-op for on-the-fly modes (pecanpy.py:231-233)."""
