@@ -159,3 +159,28 @@ def test_walk_corpus_is_lazy_and_reiterable():
     g = node2vec.SparseOTF()
     g.set_node_ids(ids)
     assert [g._map_walk(r) for r in mat] == want
+
+
+def test_read_npz_memory_maps_uncompressed_members(tmp_path):
+    """.csr.npz ingestion (reference graph.py:447-486): members stored uncompressed in the CSR dtypes are memory-mapped
+    (no host copy on the way to the GPU); anything else falls back to np.load with a dtype conversion."""
+    from pecanpy_amd import graph
+    from pecanpy_amd.synth import rmat_csr
+
+    ip, ix, dt = rmat_csr(9, seed=2, weighted=True)
+    ids = np.arange(ip.size - 1).astype(str)
+    p = str(tmp_path / "g.csr.npz")
+    np.savez(p, IDs=ids, data=dt, indptr=ip, indices=ix)
+    g = graph.SparseGraph()
+    g.read_npz(p, True)
+    assert isinstance(g.indices, np.memmap) and isinstance(g.indptr, np.memmap) and isinstance(g.data, np.memmap)
+    assert np.array_equal(g.indptr, ip) and np.array_equal(g.indices, ix) and np.array_equal(g.data, dt)
+    assert list(g.nodes) == list(ids)
+    u = graph.SparseGraph()
+    u.read_npz(p, False)                       # unweighted: all weights count as one
+    assert np.array_equal(u.data, np.ones(ix.size, dtype=np.float32))
+    np.savez_compressed(p, IDs=ids, data=dt.astype(np.float64), indptr=ip.astype(np.int64), indices=ix)
+    c = graph.SparseGraph()
+    c.read_npz(p, True)
+    assert c.indptr.dtype == np.uint32 and c.data.dtype == np.float32
+    assert np.array_equal(c.indptr, ip) and np.array_equal(c.indices, ix) and np.array_equal(c.data, dt)
