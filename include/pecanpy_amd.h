@@ -225,10 +225,12 @@ int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, floa
  * position, 0xfffffffb when that prefix never reaches r[i], 0xfffffffa on a rounding tie the thread cannot afford
  * (the walk is then redone by the wavefront kernel).  use_hints != 0: both searches start from the per-list hint
  * table (csrc/seqscan.h: build_list_hints) -- same results, fewer list reads; probes (may be NULL) = list / hint
- * entries read per target. */
+ * entries read per target.  refined (may be NULL) = lane[i] after the refined decision of ambiguous targets
+ * (csrc/seqscan.h: lane_refine, the chain's drift computed from per-binade class counts): decided index or still
+ * 0xfffffffd. */
 int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                             uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
-                            int use_hints, uint32_t *probes);
+                            int use_hints, uint32_t *probes, uint32_t *refined);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

@@ -940,16 +940,14 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         unsigned long long hp[16], zero[16] = {0};
         HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(pw::g_lprof), sizeof(hp)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pw::g_lprof), zero, sizeof(zero)));
-        static const char *names[4] = {"refill", "draw + exact decision", "float chains", "edge record + store"};
+        static const char *names[5] = {"refill", "draw + exact decision", "refined decisions", "edge record + store", "float chains"};
         double tot = 0;
-        for (int i = 0; i < 4; i++) tot += (double)hp[i];
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 5; i++) tot += (double)hp[i];
+        for (int i = 0; i < 5; i++)
             fprintf(stderr, "[lane_prof] %-22s %6.2f%%  %.0f cycles per iteration\n", names[i], 100.0 * hp[i] / tot, (double)hp[i] / (double)hp[8]);
-        for (int bk = 0; bk < 4; bk++)
-            fprintf(stderr, "[lane_prof] chain passes with %s lanes: %llu, %.0f cycles each\n", bk == 0 ? "1-2" : (bk == 1 ? "3-4" : (bk == 2 ? "5-8" : "9+")),
-                    hp[4 + bk], hp[4 + bk] ? (double)hp[12 + bk] / (double)hp[4 + bk] : 0.0);
-        fprintf(stderr, "[lane_prof] iterations %llu  chain passes %llu (%.1f lanes each)  runnable lanes per iteration %.1f\n", hp[8], hp[9],
-                hp[9] ? (double)hp[10] / (double)hp[9] : 0.0, (double)hp[11] / (double)hp[8]);
+        fprintf(stderr, "[lane_prof] iterations %llu  refinement passes %llu (%.1f lanes each, %.0f cycles)  chain passes %llu (%.1f lanes each, %.0f cycles)\n",
+                hp[8], hp[9], hp[9] ? (double)hp[10] / (double)hp[9] : 0.0, hp[9] ? (double)hp[2] / (double)hp[9] : 0.0, hp[5],
+                hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[5] ? (double)hp[4] / (double)hp[5] : 0.0);
     }
 #endif
     float lms = 0;
@@ -1380,7 +1378,7 @@ PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, dou
 // ---- host self test of the lane kernel's per-thread decision (seqscan.h: lane_decide) ----------------------------
 PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                       uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
-                                      int use_hints, uint32_t *probes) {
+                                      int use_hints, uint32_t *probes, uint32_t *refined) {
     if (!cls || !r || !chain || !lane || !kmax || n == 0) return fail(PW_ERR_INVALID, "bad argument");
     auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
     if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
@@ -1414,11 +1412,15 @@ PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_ou
             if ((double)c >= r[i]) { kc = k; break; }
         }
         chain[i] = kc;
-        pw::LaneStep ls{0.0f, 0u, 0u};
+        pw::LaneStep ls{0.0f, 0u, 0u, 0u, 0u, 0u};
         lane[i] = pw::lane_decide(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls, hp, hs_in, hs_out, wd);
         if (probes) probes[i] = ls.probes;
         kmax[i] = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : 0u;
         if (lane[i] != pw::LANE_REDO && ls.tot != tot) return fail(PW_ERR_INVALID, "row total mismatch");
+        if (refined) {      // the refined decision of ambiguous steps (seqscan.h: lane_refine)
+            uint32_t rr = 0;
+            refined[i] = lane[i] == pw::LANE_AMBIGUOUS ? pw::lane_refine(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls, rr) : lane[i];
+        }
         if (chain_lane) {   // the per-thread float chain: over the ambiguous prefix, or the whole row when decided
             const uint32_t kend = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : n;
             uint32_t reads = 0;

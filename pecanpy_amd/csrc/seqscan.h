@@ -193,6 +193,13 @@ PW_HD ExactThresholds exact_thresholds_f32(double R, uint32_t prefix, uint32_t w
     return t;
 }
 
+// the drift bound zr itself (units) for partial sums up to mass R
+PW_HD double drift_bound_f32(double R, uint32_t prefix, uint32_t wmax_units) {
+    const double wmax = (double)wmax_units + 2.0;
+    const double jb = (double)prefix < R + 2.0 ? (double)prefix : R + 2.0;
+    return ((jb + 6.0) * (R + wmax) - 0.5 * jb * (jb - 1.0)) * (1.0001 / 16777216.0) + 1e-6;
+}
+
 // float64 flavour (DenseOTF): the same bound with 2^-53; R = r * units itself is rounded (2^-52 relative).
 struct ExactThresholds64 {
     uint64_t lo, hi;
@@ -405,6 +412,9 @@ struct LaneStep {
     float tot;        // exact row total (float32)
     uint32_t kmax;    // ambiguous steps: leading positions the float chain can need
     uint32_t probes;  // list / hint entries read
+    uint32_t k1;      // ambiguous steps: every position below k1 is known to stay below r
+    uint32_t f;       // ... number of common neighbours before k1
+    uint32_t shifts;  // ... sh_in | sh_out << 8 | sh_prev << 16 (weights in units of the smallest)
 };
 
 struct MassEval {   // E(P_i) in units of the smallest weight
@@ -439,7 +449,7 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     const uint32_t lo_th = th.lo, hi_th = th.hi;
     const uint32_t wp = 1u << sh_prev;
     // first common neighbour whose exact mass reaches lo_th
-    uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0;
+    uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0, f_below = 0;
     if (n_in) {
         uint32_t g = 0xffffffffu;
         if (hint && sh_in >= hs_in) {   // hint units are 2^(sh_in - hs_in) of this step's units
@@ -450,6 +460,7 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
         const SearchResult sr = guided_search(cl, 0u, n_in, g, ev, (uint64_t)lo_th, ls.probes);
         if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
         if (sr.f < n_in) { p_f = sr.p_at; e_f = (uint32_t)sr.v_at; }
+        f_below = sr.f;   // entries whose mass stays below lo_th: exactly the common neighbours before k1
     }
     uint32_t e1;
     uint32_t k1 = solve_out_run(s_run, base, lo_th, (n_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, wp, e1);
@@ -458,6 +469,9 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     // every j < k1 has c_j < r; the chain reaches r at the latest where E >= hi_th, and E grows by >= 1 per element
     const uint64_t km = (uint64_t)k1 + (uint64_t)(hi_th > lo_th ? hi_th - lo_th : 0u) + 2ull;
     ls.kmax = km < d ? (uint32_t)km : d;
+    ls.k1 = k1;
+    ls.f = f_below;
+    ls.shifts = sh_in | (sh_out << 8) | (sh_prev << 16);
     return LANE_AMBIGUOUS;
 }
 
@@ -709,6 +723,194 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
     return LANE_CHAIN_END;
 #undef PW_LANE_SEQ
 #undef PW_LANE_CURSOR
+}
+
+// ---- refined decision of an ambiguous step: the drift of the float32 chain, computed instead of bounded ---------
+// lane_decide's bound treats every rounding as a worst case; but the chain's roundings are SYSTEMATIC.  While the
+// sum stays in binade e, adding a value of class c moves it by inc_{e,c} ulps exactly (no tie), i.e. errs by the
+// constant  delta_{e,c} = inc_{e,c} * ulp_e - x_c;  the only other roundings are the one addition per binade that
+// crosses its top (|error| <= ulp/2 of the binade entered).  Hence with n_{e,c} = number of class-c additions inside
+// binade e before position k0,
+//      c_k0 = E(k0) * x_unit  +  sum_e sum_c n_{e,c} * delta_{e,c}  +  (crossing errors),
+// and the n_{e,c} follow from the POSITIONS where the sum enters each binade, which lie within the a-priori drift of
+// where the exact mass reaches 2^e: an E-space search per binade (mass_locate), independent of one another.  The top
+// LANE_RF binades are evaluated this way, everything below is bounded (its ulps are 2^LANE_RF times smaller).  Error
+// budget eps (all provable): crossings <= ulp_top; additions below the evaluated binades <= count * ulp/2;
+// a boundary misplaced by m positions <= m * 0.75 ulp of its binade; float64 evaluation 2^-45.  The interval
+// [c - eps, c + eps] pins the integer significand C of c_k0 to a few candidates; the step is decided when its
+// lowest and highest candidate agree on the element that reaches r inside the top binade (closed form, as in
+// lane_chain).  Anything else -- ties, prev next in line, a crossing before r, candidates that disagree -- returns
+// LANE_AMBIGUOUS and the chain decides.  About 12 % of the RMAT-22 steps enter; ~0.x % leave undecided.
+constexpr int LANE_RF = 5;
+
+struct MassPos {
+    uint32_t pos;      // first position whose exact mass reaches the target (d when none)
+    uint32_t rank;     // common neighbours before pos
+    bool common;       // pos is a common neighbour
+};
+PW_HD MassPos mass_locate(const uint32_t *cl, uint32_t n_in, uint32_t d, uint32_t pp, uint32_t sh_in, uint32_t sh_out,
+                          uint32_t sh_prev, uint64_t target, uint32_t &reads) {
+    MassPos m;
+    uint32_t s_run = 0, base = 0, p_f = 0xffffffffu;
+    m.rank = 0;
+    if (n_in) {
+        const MassEval ev{pp, sh_in, sh_out, sh_prev};
+        const SearchResult sr = guided_search(cl, 0u, n_in, 0xffffffffu, ev, target, reads);
+        if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
+        if (sr.f < n_in) p_f = sr.p_at;
+        m.rank = sr.f;
+    }
+    uint32_t e1;
+    const uint32_t th = target > 0xffffffffull ? 0xffffffffu : (uint32_t)target;
+    uint32_t k = solve_out_run(s_run, base, th, (pp != 0xffffffffu && pp >= s_run) ? pp : 0xffffffffu, sh_out, 1u << sh_prev, e1);
+    m.common = false;
+    if (p_f != 0xffffffffu && k >= p_f) { k = p_f; m.common = true; }
+    m.pos = k < d ? k : d;
+    return m;
+}
+
+PW_HD uint32_t lane_refine(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev, const uint32_t *cl,
+                           const LaneStep &ls, uint32_t &reads) {
+    using B = Binade<float>;
+    const uint32_t sh_in = ls.shifts & 0xffu, sh_out = (ls.shifts >> 8) & 0xffu, sh_prev = (ls.shifts >> 16) & 0xffu;
+    const uint32_t k1 = ls.k1, i1 = ls.f, kend = ls.kmax;
+    if (k1 == 0 || k1 >= kend) return LANE_AMBIGUOUS;
+    const bool has_pv = pp != 0xffffffffu;   // (k0 = k1 - 1 is the last position known to stay below r)
+    const float x_in = 1.0f / ls.tot, x_out = x_in * w_out, x_pv = x_in * w_prev;
+    const double x_u = ldexp((double)x_in, -(int)sh_in);   // float value of one unit of mass (exact)
+    const uint32_t pv0 = (has_pv && pp < k1) ? 1u : 0u;
+    const uint64_t E0 = ((uint64_t)(k1 - i1 - pv0) << sh_out) + ((uint64_t)i1 << sh_in) + ((uint64_t)pv0 << sh_prev);
+    const double v0 = (double)E0 * x_u;                     // exact: 24 x 24 bits
+    int ex = 0;
+    (void)frexp(v0, &ex);                                   // v0 = m * 2^ex, m in [0.5, 1)
+    const int e_t = ex - 1 + 127;                           // binade (biased float32 exponent) of the exact mass value
+    if (e_t < 2 || e_t > 126) return LANE_AMBIGUOUS;
+    uint32_t sh_max = sh_in > sh_out ? sh_in : sh_out;
+    if (sh_prev > sh_max) sh_max = sh_prev;
+    // where the sum enters each of the top binades: LANE_RF independent E-space searches, run as ONE bisection loop
+    // (every trip issues the probes of all searches before it waits: one memory round trip per level, not LANE_RF)
+    MassPos bnd[LANE_RF];
+    double eps = ldexp(1.0, e_t - 150);                     // crossing additions: sum of ulp_e / 2 over all binades
+    int n_b = 0;
+    uint64_t T[LANE_RF];
+    uint32_t lo[LANE_RF], hi[LANE_RF], pb[LANE_RF], pa[LANE_RF];   // bisection bounds, entries below / at the target
+    uint64_t vb[LANE_RF];
+#pragma unroll
+    for (int j = 0; j < LANE_RF; j++) {
+        const int e = e_t - j;                              // bnd[j] = entry into binade e_t - j
+        T[j] = 0; lo[j] = 0; hi[j] = 0; pb[j] = 0xffffffffu; pa[j] = 0xffffffffu; vb[j] = 0;
+        if (e < 1) continue;
+        const double tau = ldexp(1.0, e - 127) / x_u;       // mass (units) at which the exact sum reaches 2^(e - 127)
+        T[j] = (uint64_t)ceil(tau);
+        hi[j] = n_in;
+        // the float sum enters the binade within the a-priori drift of that position
+        const double zeta = 1.01 * drift_bound_f32(tau + (double)(2u << sh_max), d, 1u << sh_max);
+        const double m_e = ceil(zeta) + 2.0;
+        eps += m_e * 0.75 * ldexp(1.0, e - 150);
+        n_b = j + 1;
+    }
+    {
+        const MassEval ev{pp, sh_in, sh_out, sh_prev};
+        bool more = true;
+        while (more) {
+            uint32_t P[LANE_RF];
+#pragma unroll
+            for (int j = 0; j < LANE_RF; j++) P[j] = lo[j] < hi[j] ? cl[(lo[j] + hi[j]) >> 1] : 0u;
+            more = false;
+#pragma unroll
+            for (int j = 0; j < LANE_RF; j++) {
+                if (lo[j] < hi[j]) {
+                    const uint32_t mid = (lo[j] + hi[j]) >> 1;
+                    const uint64_t v = ev(mid, P[j]);
+                    reads++;
+                    if (v >= T[j]) { hi[j] = mid; pa[j] = P[j]; }
+                    else { lo[j] = mid + 1u; pb[j] = P[j]; vb[j] = v; }
+                    more = more || lo[j] < hi[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LANE_RF; j++) {
+        bnd[j].pos = 0; bnd[j].rank = 0; bnd[j].common = false;
+        if (j >= n_b) continue;
+        const uint32_t s_run = pb[j] != 0xffffffffu ? pb[j] + 1u : 0u;
+        const uint32_t base = pb[j] != 0xffffffffu ? (uint32_t)vb[j] : 0u;
+        uint32_t e1;
+        const uint32_t th = T[j] > 0xffffffffull ? 0xffffffffu : (uint32_t)T[j];
+        uint32_t k = solve_out_run(s_run, base, th, (has_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, 1u << sh_prev, e1);
+        if (lo[j] < n_in && pa[j] != 0xffffffffu && k >= pa[j]) { k = pa[j]; bnd[j].common = true; }
+        bnd[j].pos = k < d ? k : d;
+        bnd[j].rank = lo[j];
+    }
+    if (n_b == 0) return LANE_AMBIGUOUS;
+    // additions before the lowest evaluated binade: bounded, half an ulp of the binade below it each
+    {
+        const int e_lo = e_t - (n_b - 1);
+        eps += ((double)bnd[n_b - 1].pos + 1.0) * 0.5 * ldexp(1.0, e_lo - 1 - 150);
+    }
+    // drift of the additions inside the evaluated binades
+    double drift = 0.0;
+#pragma unroll
+    for (int j = 0; j < LANE_RF; j++) {
+        if (j >= n_b) continue;
+        const int e = e_t - j;
+        const uint32_t a = bnd[j].pos;                                     // the crossing addition itself is in eps
+        // positions a < pos < b (b = entry into the next binade), or a < pos <= k0 in the top binade
+        const uint32_t b = j == 0 ? k1 : bnd[j - 1].pos;
+        if (b <= a + 1u) continue;
+        const uint32_t n = b - a - 1u;
+        const uint32_t rank_b = j == 0 ? i1 : bnd[j - 1].rank;
+        const uint32_t c_in = rank_b - bnd[j].rank - (bnd[j].common ? 1u : 0u);
+        const uint32_t c_pv = (has_pv && pp > a && pp < b) ? 1u : 0u;
+        if (c_in + c_pv > n) return LANE_AMBIGUOUS;                         // (cannot happen)
+        const uint32_t c_out = n - c_in - c_pv;
+        const Inc<float> qi = B::quantize(x_in, e), qo = B::quantize(x_out, e), qp = B::quantize(x_pv, e);
+        if ((c_in && qi.a0 != qi.a1) || (c_out && qo.a0 != qo.a1) || (c_pv && qp.a0 != qp.a1)) return LANE_AMBIGUOUS;
+        const double ulp = ldexp(1.0, e - 150);
+        drift += (double)c_in * ((double)qi.a0 * ulp - (double)x_in) + (double)c_out * ((double)qo.a0 * ulp - (double)x_out) +
+                 (double)c_pv * ((double)qp.a0 * ulp - (double)x_pv);
+    }
+    eps += ldexp(1.0, -45) + 1e-9 * fabs(drift);
+    // integer significand of c_k0 in the top binade: candidates [C_lo, C_hi]
+    const double ulp_t = ldexp(1.0, e_t - 150);
+    const double c_lo = v0 + drift - eps, c_hi = v0 + drift + eps;
+    if (!(c_lo >= ldexp(1.0, e_t - 127)) || !(c_hi < ldexp(1.0, e_t - 126))) return LANE_AMBIGUOUS;   // near a binade boundary
+    const uint64_t C_lo = (uint64_t)ceil(c_lo / ulp_t), C_hi = (uint64_t)floor(c_hi / ulp_t);
+    if (C_lo > C_hi || C_hi - C_lo > 64) return LANE_AMBIGUOUS;
+    // continue inside the top binade from position k1 for both ends of the interval: same element => decided
+    const uint64_t Tt = B::threshold(r, e_t);
+    if (Tt >= (uint64_t)B::TOP) return LANE_AMBIGUOUS;                     // r lies beyond this binade
+    if (has_pv && pp == k1) return LANE_AMBIGUOUS;                          // prev is next: a single real addition
+    const uint32_t lim = (has_pv && pp > k1 && pp < kend) ? pp : kend;
+    const Inc<float> qi = B::quantize(x_in, e_t), qo = B::quantize(x_out, e_t);
+    if (qi.a0 != qi.a1 || qo.a0 != qo.a1) return LANE_AMBIGUOUS;
+    const uint64_t ii = qi.a0, io = qo.a0;
+    uint32_t answer = LANE_AMBIGUOUS;
+    for (int side = 0; side < 2; side++) {
+        const uint64_t C = side == 0 ? C_lo : C_hi;
+        if (side == 1 && C_hi == C_lo) break;
+        if (C >= Tt) return LANE_AMBIGUOUS;                                 // c_k0 >= r would contradict the a-priori bound
+        const ChainEval ev{C, ii, io, k1, i1, lim};
+        const SearchResult sr = guided_search(cl, i1, n_in, i1 < n_in ? i1 : 0xffffffffu, ev, Tt, reads);
+        uint32_t s_run = k1, p_f = 0xffffffffu;
+        uint64_t base = C;
+        if (sr.has_below) { s_run = sr.p_below + 1u; base = sr.v_below; }
+        if (sr.f < n_in && sr.v_at != ~0ull) p_f = sr.p_at;
+        const uint32_t run_end = p_f != 0xffffffffu ? p_f : lim;
+        const uint64_t need = Tt > base ? Tt - base : 0ull;
+        uint64_t cnt = io ? div_floor_small(need + io - 1ull, io) : 0xffffffffull;
+        if (cnt == 0) cnt = 1;
+        const uint64_t jpos = (uint64_t)s_run + cnt - 1ull;
+        uint32_t kf;
+        if (jpos >= run_end) {
+            if (p_f == 0xffffffffu) return LANE_AMBIGUOUS;                  // not reached before prev / the prefix end
+            kf = p_f;
+        } else kf = (uint32_t)jpos;
+        if (side == 0) answer = kf;
+        else if (kf != answer) return LANE_AMBIGUOUS;
+    }
+    return answer;
 }
 
 }  // namespace pw

@@ -69,8 +69,8 @@ struct LanesArgs {
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
 
 // Optional section timing of the lane kernel (-DPW_PROF_LANES builds; tools/prof_lanes.sh): wave-level cycle sums
-//   [0] refill [1] draw + exact decision [2] float chains [3] edge record + store   and counts
-//   [8] loop iterations [9] chain passes [10] lanes in chain passes [11] runnable lanes summed over iterations
+//   [0] refill [1] draw + exact decision [2] refined decisions [3] edge record + store [4] float chains   and counts
+//   [8] loop iterations [9] refinement passes [10] lanes in them [5] chain passes [6] lanes in them
 #ifdef PW_PROF_LANES
 __device__ unsigned long long g_lprof[16];
 #define LPROF_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) lp[i] += now_ - lp_last; lp_last = __builtin_readcyclecounter(); } while (0)
@@ -84,7 +84,13 @@ __device__ unsigned long long g_lprof[16];
 #define PW_LANES_MIN_WAVES 6   // 80 VGPRs: the per-lane chain spills heavily at 64
 #endif
 #ifndef PW_LANES_WAIT
-#define PW_LANES_WAIT 16   // ambiguous lanes that gather before their float chains run
+#define PW_LANES_WAIT 16   // ambiguous lanes that gather before the refined decision runs
+#endif
+#ifndef PW_LANES_REFINE
+#define PW_LANES_REFINE 0  // 1: waiting lanes first try lane_refine (seqscan.h); measured 6 % slower -- DESIGN.md 9b
+#endif
+#ifndef PW_LANES_WAIT2
+#define PW_LANES_WAIT2 (PW_LANES_REFINE ? 8 : PW_LANES_WAIT)   // lanes that gather before their float chains run
 #endif
 
 // Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
@@ -99,7 +105,21 @@ __device__ unsigned long long g_lprof[16];
         } else {                                                                                \
             const uint4 *rp_ = (const uint4 *)(a.erec + ((uint64_t)A.s0 + choice));             \
             const uint4 r0_ = rp_[0], r1_ = rp_[1];                                             \
-            a.out[(uint64_t)A.job * W + A.j] = r0_.x;                                           \
+            {   /* output cells are staged four steps at a time: one 16-byte store instead of four 4-byte ones */ \
+                const uint32_t slot_ = (A.j - 1u) & 3u;                                         \
+                ob.v[0] = slot_ == 0u ? r0_.x : ob.v[0];                                        \
+                ob.v[1] = slot_ == 1u ? r0_.x : ob.v[1];                                        \
+                ob.v[2] = slot_ == 2u ? r0_.x : ob.v[2];                                        \
+                ob.v[3] = slot_ == 3u ? r0_.x : ob.v[3];                                        \
+                const bool last_ = A.j + 1u > L || r0_.w == 0u;                                 \
+                uint32_t *cell_ = a.out + (uint64_t)A.job * W + (A.j - slot_);                  \
+                if (slot_ == 3u) *(ListWinRaw *)cell_ = ob;                                     \
+                else if (last_) {                                                               \
+                    cell_[0] = ob.v[0];                                                         \
+                    if (slot_ >= 1u) cell_[1] = ob.v[1];                                        \
+                    if (slot_ >= 2u) cell_[2] = ob.v[2];                                        \
+                }                                                                               \
+            }                                                                                   \
             A.n_in = r0_.y; A.pp = r0_.z; A.d = r0_.w;                                          \
             A.s0 = r1_.x; A.coff = ((uint64_t)r1_.z << 32) | r1_.y; A.wd = r1_.w;               \
             n_steps++;                                                                          \
@@ -145,14 +165,18 @@ walk_lanes_kernel(LanesArgs a) {
         uint32_t wd;                     // hint bucket width of that edge's list
         uint32_t flags;                  // bit 0: active, bit 1: waiting for the float chain
     };
-    constexpr uint32_t F_ACTIVE = 1u, F_WAIT = 2u;
+    constexpr uint32_t F_ACTIVE = 1u, F_WAIT = 2u, F_WAIT2 = 4u;   // waiting for the refinement / for the float chain
     Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
     bool exhausted = false;
     unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0, n_wave = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
+    ListWinRaw ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
+#if PW_LANES_REFINE
+    uint32_t k1 = 0, f1 = 0, shifts = 0;
+#endif
     const uint32_t *const hint = a.hint;
     const uint32_t hs_in = a.hs_in, hs_out = a.hs_out;
 
@@ -191,44 +215,65 @@ walk_lanes_kernel(LanesArgs a) {
 
         // ---- one step for every runnable lane ------------------------------------------------------------------
         // A lane whose step the exact decision cannot settle WAITS (keeps its draw and thresholds) while the other
-        // lanes go on stepping; the float32 chains run once PW_LANES_WAIT lanes wait (or nothing else can run), so
-        // the long, divergent chain code executes with several lanes enabled instead of one or two.
+        // lanes go on stepping.  Waiting lanes are served in two stages, each once enough of them have gathered (or
+        // nothing else can run), so that the long divergent code runs with several lanes enabled:
+        //   1. lane_refine: the chain's drift computed from per-binade class counts (settles ~97 %),
+        //   2. lane_chain : the float32 chain itself, for what the refinement leaves open.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
         if (runnable) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
             r = a.rng[A.soff + (A.j - 1)];
-            LaneStep ls{1.0f, 0u, 0u};
+            LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u};
             choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd);
             n_probes += ls.probes;
-            if (choice == LANE_AMBIGUOUS) { A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax; n_amb++; }
+            if (choice == LANE_AMBIGUOUS) {
+                A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax; n_amb++;
+#if PW_LANES_REFINE
+                k1 = ls.k1; f1 = ls.f; shifts = ls.shifts;
+#endif
+            }
         }
         LPROF_T(1);
-        const uint64_t wait_mask = ballot((A.flags & F_WAIT) != 0);
-        if (wait_mask != 0 && ((uint32_t)__popcll(wait_mask) >= PW_LANES_WAIT || ballot(runnable && choice != LANE_AMBIGUOUS) == 0)) {
-            LPROF_C(9, 1);
-            LPROF_C(10, __popcll(wait_mask));
-            if (A.flags & F_WAIT) {
-                // the float32 chain over the first kmax positions, by this lane alone (seqscan.h: lane_chain)
-                const float x_in = 1.0f / tot;
-                uint32_t reads = 0;
-                const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, a.clist + A.coff, reads,
-                                                hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd, pf, (uint32_t)WAVE);
-                n_probes += reads;
-                choice = res;
-                if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
-                if (res == LANE_TIE) { choice = A.d; n_wave++; }        // tie binade too long for one lane -> redo
-                A.flags = F_ACTIVE;
+        {
+#if PW_LANES_REFINE
+            const uint64_t w1 = ballot((A.flags & F_WAIT) != 0);
+            if (w1 != 0 && ((uint32_t)__popcll(w1) >= PW_LANES_WAIT || ballot(runnable && choice != LANE_AMBIGUOUS) == 0)) {
+                LPROF_C(9, 1);
+                LPROF_C(10, __popcll(w1));
+                if (A.flags & F_WAIT) {
+                    LaneStep ls{tot, kmax, 0u, k1, f1, shifts};
+                    uint32_t reads = 0;
+                    const uint32_t res = lane_refine(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, reads);
+                    n_probes += reads;
+                    if (res != LANE_AMBIGUOUS) { choice = res; A.flags = F_ACTIVE; }
+                    else A.flags = F_ACTIVE | F_WAIT2;
+                }
+                LPROF_T(2);
             }
-#ifdef PW_PROF_LANES
-            {   // pass duration by number of lanes in the pass: buckets 1-2, 3-4, 5-8, 9+ -> [12..15] cycles, [4..7] passes
-                const unsigned long long now_ = __builtin_readcyclecounter();
-                const int nl_ = __popcll(wait_mask);
-                const int bk_ = nl_ <= 2 ? 0 : (nl_ <= 4 ? 1 : (nl_ <= 8 ? 2 : 3));
-                if (lane == 0) { lp[12 + bk_] += now_ - lp_last; lp[4 + bk_] += 1; }
-            }
+#else
+            if (A.flags & F_WAIT) A.flags = F_ACTIVE | F_WAIT2;   // no refinement stage: straight to the chain queue
 #endif
-            LPROF_T(2);
+            const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
+            if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_WAIT2 || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0) &&
+                ballot((A.flags & F_WAIT) != 0) == 0) {
+                LPROF_C(5, 1);
+                LPROF_C(6, __popcll(w2));
+                if (A.flags & F_WAIT2) {
+                    // the float32 chain over the first kmax positions, by this lane alone (seqscan.h: lane_chain)
+                    const float x_in = 1.0f / tot;
+                    uint32_t reads = 0;
+                    const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, a.clist + A.coff, reads,
+                                                    hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd, pf, (uint32_t)WAVE);
+                    n_probes += reads;
+                    choice = res;
+                    if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
+                    if (res == LANE_TIE) choice = A.d;                      // tie binade too long for one lane -> redo
+                    n_wave++;                                               // (steps decided by the float chain)
+                    A.flags = F_ACTIVE;
+                }
+                LPROF_T(4);
+            }
         }
         if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {
             PW_LANE_APPLY();

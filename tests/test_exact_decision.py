@@ -140,11 +140,13 @@ def lane_decide(cls, w_out, w_prev, r, use_hints=False):
     kmax = np.empty(r.size, dtype=np.uint32)
     chain_lane = np.empty(r.size, dtype=np.uint32)
     probes = np.empty(r.size, dtype=np.uint32)
+    refined = np.empty(r.size, dtype=np.uint32)
     _lib.check(lib.pw_selftest_lane_decide(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
                                            r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
                                            lane.ctypes.data_as(C.c_void_p), kmax.ctypes.data_as(C.c_void_p),
                                            chain_lane.ctypes.data_as(C.c_void_p), int(use_hints),
-                                           probes.ctypes.data_as(C.c_void_p)))
+                                           probes.ctypes.data_as(C.c_void_p), refined.ctypes.data_as(C.c_void_p)))
+    lane_decide.refined = refined
     lane_decide.chain_lane = chain_lane
     lane_decide.probes = probes
     return chain, lane, kmax
@@ -217,3 +219,32 @@ def test_lane_decision_row_outside_exact_range_is_redone():
     cls[3] = 2
     _, lane, _ = lane_decide(cls, 2.0 ** -30, 1.0, np.array([0.3]))   # total 39 * 2^-30 + 1 is not a float32
     assert lane[0] == LANE_REDO
+
+
+@pytest.mark.parametrize("w_out,w_prev", BIASES)
+def test_refined_decision_of_ambiguous_steps(w_out, w_prev):
+    """lane_refine computes the drift of the float32 chain from per-binade class counts instead of bounding it: whatever
+    it decides must be the chain's answer -- on uniform targets and on targets placed exactly on / one ulp around
+    every float32 partial sum, where a drift estimate that is off by one ulp flips the answer -- and it must settle
+    most of the steps the a-priori bound leaves open."""
+    rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 99)
+    amb_u = res_u = 0
+    for n in (3, 40, 65, 300, 1500, 6000, 20000):
+        for p_common in (0.0, 0.02, 0.3, 0.9):
+            for with_prev in (False, True):
+                cls = random_row(rng, n, p_common, with_prev)
+                c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
+                cd = c32.astype(np.float64)
+                sub = slice(None, None, max(1, n // 600))
+                targets = [rng.random(1500), cd[sub], np.nextafter(cd[sub], 0.0), np.nextafter(cd[sub], 2.0), exact_cdf[sub],
+                           np.nextafter(exact_cdf[sub], 0.0), np.nextafter(exact_cdf[sub], 2.0)]
+                r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
+                chain, lane, _ = lane_decide(cls, w_out, w_prev, r)
+                ref = lane_decide.refined
+                amb = lane == LANE_AMBIGUOUS
+                assert np.array_equal(ref[~amb], lane[~amb])
+                settled = amb & (ref != LANE_AMBIGUOUS)
+                assert np.array_equal(ref[settled], chain[settled]), (n, p_common, with_prev, w_out, w_prev)
+                amb_u += int(amb[:1500].sum())
+                res_u += int(settled[:1500].sum())
+    assert amb_u == 0 or res_u / amb_u > 0.5
