@@ -26,6 +26,7 @@
 #include "walk_seq.hip.h"
 #include "walk_sparse.hip.h"
 #include "walk_lanes.hip.h"
+#include "walk_bsp.hip.h"
 
 #define PW_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -115,6 +116,10 @@ struct pw_graph {
     DevBuf<uint64_t> stream_off, tile_sums;
     DevBuf<double> rng;
     DevBuf<uint32_t> mt_state, changed, redo;
+    // step-synchronous lane path (walk_bsp.hip.h): walk slots, state, step-major draws / output, queues
+    DevBuf<uint32_t> bsp_job, bsp_ecur, bsp_len, bsp_outT, bsp_chainq;
+    DevBuf<double> bsp_rngT;
+    DevBuf<pw::AmbRec> bsp_amb;
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
     bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
@@ -214,6 +219,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     g->redo.release();
+    g->bsp_job.release(); g->bsp_ecur.release(); g->bsp_len.release(); g->bsp_outT.release(); g->bsp_chainq.release();
+    g->bsp_rngT.release(); g->bsp_amb.release();
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -957,10 +964,83 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     return 0;
 }
 
+// Step-synchronous lane path (walk_bsp.hip.h): whole job arrays of the lane kernel's regime.  counters: [12] walk
+// slots [13] ambiguous queue [14] chain queue; the redo list / count are shared with the lane kernel.
+static int launch_bsp_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
+    const uint64_t n_jobs = wa.n_jobs;
+    const uint32_t L = wa.L;
+    if (g->redo.ensure(n_jobs) || g->bsp_job.ensure(n_jobs) || g->bsp_ecur.ensure(n_jobs) || g->bsp_len.ensure(n_jobs)) return PW_ERR_NOMEM;
+    pw::BspArgs a;
+    memset(&a, 0, sizeof(a));
+    a.erec = g->d_erec;
+    a.clist = g->d_clist;
+    a.vrec = g->d_vrec;
+    a.starts = wa.starts;
+    a.stream_off = wa.stream_off;
+    a.rng = wa.rng;
+    a.rng_base = wa.rng_base;
+    a.out = wa.out;
+    a.n_jobs = n_jobs;
+    a.L = L;
+    a.w_out = wa.w_out;
+    a.w_prev = wa.w_prev;
+    a.act_job = g->bsp_job.p;
+    a.n_act = g->counters.p + 12;
+    a.e_cur = g->bsp_ecur.p;
+    a.len = g->bsp_len.p;
+    a.amb_count = g->counters.p + 13;
+    a.chain_count = g->counters.p + 14;
+    a.redo_list = g->redo.p;
+    a.redo_count = g->counters.p + 6;
+    a.stats = g->counters.p + 1;
+    HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipMemsetAsync(g->counters.p + 12, 0, 3 * sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+    hipLaunchKernelGGL(pw::bsp_compact_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, g->stream, a);
+    HIP_TRY(hipGetLastError());
+    unsigned long long n_act64 = 0;
+    HIP_TRY(hipMemcpyAsync(&n_act64, g->counters.p + 12, sizeof(n_act64), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    const uint32_t n_act = (uint32_t)n_act64;
+    *n_redo = 0;
+    if (n_act) {
+        if (g->bsp_rngT.ensure((size_t)n_act * L) || g->bsp_outT.ensure((size_t)n_act * L) || g->bsp_amb.ensure(n_act) ||
+            g->bsp_chainq.ensure(n_act))
+            return PW_ERR_NOMEM;
+        a.rngT = g->bsp_rngT.p;
+        a.outT = g->bsp_outT.p;
+        a.amb = g->bsp_amb.p;
+        a.chainq = g->bsp_chainq.p;
+        const unsigned gw = (n_act + 255) / 256, gq = (unsigned)(g->n_cu * 8);
+        hipLaunchKernelGGL(pw::bsp_rng_transpose_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act);
+        for (uint32_t j = 1; j <= L; j++) {
+            HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, 2 * sizeof(unsigned long long), g->stream));
+            hipLaunchKernelGGL(pw::bsp_step_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act, j);
+            hipLaunchKernelGGL(pw::bsp_refine_kernel, dim3(gq), dim3(256), 0, g->stream, a);
+            hipLaunchKernelGGL(pw::bsp_chain_kernel, dim3(gq), dim3(256), 0, g->stream, a);
+        }
+        hipLaunchKernelGGL(pw::bsp_final_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act);
+        hipLaunchKernelGGL(pw::bsp_out_transpose_kernel, dim3((n_act + 63) / 64), dim3(256), (size_t)64 * (L + 1) * sizeof(uint32_t),
+                           g->stream, a, n_act);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+    unsigned long long nr = 0;
+    HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float lms = 0;
+    HIP_TRY(hipEventElapsedTime(&lms, g->ev[4], g->ev[5]));
+    g->lane_ms += lms;
+    *n_redo = nr;
+    return 0;
+}
+
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    int rc = launch_lane_walks(g, wa, &n_redo);
+    // whole job arrays go step-synchronously (walk_bsp.hip.h); repair passes over job lists keep the persistent kernel
+    const bool bsp = !wa.job_list && getenv("PECANPY_AMD_BSP") && (uint64_t)wa.L * 64 * sizeof(uint32_t) < 60000;
+    int rc = bsp ? launch_bsp_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
     if (rc || !n_redo) return rc;
     if (redo_total) *redo_total += n_redo;
     pw::WalkArgs wr = wa;
