@@ -136,15 +136,42 @@ def _dump_walks(path, walks):
         out.writelines(" ".join(w) + "\n" for w in walks)
 
 
+def _walk_matrix(g, walks):
+    """ID lists -> uint32[n_walks, L + 2] (the engine's matrix; only needed when gensim is absent)."""
+    index = {name: i for i, name in enumerate(g.nodes)}
+    width = max((len(w) for w in walks), default=1) + 1
+    mat = np.zeros((len(walks), width), dtype=np.uint32)
+    for r, w in enumerate(walks):
+        mat[r, : len(w)] = [index[x] for x in w]
+        mat[r, -1] = len(w)
+    return mat
+
+
 @Timer("train embeddings")
-def learn_embeddings(args, walks):
-    """Skip-gram over the walk corpus (gensim, cli.py:307-325); without gensim the walks are written."""
+def learn_embeddings(args, walks, g=None):
+    """Skip-gram over the walk corpus (cli.py:307-325): gensim when it is installed, else the GPU trainer of this
+    package (``pecanpy_amd.embed``); ``PECANPY_AMD_DUMP_WALKS=1`` writes the walks (one per line) instead."""
+    if os.environ.get("PECANPY_AMD_DUMP_WALKS"):
+        _dump_walks(args.output, walks)
+        return
     try:
         from gensim.models import Word2Vec
     except ImportError:
-        _dump_walks(args.output, walks)
-        warnings.warn(f"gensim is not installed: {len(walks)} walks written to {args.output} instead of "
-                      "embeddings (Word2Vec training is outside this engine)", stacklevel=2)
+        Word2Vec = None
+    if Word2Vec is None:
+        if g is None:
+            _dump_walks(args.output, walks)
+            warnings.warn(f"gensim is not installed and no graph was passed: {len(walks)} walks written to "
+                          f"{args.output} instead of embeddings", stacklevel=2)
+            return
+        from .embed import save_word2vec_format, train_sgns
+
+        vecs = train_sgns(_walk_matrix(g, walks), g.num_nodes, dim=args.dimensions, window=args.window_size,
+                          epochs=args.epochs, seed=args.random_state)
+        if args.output.endswith(".npz"):
+            np.savez(args.output, IDs=g.nodes, data=vecs)
+        else:
+            save_word2vec_format(args.output, g.nodes, vecs)
         return
     w2v = Word2Vec(walks, vector_size=args.dimensions, window=args.window_size, min_count=0, sg=1,
                    workers=args.workers, epochs=args.epochs, seed=args.random_state)
@@ -161,7 +188,7 @@ def main(argv=None):
     args.workers = args.workers or (os.cpu_count() or 1)
     g = read_graph(args)
     preprocess(g)
-    learn_embeddings(args, simulate_walks(args, g))
+    learn_embeddings(args, simulate_walks(args, g), g)
 
 
 if __name__ == "__main__":

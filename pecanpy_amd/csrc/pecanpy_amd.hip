@@ -28,6 +28,7 @@
 #include "walk_sparse.hip.h"
 #include "walk_lanes.hip.h"
 #include "walk_bsp.hip.h"
+#include "sgns.hip.h"
 
 #define PW_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -1411,6 +1412,97 @@ PW_EXPORT int pw_probs(pw_graph *g, int mode, double p, double q, int extend, ui
     int rc = run_probe(g, mode, p, q, extend, cur, has_prev, prev, 0.5, probs, out);
     if (rc) return rc;
     *n = out[2];
+    return PW_OK;
+}
+
+// ---- skip-gram with negative sampling over a walk matrix (sgns.hip.h) -------------------------
+PW_EXPORT int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks, uint32_t walk_length, uint32_t n_nodes,
+                            uint32_t dim, uint32_t window, uint32_t negative, uint32_t epochs, float alpha, float min_alpha,
+                            float sample, uint32_t seed, float *vectors) {
+    if (!walks || !vectors || !n_walks || !n_nodes) return fail(PW_ERR_INVALID, "null pointer / empty corpus");
+    if (dim == 0 || dim > 64 * pw::SGNS_MAX_PER_LANE) return fail(PW_ERR_INVALID, "dim must be in 1..512");
+    if (window == 0 || epochs == 0) return fail(PW_ERR_INVALID, "window and epochs must be positive");
+    int ndev = pw_device_count();
+    if (ndev <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(PW_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t L = walk_length;
+    const size_t wbytes = sizeof(uint32_t) * (size_t)n_walks * ((size_t)L + 2), vbytes = sizeof(float) * (size_t)n_nodes * dim;
+    uint32_t *d_walks = nullptr, *d_table = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    float *d_syn0 = nullptr, *d_syn1 = nullptr, *d_keep = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_walks, (void *)d_table, (void *)d_cnt, (void *)d_syn0, (void *)d_syn1, (void *)d_keep})
+            if (q) (void)hipFree(q);
+    };
+    hipError_t e = hipMalloc((void **)&d_walks, wbytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof(unsigned long long) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_syn0, vbytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_syn1, vbytes);
+    if (e == hipSuccess) e = hipMemcpy(d_walks, walks, wbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMemset(d_syn1, 0, vbytes);
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
+    // vocabulary statistics
+    const uint64_t n_items = n_walks * (uint64_t)(L + 1);
+    hipLaunchKernelGGL(pw::sgns_count_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, 0, d_walks, n_walks, L, d_cnt);
+    std::vector<unsigned long long> cnt(n_nodes);
+    e = hipMemcpy(cnt.data(), d_cnt, sizeof(unsigned long long) * (size_t)n_nodes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
+    double total = 0, pow_total = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) { total += (double)cnt[i]; pow_total += std::pow((double)cnt[i], 0.75); }
+    if (!(total > 0)) { cleanup(); return fail(PW_ERR_INVALID, "the walk matrix holds no nodes"); }
+    // word2vec's unigram^0.75 table and subsampling probabilities
+    const uint32_t table_size = (uint32_t)std::min<uint64_t>(1ull << 26, std::max<uint64_t>(1ull << 16, 16ull * n_nodes));
+    std::vector<uint32_t> table(table_size);
+    {
+        uint32_t w = 0;
+        double cum = std::pow((double)cnt[0], 0.75) / pow_total;
+        for (uint32_t t = 0; t < table_size; t++) {
+            table[t] = w;
+            if ((double)(t + 1) / table_size > cum && w + 1 < n_nodes) { w++; cum += std::pow((double)cnt[w], 0.75) / pow_total; }
+            while ((double)(t + 1) / table_size > cum && w + 1 < n_nodes) { w++; cum += std::pow((double)cnt[w], 0.75) / pow_total; }
+        }
+    }
+    std::vector<float> keep;
+    if (sample > 0) {
+        keep.resize(n_nodes);
+        const double thr = (double)sample * total;
+        for (uint32_t i = 0; i < n_nodes; i++)
+            keep[i] = cnt[i] ? (float)std::min(1.0, (std::sqrt((double)cnt[i] / thr) + 1.0) * thr / (double)cnt[i]) : 1.0f;
+    }
+    // syn0 ~ U(-0.5, 0.5) / dim (word2vec.c), seeded
+    std::vector<float> init((size_t)n_nodes * dim);
+    {
+        uint64_t x = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 17);
+        for (auto &f : init) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            f = (((float)((x >> 40) & 0xffffff) / 16777216.0f) - 0.5f) / (float)dim;
+        }
+    }
+    e = hipMalloc((void **)&d_table, sizeof(uint32_t) * (size_t)table_size);
+    if (e == hipSuccess) e = hipMemcpy(d_table, table.data(), sizeof(uint32_t) * (size_t)table_size, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_syn0, init.data(), vbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && sample > 0) {
+        e = hipMalloc((void **)&d_keep, sizeof(float) * (size_t)n_nodes);
+        if (e == hipSuccess) e = hipMemcpy(d_keep, keep.data(), sizeof(float) * (size_t)n_nodes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    pw::SgnsArgs a;
+    a.walks = d_walks; a.n_walks = n_walks; a.L = L; a.dim = dim; a.window = window; a.negative = negative;
+    a.syn0 = d_syn0; a.syn1 = d_syn1; a.table = d_table; a.table_size = table_size; a.keep = d_keep;
+    a.alpha = alpha; a.min_alpha = min_alpha; a.item_total = n_items * epochs; a.seed = seed;
+    for (uint32_t ep = 0; ep < epochs; ep++) {
+        a.item_base = n_items * ep;
+        hipLaunchKernelGGL(pw::sgns_kernel, dim3((unsigned)(prop.multiProcessorCount * 8)), dim3(256), 0, 0, a);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(vectors, d_syn0, vbytes, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e));
     return PW_OK;
 }
 

@@ -256,13 +256,22 @@ class Base(BaseGraph):
             self._preprocessed = True
 
     def embed(self, dim=128, num_walks=10, walk_length=80, window_size=10, epochs=1, verbose=False):
-        """``simulate_walks`` + gensim skip-gram (pecanpy.py:240-290).  Embedding training is out
-        of scope for the GPU engine; gensim is used when installed."""
+        """``simulate_walks`` + skip-gram (pecanpy.py:240-290): returns ``float32[num_nodes, dim]`` in node order.
+
+        With gensim installed the reference's call is made (``Word2Vec(walks, sg=1, min_count=0, ...)``); without
+        it the GPU trainer of this package runs on the walk matrix directly (``pecanpy_amd.embed.train_sgns``: same
+        model and defaults, no string corpus)."""
         try:
             from gensim.models import Word2Vec
-        except ImportError as exc:  # pragma: no cover
-            raise ImportError("embed() needs gensim for the Word2Vec step; walk generation "
-                              "(simulate_walks) does not") from exc
+        except ImportError:
+            Word2Vec = None
+        if Word2Vec is None:
+            from .embed import train_sgns
+
+            mat = Timer("generate walks", verbose)(self.simulate_walks_array)(num_walks, walk_length)
+            return Timer("train embeddings", verbose)(train_sgns)(
+                mat, self.num_nodes, dim=dim, window=window_size, epochs=epochs, seed=self.random_state,
+                device=self._device_index())
         walks = Timer("generate walks", verbose)(self.simulate_walks)(num_walks, walk_length)
         w2v = Timer("train embeddings", verbose)(Word2Vec)(
             walks, vector_size=dim, window=window_size, sg=1, min_count=0, workers=self.workers,

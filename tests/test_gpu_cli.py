@@ -47,13 +47,8 @@ def _write_edg(path):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_cli_main_reproduces_the_reference_walks(mode, tmp_path):
-    pytest.importorskip("pecanpy_amd")
-    try:
-        import gensim  # noqa: F401
-        pytest.skip("gensim present: the CLI trains embeddings instead of writing the walks")
-    except ImportError:
-        pass
+def test_cli_main_reproduces_the_reference_walks(mode, tmp_path, monkeypatch):
+    monkeypatch.setenv("PECANPY_AMD_DUMP_WALKS", "1")      # last stage: write the walks instead of training
     edg, out = tmp_path / "karate.edg", tmp_path / "karate.walks"
     ids = _write_edg(edg)
     with warnings.catch_warnings():
@@ -75,8 +70,9 @@ def test_cli_first_order_modes_reject_second_order_parameters(mode, p, q, tmp_pa
         cli.main(["--input", str(edg), "--output", os.devnull, "--mode", mode, "--p", str(p), "--q", str(q)])
 
 
-def test_cli_from_npz(tmp_path):
+def test_cli_from_npz(tmp_path, monkeypatch):
     """--input *.npz (CSR with IDs, graph.py:447-486) through SparseOTF with p = 0.5, q = 2."""
+    monkeypatch.setenv("PECANPY_AMD_DUMP_WALKS", "1")
     out, npz = tmp_path / "w.txt", tmp_path / "karate.csr.npz"
     k = np.load(os.path.join(GOLDEN, "karate_csr.npz"))
     np.savez(npz, IDs=k["ids"], data=k["data"], indptr=k["indptr"], indices=k["indices"])
@@ -87,3 +83,48 @@ def test_cli_from_npz(tmp_path):
     gold = np.load(os.path.join(GOLDEN, "karate_SparseOTF_p0.5_q2.npz"))
     want = [" ".join(k["ids"][row[: row[-1]]].tolist()) for row in gold["walks"]]
     assert out.read_text().splitlines() == want
+
+
+# Zachary's factions (Mr. Hi's group, 1-based IDs as in demo/karate.edg)
+MR_HI = {"1", "2", "3", "4", "5", "6", "7", "8", "11", "12", "13", "14", "17", "18", "20", "22"}
+
+
+def test_cli_end_to_end_embeddings_on_the_gpu(tmp_path):
+    """The whole pipeline without gensim: edge list -> walks (GPU) -> skip-gram (GPU) -> word2vec text file; the
+    embedding must carry the graph's structure: members of the same faction are closer than members of different ones."""
+    try:
+        import gensim  # noqa: F401
+        pytest.skip("gensim present: the reference's trainer is used")
+    except ImportError:
+        pass
+    edg, out = tmp_path / "karate.edg", tmp_path / "karate.emb"
+    _write_edg(edg)
+    cli.main(["--input", str(edg), "--output", str(out), "--mode", "SparseOTF", "--p", "1", "--q", "0.5", "--random_state", "1",
+              "--num-walks", "20", "--walk-length", "40", "--dimensions", "16", "--epochs", "5", "--window-size", "5"])
+    lines = out.read_text().splitlines()
+    n, dim = (int(x) for x in lines[0].split())
+    assert (n, dim) == (34, 16) and len(lines) == 35
+    names = [ln.split()[0] for ln in lines[1:]]
+    vec = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[1:]])
+    assert np.isfinite(vec).all() and np.abs(vec).max() > 0.05            # trained, not the initial noise
+    unit = vec / np.linalg.norm(vec, axis=1, keepdims=True)
+    sim = unit @ unit.T
+    same = np.array([[(a in MR_HI) == (b in MR_HI) for b in names] for a in names])
+    off = ~np.eye(34, dtype=bool)
+    assert sim[same & off].mean() > sim[~same].mean() + 0.15
+
+
+def test_embed_method_returns_node_ordered_vectors():
+    from pecanpy_amd import pecanpy as node2vec
+
+    k = np.load(os.path.join(GOLDEN, "karate_csr.npz"))
+    g = node2vec.SparseOTF.from_csr(k["indptr"], k["indices"], k["data"], node_ids=list(k["ids"]), p=1, q=1, random_state=2)
+    try:
+        import gensim  # noqa: F401
+        pytest.skip("gensim present")
+    except ImportError:
+        pass
+    emb = g.embed(dim=8, num_walks=10, walk_length=20, window_size=4, epochs=3)
+    assert emb.shape == (34, 8) and emb.dtype == np.float32 and np.isfinite(emb).all()
+    again = g.embed(dim=8, num_walks=10, walk_length=20, window_size=4, epochs=3)
+    assert again.shape == emb.shape          # (hogwild updates: repeatable in distribution, not bit for bit)
