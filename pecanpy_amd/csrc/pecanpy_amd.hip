@@ -1494,9 +1494,13 @@ PW_EXPORT int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks,
     a.walks = d_walks; a.n_walks = n_walks; a.L = L; a.dim = dim; a.window = window; a.negative = negative;
     a.syn0 = d_syn0; a.syn1 = d_syn1; a.table = d_table; a.table_size = table_size; a.keep = d_keep;
     a.alpha = alpha; a.min_alpha = min_alpha; a.item_total = n_items * epochs; a.seed = seed;
+    // concurrency: hogwild updates collide when far more wavefronts than vocabulary rows are in flight (a small graph
+    // would see most of its updates overwritten): at least ~256 items per wavefront
+    const uint64_t want_blocks = (n_items + 1023) / 1024;
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want_blocks, (uint64_t)prop.multiProcessorCount * 8));
     for (uint32_t ep = 0; ep < epochs; ep++) {
         a.item_base = n_items * ep;
-        hipLaunchKernelGGL(pw::sgns_kernel, dim3((unsigned)(prop.multiProcessorCount * 8)), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(pw::sgns_kernel, dim3(blocks), dim3(256), 0, 0, a);
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();

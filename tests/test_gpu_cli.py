@@ -100,13 +100,13 @@ def test_cli_end_to_end_embeddings_on_the_gpu(tmp_path):
     edg, out = tmp_path / "karate.edg", tmp_path / "karate.emb"
     _write_edg(edg)
     cli.main(["--input", str(edg), "--output", str(out), "--mode", "SparseOTF", "--p", "1", "--q", "0.5", "--random_state", "1",
-              "--num-walks", "20", "--walk-length", "40", "--dimensions", "16", "--epochs", "5", "--window-size", "5"])
+              "--num-walks", "20", "--walk-length", "40", "--dimensions", "16", "--epochs", "40", "--window-size", "5"])
     lines = out.read_text().splitlines()
     n, dim = (int(x) for x in lines[0].split())
     assert (n, dim) == (34, 16) and len(lines) == 35
     names = [ln.split()[0] for ln in lines[1:]]
     vec = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[1:]])
-    assert np.isfinite(vec).all() and np.abs(vec).max() > 0.05            # trained, not the initial noise
+    assert np.isfinite(vec).all() and np.abs(vec).max() > 0.1             # trained, not the initial noise (|x| < 0.032)
     unit = vec / np.linalg.norm(vec, axis=1, keepdims=True)
     sim = unit @ unit.T
     same = np.array([[(a in MR_HI) == (b in MR_HI) for b in names] for a in names])
