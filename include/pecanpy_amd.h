@@ -191,6 +191,11 @@ int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out)
  * The result is what pw_graph_set_thresholds() expects. */
 int pw_noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr);
 int pw_noise_thresholds_dense(const double *data, uint32_t n_nodes, double gamma, float *thr);
+/* pw_noise_thresholds_csr evaluates mean + gamma * std as NumPy >= 2 does (float32 throughout); this variant as NumPy
+ * 1.x does (the reference pins numpy==1.23.2: float32 scalar * Python float -> float64, one rounding on store).  They
+ * differ by an ulp when gamma * std is not exact in float32 (gamma = 0.1, ...); the Python layer picks the one that
+ * matches the installed NumPy, i.e. what the reference's expression would give in the same environment. */
+int pw_noise_thresholds_csr_numpy1(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr);
 
 /* ---- edge-list ingestion (host side; usable without a GPU) -------------------------------- */
 /* Fast path of AdjlstGraph.read + to_csr (reference src/pecanpy/graph.py:270-341): parses a 2- or

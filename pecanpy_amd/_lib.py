@@ -76,6 +76,7 @@ SYMBOLS = {
                                 C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "pw_mt_random_sample": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pw_noise_thresholds_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
+    "pw_noise_thresholds_csr_numpy1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
     "pw_noise_thresholds_dense": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
     "pw_edgelist_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "pw_edgelist_shape": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),

@@ -671,6 +671,8 @@ PW_EXPORT int pw_precomp_build(pw_graph *g, double p, double q, int extend, int 
                            g->alias_s.p, g->alias_l.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g->stream));
+    g->alias_s.release();   // scratch of the build only (2 x sum(deg^2) words)
+    g->alias_l.release();
     g->n_alias = n_alias;
     g->alias_kind = first_order;
     g->alias_p = p;
@@ -1661,6 +1663,12 @@ PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_ou
 PW_EXPORT int pw_noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr) {
     if (!indptr || !thr || (!data && indptr[n_nodes] != 0)) return fail(PW_ERR_INVALID, "null pointer");
     pw::noise_thresholds_csr(indptr, data, n_nodes, gamma, thr);
+    return PW_OK;
+}
+
+PW_EXPORT int pw_noise_thresholds_csr_numpy1(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr) {
+    if (!indptr || !thr || (!data && indptr[n_nodes] != 0)) return fail(PW_ERR_INVALID, "null pointer");
+    pw::noise_thresholds_csr(indptr, data, n_nodes, gamma, thr, true);
     return PW_OK;
 }
 

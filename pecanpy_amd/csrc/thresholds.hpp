@@ -58,14 +58,20 @@ template <typename T> inline void numpy_mean_std(const T *a, uint64_t n, std::ve
     stdev = (T)sqrt((double)var);   // correctly rounded sqrt of a T value, rounded to T: same as sqrtf / sqrt
 }
 
-// CSR rows of float32 weights; gamma is applied in float32 (NumPy 2 scalar promotion: python float is "weak")
-inline void noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr) {
+// CSR rows of float32 weights.  How `row.mean() + gamma * row.std()` (two float32 scalars and a Python float) is
+// evaluated depends on the NumPy the reference runs under:
+//   numpy1 = false: NumPy >= 2 (NEP 50): the Python float is "weak", everything stays float32 (two roundings);
+//   numpy1 = true : NumPy 1.x (the reference pins 1.23.2): float32 scalar * Python float -> float64, the sum is
+//                   float64 and is rounded once when stored into the float32 threshold array.
+// Both agree whenever gamma * std is exact in float32 (gamma = 0, 0.5, ... as in the fixtures).
+inline void noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr,
+                                 bool numpy1 = false) {
     std::vector<float> scratch;
     const float g = (float)gamma;
     for (uint32_t i = 0; i < n_nodes; i++) {
         float m, s;
         numpy_mean_std<float>(data + indptr[i], (uint64_t)indptr[i + 1] - indptr[i], scratch, m, s);
-        const float t = m + g * s;
+        const float t = numpy1 ? (float)((double)m + gamma * (double)s) : m + g * s;
         thr[i] = (t != t) ? t : (t > 0.0f ? t : 0.0f);   // np.maximum(t, 0): NaN propagates
     }
 }

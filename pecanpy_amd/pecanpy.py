@@ -315,8 +315,10 @@ class _SparseBase(Base, SparseGraph):
         except Exception:  # library not built
             lib = None
         if lib is not None:
-            _lib.check(lib.pw_noise_thresholds_csr(indptr.ctypes.data, data.ctypes.data, n, float(self.gamma),
-                                                   thr.ctypes.data))
+            # the promotion rule of the installed NumPy (NEP 50 from 2.0 on), so that the native path equals the
+            # row-by-row NumPy expression below in the same environment
+            fn = lib.pw_noise_thresholds_csr if int(np.__version__.split(".")[0]) >= 2 else lib.pw_noise_thresholds_csr_numpy1
+            _lib.check(fn(indptr.ctypes.data, data.ctypes.data, n, float(self.gamma), thr.ctypes.data))
             return thr
         for i in range(n):
             row = data[indptr[i]:indptr[i + 1]]

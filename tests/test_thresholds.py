@@ -69,3 +69,31 @@ def test_native_thresholds_equal_numpy_row_by_row(gamma):
         data = data.astype(np.float32)
         g = sparse_graph(indptr, np.zeros(indptr[-1], dtype=np.uint32), data, gamma)
         assert same_bits(g.get_noise_thresholds(), numpy_rowwise(indptr, data, gamma))
+
+
+def test_numpy1_promotion_variant():
+    """gamma = 0.1 is not a float32: NumPy 1.x (pinned by the reference) evaluates mean + gamma * std in float64 and rounds
+    once, NumPy >= 2 stays in float32.  Each native variant equals its rule evaluated with explicit dtypes."""
+    import ctypes as C
+
+    from pecanpy_amd import _lib
+    from pecanpy_amd.synth import rmat_csr
+
+    lib = _lib.load()
+    indptr, _, data = rmat_csr(9, seed=4, weighted=True)
+    n = indptr.size - 1
+    a = np.zeros(n, dtype=np.float32)
+    b = np.zeros(n, dtype=np.float32)
+    _lib.check(lib.pw_noise_thresholds_csr(indptr.ctypes.data, data.ctypes.data, n, 0.1, a.ctypes.data))
+    _lib.check(lib.pw_noise_thresholds_csr_numpy1(indptr.ctypes.data, data.ctypes.data, n, 0.1, b.ctypes.data))
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            row = data[indptr[i]:indptr[i + 1]]
+            if row.size == 0:
+                assert np.isnan(a[i]) and np.isnan(b[i])
+                continue
+            m, s = row.mean(), row.std()                                   # float32 scalars
+            want2 = np.float32(m + np.float32(0.1) * s)
+            want1 = np.float32(np.float64(m) + 0.1 * np.float64(s))
+            assert a[i] == max(want2, np.float32(0)) and b[i] == max(want1, np.float32(0)), i
+    assert (a != b).any()                                                  # the two rules really differ somewhere
