@@ -233,7 +233,7 @@ def main():
             parts.append([torch.empty_like(pad) for _ in range(world)] if rank == 0 else None)
 
     acc = {k: [] for k in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "total_steps", "list_entries_read",
-                           "ambiguous_steps", "redo_walks", "overflow_reads")}
+                           "ambiguous_steps", "wave_chain_steps", "redo_walks", "overflow_reads")}
     param_index_ms = [0.0]   # (p, q)-dependent index built by the first call (normaliser table of weighted graphs)
 
     def one_pass():
@@ -354,6 +354,7 @@ def main():
         roofline["issue_bound"] = pmc["issue"]
     if lane:
         roofline["ambiguous_step_frac"] = round(acc["ambiguous_steps"][-1] / max(steps0, 1), 5)
+        roofline["float_chain_step_frac"] = round(acc["wave_chain_steps"][-1] / max(steps0, 1), 5)
         roofline["list_entries_per_step"] = round(acc["list_entries_read"][-1] / max(steps0, 1), 2)
         roofline["redo_walks"] = int(acc["redo_walks"][-1])
 

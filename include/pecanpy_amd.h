@@ -248,6 +248,11 @@ int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, floa
 int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                             uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
                             int use_hints, uint32_t *probes, uint32_t *refined);
+/* The list-free interval decision of ambiguous targets (csrc/seqscan.h: lane_tight -- the chain's systematic drift
+ * bounded from the class counts lane_decide already knows): chain / lane as above, tight[i] = lane[i] when that is
+ * decided, else lane_tight's answer (an index, or still 0xfffffffd). */
+int pw_selftest_lane_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                           uint32_t *chain, uint32_t *lane, uint32_t *tight);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

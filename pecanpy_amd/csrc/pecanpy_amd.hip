@@ -39,7 +39,7 @@ thread_local std::string g_err;
 // pw_graph::counters layout: [0] job counter [1..4] stats [5] changed count [6] redo count [7] list entries read
 // by the lane kernel [8] ambiguous steps (float chain) of the lane kernel [9] first bad start [10] ambiguous steps the
 // per-lane chain left to the wave-cooperative chain (rounding ties)
-constexpr int N_COUNTERS = 16;
+constexpr int N_COUNTERS = 48;   // ... [32] parked walks (lane kernel's chain queue; a cache line of its own)
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -119,6 +119,8 @@ struct pw_graph {
     DevBuf<uint64_t> stream_off, tile_sums;
     DevBuf<double> rng;
     DevBuf<uint32_t> mt_state, changed, redo;
+    DevBuf<pw::SuspRec> susp[2];      // lane kernel: walks parked for the float chain (two queues, swapped per round)
+    uint32_t lane_rounds = 0;         // lane kernel launches of the last call
     // generator states of recent calls, keyed by (seed, first block, blocks per generator, generators): a repeated
     // call (every pass of a benchmark, every chunk of a sharded run) skips the ~20 sequential jump-ahead launches
     struct MtCache { bool valid = false; uint32_t seed = 0, n_gen = 0; uint64_t first_block = 0; int per_gen_log = 0; uint64_t stamp = 0;
@@ -940,19 +942,64 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     la.w_out = wa.w_out;
     la.w_prev = wa.w_prev;
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
-    uint64_t want = (n_work + pw::WAVES_PER_BLOCK * pw::WAVE - 1) / (pw::WAVES_PER_BLOCK * pw::WAVE);
-    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
-    if (grid > want) grid = want;
-    if (grid < 1) grid = 1;
-    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    int occ_in = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ_in < 1) occ_in = 1;
+    const uint64_t lanes_resident = (uint64_t)g->n_cu * (uint64_t)occ * pw::WAVES_PER_BLOCK * pw::WAVE;
+    // Steps that need the float32 chain (~1 % on RMAT-22 after lane_tight) are not run in place -- a chain with a few
+    // of the wavefront's 64 lanes enabled costs the other lanes ~300 us -- their walks are PARKED in a queue, a
+    // separate launch runs all queued chains at full width, and the next round of the lane kernel resumes the walks.
+    // Rounds go on while a queue is worth a launch; the last one runs its chains in place.
+    const char *tail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
+    uint64_t tail = tail_env ? (uint64_t)strtoull(tail_env, nullptr, 10) : lanes_resident / 2;
+    bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
+    const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;   // + the void slots of every wavefront's last reservation
+    if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
+        (void)hipGetLastError();
+        use_queue = false;              // no room for the queues: chains run in place
+    }
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
-    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-    hipLaunchKernelGGL(pw::walk_lanes_kernel, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
-    unsigned long long nr = 0;
+    unsigned long long nr = 0, parked = 0;
+    uint64_t todo = n_work;
+    g->lane_rounds = 0;
+    for (int round = 0;; round++) {
+        const bool queue_out = use_queue && todo > tail && round < 64;
+        la.susp = queue_out ? g->susp[round & 1].p : nullptr;
+        la.susp_count = g->counters.p + 32;
+        la.susp_chunk = todo > 32 * lanes_resident ? 128u : 1u;   // (void slots: < 128 per wavefront)
+        la.resume = round ? g->susp[(round - 1) & 1].p : nullptr;
+        la.n_resume = round ? todo : 0;
+        uint64_t want = (todo + pw::WAVES_PER_BLOCK * pw::WAVE - 1) / (pw::WAVES_PER_BLOCK * pw::WAVE);
+        uint64_t grid = (uint64_t)g->n_cu * (uint64_t)(queue_out ? occ : occ_in);
+        if (grid > want) grid = want;
+        if (grid < 1) grid = 1;
+        HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+        HIP_TRY(hipMemsetAsync(g->counters.p + 32, 0, sizeof(unsigned long long), g->stream));
+        HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+        if (queue_out)
+            hipLaunchKernelGGL(pw::walk_lanes_kernel<false>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+        else
+            hipLaunchKernelGGL(pw::walk_lanes_kernel<true>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (parked) {   // settle the queue just filled
+            hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
+                               g->susp[round & 1].p, (uint64_t)parked, g->d_clist, wa.w_prev, g->counters.p + 1);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        float rms = 0;
+        HIP_TRY(hipEventElapsedTime(&rms, g->ev[4], g->ev[5]));
+        g->lane_ms += rms;
+        g->lane_rounds++;
+        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[lanes] round %d: %llu walks, %llu parked, %.2f ms\n", round, (unsigned long long)todo, parked, rms);
+        if (!parked) break;
+        todo = parked;
+    }
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
 #ifdef PW_PROF_LANES
@@ -970,9 +1017,6 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
                 hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[5] ? (double)hp[4] / (double)hp[5] : 0.0);
     }
 #endif
-    float lms = 0;
-    HIP_TRY(hipEventElapsedTime(&lms, g->ev[4], g->ev[5]));
-    g->lane_ms += lms;
     *n_redo = nr;
     return 0;
 }
@@ -1041,9 +1085,6 @@ static int launch_bsp_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     unsigned long long nr = 0;
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    float lms = 0;
-    HIP_TRY(hipEventElapsedTime(&lms, g->ev[4], g->ev[5]));
-    g->lane_ms += lms;
     *n_redo = nr;
     return 0;
 }
@@ -1675,6 +1716,50 @@ PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_ou
 #endif
         }
     }
+    return PW_OK;
+}
+
+// Host run of lane_decide + lane_tight (the list-free interval decision) beside the sequential float32 chain.
+PW_EXPORT int pw_selftest_lane_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                                     uint32_t *chain, uint32_t *lane, uint32_t *tight) {
+    if (!cls || !r || !chain || !lane || !tight || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
+    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    std::vector<uint32_t> cl;
+    uint32_t pp = 0xffffffffu, cnt[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < n; k++) {
+        if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
+        cnt[cls[k]]++;
+        if (cls[k] == 1) cl.push_back(k);
+        if (cls[k] == 2) pp = k;
+    }
+    if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
+    const float tot = (float)((double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev);
+    const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
+    const uint32_t n_cl = (uint32_t)cl.size();
+    cl.resize((size_t)n_cl + 4, 0xffffffffu);
+    // the chain once: prefix sums, then one binary search per draw (the sums are non-decreasing)
+    std::vector<float> c(n);
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < n; k++) {
+        acc = acc + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
+        c[k] = acc;
+    }
+    for (uint32_t i = 0; i < n_r; i++) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+        chain[i] = lo;
+        pw::LaneStep ls{0.0f, 0u, 0u, 0u, 0u, 0u, 0u};
+        lane[i] = pw::lane_decide(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls);
+        tight[i] = lane[i] == pw::LANE_AMBIGUOUS ? pw::lane_tight(n, pp, r[i], w_out, w_prev, ls) : lane[i];
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (getenv("PW_TIGHT_STATS")) {
+        fprintf(stderr, "tight bail reasons:");
+        for (int k = 1; k < 24; k++) if (pw::g_tight_reason[k]) fprintf(stderr, " [%d]=%llu", k, (unsigned long long)pw::g_tight_reason[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return PW_OK;
 }
 

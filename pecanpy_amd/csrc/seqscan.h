@@ -23,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define PW_HD __host__ __device__ __forceinline__
+#define PW_HD_CALL __host__ __device__ __attribute__((noinline))   // a real call: own register allocation
 #else
 #define PW_HD inline
+#define PW_HD_CALL inline
 #endif
 
 namespace pw {
@@ -415,6 +417,7 @@ struct LaneStep {
     uint32_t k1;      // ambiguous steps: every position below k1 is known to stay below r
     uint32_t f;       // ... number of common neighbours before k1
     uint32_t shifts;  // ... sh_in | sh_out << 8 | sh_prev << 16 (weights in units of the smallest)
+    uint32_t p_next;  // ... position of the first common neighbour at or after k1 (0xffffffff: none)
 };
 
 struct MassEval {   // E(P_i) in units of the smallest weight
@@ -472,6 +475,7 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     ls.k1 = k1;
     ls.f = f_below;
     ls.shifts = sh_in | (sh_out << 8) | (sh_prev << 16);
+    ls.p_next = p_f;
     return LANE_AMBIGUOUS;
 }
 
@@ -913,4 +917,223 @@ PW_HD uint32_t lane_refine(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     return answer;
 }
 
+// ---- interval decision of an ambiguous step: the chain's drift bounded WITHOUT touching the list -------------------
+// Same facts as lane_refine -- inside binade e an addition of class c errs by the constant delta_{e,c} -- but the
+// per-binade class counts are not looked up: they are eliminated.  The non-crossing additions inside binade e obey
+//      a_e X_in + o_e X_out + p_e X_pv = W_e        (X = x + delta: the quantised increments; W_e = span of the sum)
+// so their drift is   D_e = (delta_out / X_out) W_e  +  a_e g_e  +  p_e h_e,   g_e = delta_in - delta_out X_in / X_out,
+// h_e likewise for prev.  W_e is known to within two elements (a full binade spans 2^e; the top one ends at c_k0,
+// known to the a-priori bound), sum a_e <= i1 = common neighbours before k1, p_e <= 1: the drift lies in
+//      [ sum_e min D_e(W) + i1 min(0, g_e) + min(0, h_e) - eps,  sum_e max D_e(W) + i1 max(0, g_e) + max(0, h_e) + eps ],
+// eps = crossing additions (one per binade, <= ulp_top in total) + additions below the LANE_TB evaluated binades
+// (count * ulp / 2) + float64 evaluation.  On RMAT graphs the walks' ambiguous steps sit on hub rows whose common
+// neighbours are a percent of the prefix (i1 ~ k1 / 100), so the interval is a small fraction of one increment and
+// ~9 in 10 ambiguous steps are settled here, by arithmetic alone; the continuation from k1 only needs the next common
+// neighbour's position (ls.p_next, known from lane_decide's search).  Anything doubtful returns LANE_AMBIGUOUS.
+#ifndef PW_LANE_TB
+#define PW_LANE_TB 6   // evaluated binades (4: +25 % float chains, 6: -4 %; each costs ~100 instructions per ambiguous step)
+#endif
+constexpr int LANE_TB = PW_LANE_TB;
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+static thread_local uint64_t g_tight_reason[24] = {0};
+#define TIGHT_BAIL(i) do { g_tight_reason[i]++; return LANE_AMBIGUOUS; } while (0)
+#else
+#define TIGHT_BAIL(i) return LANE_AMBIGUOUS
+#endif
+// increments of adding x inside binade eb (sum even / odd, as Binade::quantize) and the error of a0 in ulps of that
+// binade, d0 = a0 - x / ulp (exact: the discarded bits of the significand; a1's error is d0 + (a1 - a0))
+struct QuantErr {
+    uint32_t a0, a1;
+    float d0;
+};
+PW_HD QuantErr quant_err(float x, int eb) {
+    using B = Binade<float>;
+    const uint32_t M = B::sig_of(x);
+    const int s = eb - B::eb_of(x);
+    QuantErr q;
+    q.a0 = q.a1 = 0;
+    q.d0 = 0.0f;
+    if (M == 0) return q;
+    if (s <= 0) { q.a0 = q.a1 = B::SAT; return q; }
+    if (s > B::MANT + 2) { q.d0 = -ldexpf((float)M, -s); return q; }
+    const uint32_t fl = M >> s, rem = M & ((1u << s) - 1u), half = 1u << (s - 1);
+    if (rem > half) q.a0 = q.a1 = fl + 1u;
+    else if (rem < half) q.a0 = q.a1 = fl;
+    else { const uint32_t odd = fl & 1u; q.a0 = fl + odd; q.a1 = fl + (odd ^ 1u); }
+    q.d0 = (float)(int)(q.a0 - fl) - ldexpf((float)rem, -s);
+    return q;
+}
+
+PW_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);   // 1 ulp; every use below carries a 2^-20 relative allowance
+#else
+    return 1.0f / x;
+#endif
+}
+
+// Arithmetic: everything is kept in ULPS OF THE TOP BINADE as float32 (errors of binade e_t - j scale by 2^-j), the
+// exact mass value v0 = E0 * x_unit as a 48-bit integer product split into its integer significand V and a fraction;
+// float32 roundings of the interval's terms are covered by a 2^-20 relative allowance on their magnitudes.
+PW_HD uint32_t lane_tight(uint32_t d, uint32_t pp, double r, float w_out, float w_prev, const LaneStep &ls) {
+    using B = Binade<float>;
+    const uint32_t sh_in = ls.shifts & 0xffu, sh_out = (ls.shifts >> 8) & 0xffu, sh_prev = (ls.shifts >> 16) & 0xffu;
+    const uint32_t k1 = ls.k1, i1 = ls.f, kend = ls.kmax, p_f = ls.p_next;
+    if (k1 == 0 || k1 >= kend) TIGHT_BAIL(1);
+    const bool has_pv = pp != 0xffffffffu;
+    const float x_in = 1.0f / ls.tot, x_out = x_in * w_out, x_pv = x_in * w_prev;
+    const float x_u = ldexpf(x_in, -(int)sh_in);            // float value of one unit of mass (exact)
+    const uint32_t pv0 = (has_pv && pp < k1) ? 1u : 0u;
+    const uint32_t o0 = k1 - i1 - pv0;
+    if (o0 == 0) TIGHT_BAIL(2);                             // (the elimination runs over the "out" class)
+    const uint64_t E0 = ((uint64_t)o0 << sh_out) + ((uint64_t)i1 << sh_in) + ((uint64_t)pv0 << sh_prev);
+    if (E0 >> 25) TIGHT_BAIL(3);                            // (lane_decide's range: at most 2^24 units)
+    // v0 = E0 * x_u = P * 2^(e_u - 150), P = E0 * M_u < 2^49: binade e_t = e_u + sh, integer significand V = P >> sh
+    const uint64_t P = E0 * (uint64_t)B::sig_of(x_u);
+    if (P < (1ull << 24)) TIGHT_BAIL(3);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int top = 63 - __clzll((long long)P);
+#else
+    const int top = 63 - __builtin_clzll(P);
+#endif
+    const int sh = top - 23;                                // >= 1
+    const int e_t = B::eb_of(x_u) + sh;                     // binade (biased float32 exponent) of the exact mass value
+    if (e_t < 2 || e_t > 126) TIGHT_BAIL(3);
+    const uint32_t V = (uint32_t)(P >> sh);                 // in [2^23, 2^24)
+    const float fr = ldexpf((float)(uint32_t)(P & ((1ull << sh) - 1ull)), -sh);   // v0 / ulp_t = V + fr, fr in [0, 1)
+    const float voff = (float)(V - (1u << 23));             // offset of v0 inside its binade, whole ulps (exact)
+    const float upu = ldexpf((float)B::sig_of(x_u), -sh);   // ulps (top binade) per unit of mass
+    uint32_t sh_max = sh_in > sh_out ? sh_in : sh_out;
+    if (sh_prev > sh_max) sh_max = sh_prev;
+    // a-priori: |c_k0 - v0| <= Z (drift_bound_f32, evaluated in float32 and inflated), hence the binade of c_k0 itself
+    float Z;
+    {
+        const float units = ldexpf(ls.tot, (int)sh_in);
+        const float R = (float)r * units, wmax = (float)(1u << sh_max) + 2.0f;
+        const float jb = (float)d < R + 2.0f ? (float)d : R + 2.0f;
+        const float zr = ((jb + 6.0f) * (R + wmax) - 0.5f * jb * (jb - 1.0f)) * (1.001f / 16777216.0f) + 1e-6f;
+        Z = (1.01f * zr + 1.01f * (float)E0 * (1.0f / 16777216.0f) + 0.01f) * upu * 1.002f + 1.0f;
+    }
+    if (!(voff - Z >= 0.0f) || !(voff + Z + 2.0f < 8388608.0f)) TIGHT_BAIL(4);
+    float xmax = x_in > x_out ? x_in : x_out;
+    if (has_pv && x_pv > xmax) xmax = x_pv;
+    const float xmax_u = ldexpf((float)B::sig_of(xmax), B::eb_of(xmax) - e_t) * 1.0001f;   // largest value, ulps of the top binade
+    float d_lo = 0.0f, d_hi = 0.0f, g_lo = 0.0f, g_hi = 0.0f, h_lo = 0.0f, h_hi = 0.0f, mag = 0.0f;
+    float ro_t = 0.0f, scale = 1.0f;
+    int jl = 0;                                             // lowest evaluated binade: e_t - jl
+#pragma unroll
+    for (int j = 0; j < LANE_TB; j++, scale *= 0.5f) {
+        const int e = e_t - j;
+        if (e < 2) break;
+        const QuantErr qo = quant_err(x_out, e);
+        if (qo.a0 != qo.a1 || qo.a0 == 0 || qo.a0 >= B::SAT) {   // no constant "out" increment here: this binade and
+            if (j == 0) TIGHT_BAIL(5);                            // everything below it are bounded, not evaluated
+            break;
+        }
+        jl = j;
+        const float ro = qo.d0 * fast_rcp((float)qo.a0);   // drift per ulp of span, "out" additions only (dimensionless)
+        if (j == 0) ro_t = ro;                              // (the top binade's span: below)
+        else {                                              // a full binade spans 2^23 of its ulps, less two elements
+            float w_lo = 8388608.0f - 2.0f * (xmax_u / scale) - 2.0f;
+            if (w_lo < 0.0f) w_lo = 0.0f;
+            const float b0 = ro * w_lo * scale, b1 = ro * 8388608.0f * scale;
+            d_lo += b0 < b1 ? b0 : b1;
+            d_hi += b0 < b1 ? b1 : b0;
+            mag += fabsf(b0) + fabsf(b1);
+        }
+        // (a value >= the binade's bottom always leaves it: a crossing addition, none inside; a tie rounds either way)
+        if (i1) {
+            const QuantErr qi = quant_err(x_in, e);
+            if (qi.a0 < B::SAT) {
+                const float g = (qi.d0 - ro * (float)qi.a0) * scale;
+                if (g < g_lo) g_lo = g;
+                if (g > g_hi) g_hi = g;
+                if (qi.a1 != qi.a0) {
+                    const float g1 = (qi.d0 + (float)(int)(qi.a1 - qi.a0) - ro * (float)qi.a1) * scale;
+                    if (g1 < g_lo) g_lo = g1;
+                    if (g1 > g_hi) g_hi = g1;
+                }
+            }
+        }
+        if (pv0) {
+            const QuantErr qp = quant_err(x_pv, e);
+            if (qp.a0 < B::SAT) {
+                const float h = (qp.d0 - ro * (float)qp.a0) * scale;
+                if (h < h_lo) h_lo = h;
+                if (h > h_hi) h_hi = h;
+                if (qp.a1 != qp.a0) {
+                    const float h1 = (qp.d0 + (float)(int)(qp.a1 - qp.a0) - ro * (float)qp.a1) * scale;
+                    if (h1 < h_lo) h_lo = h1;
+                    if (h1 > h_hi) h_hi = h1;
+                }
+            }
+        }
+    }
+    if (e_t - jl <= 2) TIGHT_BAIL(8);
+    // crossing additions: one per binade, <= half an ulp of the binade entered (1 ulp of the top one in total);
+    // additions before the evaluated binades: count * half an ulp of the binade below the lowest evaluated one;
+    // float32 evaluation of the terms: 2^-20 of their magnitudes
+    const float low_scale = ldexpf(1.0f, -jl);
+    float n_low = 1.02f * 8388608.0f * low_scale / upu + 3.0f;
+    if (n_low > (float)k1) n_low = (float)k1;
+    const float gi = (float)i1;
+    const float eps = 1.0f + n_low * 0.25f * low_scale +
+                      (1.0f / 1048576.0f) * (mag + fabsf(ro_t) * 8388608.0f + gi * (g_hi - g_lo) + (h_hi - h_lo)) + 0.02f;
+    // the top binade spans [entry, c_k0]: c_k0 from the a-priori bound first, then from the interval that gives
+    float lo_off = -Z, hi_off = Z;                          // c_k0 / ulp_t - (V + fr)
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        float w_lo = voff + lo_off - xmax_u - 2.0f;
+        if (w_lo < 0.0f) w_lo = 0.0f;
+        const float b0 = ro_t * w_lo, b1 = ro_t * (voff + hi_off + 2.0f);
+        const float n_lo = d_lo + (b0 < b1 ? b0 : b1) + gi * g_lo + h_lo - eps;
+        const float n_hi = d_hi + (b0 < b1 ? b1 : b0) + gi * g_hi + h_hi + eps;
+        if (n_lo > lo_off) lo_off = n_lo;
+        if (n_hi < hi_off) hi_off = n_hi;
+    }
+    lo_off -= 4e-6f * (fabsf(lo_off) + 1.0f);
+    hi_off += 4e-6f * (fabsf(hi_off) + 1.0f);
+    if (!(voff + lo_off >= 0.0f) || !(voff + hi_off + 2.0f < 8388608.0f) || !(lo_off <= hi_off)) TIGHT_BAIL(9);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (getenv("PW_TIGHT_DEBUG"))
+        fprintf(stderr, "tight k1=%u i1=%u pv0=%u width=%.1f ulps: base=%.1f g=%.1f h=%.1f eps=%.1f io=%u Z=%.1f\n", k1, i1, pv0, hi_off - lo_off,
+                d_hi - d_lo, gi * (g_hi - g_lo), h_hi - h_lo, 2 * eps, B::quantize(x_out, e_t).a0, Z);
+#endif
+    uint64_t C_lo = (uint64_t)((int64_t)V + (int64_t)ceilf(fr + lo_off)), C_hi = (uint64_t)((int64_t)V + (int64_t)floorf(fr + hi_off));
+    const uint64_t Tt = B::threshold(r, e_t);
+    if (Tt >= (uint64_t)B::TOP) TIGHT_BAIL(10);                     // r lies beyond this binade
+    if (C_hi >= Tt) C_hi = Tt - 1ull;                                      // c_k0 < r is known (lane_decide)
+    if (C_lo > C_hi) TIGHT_BAIL(11);
+    // the chain inside the top binade from position k1, for both ends of the interval: same element => decided
+    const Inc<float> qo = B::quantize(x_out, e_t), qi = B::quantize(x_in, e_t), qp = B::quantize(x_pv, e_t);
+    const uint32_t lim = (p_f != 0xffffffffu && p_f < kend) ? p_f + 1u : kend;   // classes are known up to p_next
+    if (p_f < lim && qi.a0 != qi.a1) TIGHT_BAIL(13);
+    const uint32_t sp = (has_pv && pp >= k1 && pp < lim) ? pp : 0xffffffffu;   // prev ahead: the other special position
+    if (sp != 0xffffffffu && qp.a0 != qp.a1) TIGHT_BAIL(14);
+    const uint64_t io = qo.a0;                                             // (no tie, not 0: checked for the top binade)
+    uint32_t pos = k1;
+    for (int seg = 0; seg < 3; seg++) {
+        // run of "out" positions [pos, nxt), then the special position nxt (prev, or the common neighbour p_next)
+        const uint32_t nxt = (sp != 0xffffffffu && sp >= pos) ? sp : ((p_f < lim && p_f >= pos) ? p_f : lim);
+        const uint64_t n_hi = div_floor_small(Tt - C_hi + io - 1ull, io);   // additions the upper candidate needs (>= 1)
+        const uint64_t run = (uint64_t)(nxt - pos);
+        if (n_hi <= run) {                                                 // it gets there inside the run:
+            if (C_lo + n_hi * io >= Tt) return pos + (uint32_t)n_hi - 1u;  // ... and so does the lower one, no earlier
+            TIGHT_BAIL(16);
+        }
+        if (nxt >= lim) TIGHT_BAIL(15);                                    // classes beyond are not known here
+        C_lo += run * io;
+        C_hi += run * io;
+        const uint64_t inc = nxt == sp ? qp.a0 : qi.a0;
+        C_lo += inc;
+        C_hi += inc;
+        if (C_hi >= Tt) { if (C_lo >= Tt) return nxt; TIGHT_BAIL(16); }
+        if (nxt == p_f) TIGHT_BAIL(15);                                    // the next common neighbour is not known
+        pos = nxt + 1u;
+    }
+    TIGHT_BAIL(15);
+}
+
+#undef TIGHT_BAIL
 }  // namespace pw

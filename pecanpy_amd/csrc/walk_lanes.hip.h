@@ -41,6 +41,18 @@ struct ERec {
 };
 static_assert(sizeof(ERec) == 32, "edge record is two 16-byte loads");
 
+// A walk parked at a step that only the float32 chain can settle: everything the step and the rest of the walk
+// need.  The lane kernel appends these to a queue instead of running the chain with a handful of its 64 lanes enabled;
+// lanes_chain_kernel settles a whole queue at full width (choice), and the next lane launch resumes the walks.
+struct SuspRec {
+    uint32_t job, j, s0, d;
+    uint32_t n_in, pp, coff_lo, coff_hi;
+    uint32_t kmax, choice, soff_lo, soff_hi;   // (soff: position of the walk's draws in this call's stream block)
+    float tot, wo;
+    double r;
+};
+static_assert(sizeof(SuspRec) == 64, "queue record is four 16-byte accesses");
+
 struct LanesArgs {
     const ERec *__restrict__ erec;
     const uint32_t *__restrict__ clist;
@@ -64,6 +76,11 @@ struct LanesArgs {
     float w_out, w_prev;                      // fl32(1/q), fl32(1/p): powers of two (host checked)
     const uint32_t *__restrict__ hint;        // per-edge hint words of the guided search (seqscan.h), or nullptr
     uint32_t hs_in, hs_out;                   // mass units the hints were built for
+    SuspRec *susp;                            // queue for walks that need the float chain (nullptr: chains run in-kernel)
+    unsigned long long *susp_count;
+    uint32_t susp_chunk;                      // queue slots a wavefront reserves at a time (1: exact, no void slots)
+    const SuspRec *resume;                    // walks to take up again (their `choice` settled) INSTEAD of fresh jobs
+    uint64_t n_resume;
 };
 
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
@@ -81,7 +98,10 @@ __device__ unsigned long long g_lprof[16];
 #endif
 
 #ifndef PW_LANES_MIN_WAVES
-#define PW_LANES_MIN_WAVES 6   // 80 VGPRs: the per-lane chain spills heavily at 64
+#define PW_LANES_MIN_WAVES 4   // 128 VGPRs: the kernel needs ~130 (float64 interval arithmetic); at 5-6 waves it spills in the hot loop and runs 1.6-2x slower
+#endif
+#ifndef PW_LANES_MIN_WAVES_Q
+#define PW_LANES_MIN_WAVES_Q 5   // ... of the queueing form (no chain code): ~100 VGPRs, fits 5 waves without spilling
 #endif
 #ifndef PW_LANES_WAIT
 #define PW_LANES_WAIT 16   // ambiguous lanes that gather before the refined decision runs
@@ -89,8 +109,18 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_REFINE
 #define PW_LANES_REFINE 0  // 1: waiting lanes first try lane_refine (seqscan.h); measured 6 % slower -- DESIGN.md 9b
 #endif
+#ifndef PW_LANES_CHUNK
+#define PW_LANES_CHUNK 1024   // jobs a wavefront reserves per access to the shared job counter
+#endif
+#ifndef PW_LANES_REFILL_MIN
+#define PW_LANES_REFILL_MIN 1   // idle lanes that trigger a refill
+#endif
+#ifndef PW_LANES_TIGHT
+#define PW_LANES_TIGHT 1   // ambiguous steps first try lane_tight (seqscan.h), which settles ~9 in 10 without a memory
+#endif                     // access: 1 = right away, 2 = once PW_LANES_WAIT of them have gathered (stage 1), 0 = off
+#define PW_LANES_STAGE1 (PW_LANES_REFINE || PW_LANES_TIGHT == 2)
 #ifndef PW_LANES_WAIT2
-#define PW_LANES_WAIT2 (PW_LANES_REFINE ? 8 : PW_LANES_WAIT)   // lanes that gather before their float chains run
+#define PW_LANES_WAIT2 (PW_LANES_STAGE1 ? 8 : (PW_LANES_TIGHT ? 2 : PW_LANES_WAIT))   // lanes that gather before their float chains run in place
 #endif
 
 // Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
@@ -132,11 +162,15 @@ __device__ unsigned long long g_lprof[16];
                     for (uint32_t z_ = A.j; z_ <= L; z_++) row_[z_] = 0;                        \
                 }                                                                               \
                 A.flags = 0;                                                                    \
-            }                                                                                   \
+            } else r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */   \
         }                                                                                       \
     } while (0)
 
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_LANES_MIN_WAVES)
+// INPLACE: steps the interval decision leaves open run their float chain in the kernel (waiting lanes, below) -- the
+// form used when no queue is given (a.susp == nullptr: short job lists, the last round).  !INPLACE: such walks are
+// always parked (a.susp != nullptr); without the chain code the kernel needs fewer registers.
+template <bool INPLACE>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : PW_LANES_MIN_WAVES_Q)
 walk_lanes_kernel(LanesArgs a) {
     const int lane = lane_id();
 #ifdef PW_LANES_PREFETCH
@@ -148,7 +182,7 @@ walk_lanes_kernel(LanesArgs a) {
 #endif
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
-    const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
+    const uint64_t n_work = a.resume ? a.n_resume : (a.job_list ? a.n_list : a.n_jobs);
     const float w_out = a.w_out, w_prev = a.w_prev;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
 #ifdef PW_PROF_LANES
@@ -166,16 +200,21 @@ walk_lanes_kernel(LanesArgs a) {
         uint32_t flags;                  // bit 0: active, bit 1: waiting for the float chain
     };
     constexpr uint32_t F_ACTIVE = 1u, F_WAIT = 2u, F_WAIT2 = 4u;   // waiting for the refinement / for the float chain
+    constexpr uint32_t F_PRE = 8u;                                 // resumed walk: the pending step's choice is known (pre)
+    uint32_t pre = 0;
     Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
     bool exhausted = false;
+    uint64_t pool_lo = 0, pool_hi = 0;   // wavefront-uniform: job indices reserved from the shared counter
+    uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
+    const uint64_t grid_lanes = (uint64_t)gridDim.x * (WAVES_PER_BLOCK * WAVE);
     unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0, n_wave = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
     ListWinRaw ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
-#if PW_LANES_REFINE
-    uint32_t k1 = 0, f1 = 0, shifts = 0;
+#if PW_LANES_STAGE1
+    uint32_t k1 = 0, f1 = 0, shifts = 0, p_next = 0;
 #endif
     const uint32_t *const hint = a.hint;
     const uint32_t hs_in = a.hs_in, hs_out = a.hs_out;
@@ -185,13 +224,43 @@ walk_lanes_kernel(LanesArgs a) {
         for (;;) {
             const uint64_t need = ballot(!(A.flags & F_ACTIVE) && !exhausted);
             if (!need) break;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(a.job_counter, (unsigned long long)__popcll(need));
-            base = readfirst_u64(base);
-            if (!(A.flags & F_ACTIVE) && !exhausted) {
-                const uint64_t widx = base + (uint64_t)__popcll(need & lane_lt);
-                if (widx >= n_work) exhausted = true;
-                else {
+#if PW_LANES_REFILL_MIN > 1
+            // a refill is three dependent loads for the whole wavefront: wait until a few lanes are idle
+            if ((uint32_t)__popcll(need) < PW_LANES_REFILL_MIN && ballot((A.flags & F_ACTIVE) != 0) != 0) break;
+#endif
+            // jobs are taken from a wavefront-local pool; the shared counter is touched once per PW_LANES_CHUNK jobs
+            // (one atomic per refill made every wavefront queue on ONE address ~40 M times a second -- the counter's
+            // L2 channel, not the walks, set the pace).  Near the end of the work the chunks shrink to what is needed.
+            if (pool_lo == pool_hi) {
+                const uint64_t left = n_work > pool_hi ? n_work - pool_hi : 0;   // (as far as this wavefront knows)
+                const unsigned long long chunk = left > 16ull * grid_lanes ? (unsigned long long)PW_LANES_CHUNK
+                                                                          : (unsigned long long)__popcll(need);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(a.job_counter, chunk);
+                base = readfirst_u64(base);
+                pool_lo = base;
+                pool_hi = base + chunk < n_work ? base + chunk : n_work;
+                if (pool_lo >= n_work) { pool_lo = pool_hi = n_work; exhausted = true; continue; }
+            }
+            const uint64_t avail = pool_hi - pool_lo;
+            const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
+            const uint64_t pool_base = pool_lo;
+            pool_lo += avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+            if (!(A.flags & F_ACTIVE) && !exhausted && rank < avail) {
+                const uint64_t widx = pool_base + rank;
+                if (a.resume) {
+                    const uint4 *qp = (const uint4 *)(a.resume + widx);
+                    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+                    if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
+                        A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
+                        A.n_in = q1.x; A.pp = q1.y; A.coff = ((uint64_t)q1.w << 32) | q1.z;
+                        A.wd = 0; pre = q2.y;                       // (wd: refreshed by the parked step's edge record)
+                        A.soff = ((uint64_t)q2.w << 32) | q2.z;
+                        const uint32_t slot = (A.j - 1u) & 3u;      // staged output cells of the group in progress
+                        if (slot) ob = *(const ListWinRaw *)(a.out + (uint64_t)A.job * W + (A.j - slot));
+                        A.flags = F_ACTIVE | F_PRE;
+                    }
+                } else {
                     A.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
                     const uint32_t start = a.starts[A.job];
                     const uint4 vr = a.vrec[start];
@@ -204,6 +273,7 @@ walk_lanes_kernel(LanesArgs a) {
                     } else {
                         A.soff = a.stream_off[A.job] - a.rng_base;
                         A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.coff = 0; A.wd = 0; A.j = 1;
+                        r = a.rng[A.soff];
                         A.flags = F_ACTIVE;
                     }
                 }
@@ -221,38 +291,91 @@ walk_lanes_kernel(LanesArgs a) {
         //   2. lane_chain : the float32 chain itself, for what the refinement leaves open.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
+        LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
         if (runnable) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
-            r = a.rng[A.soff + (A.j - 1)];
-            LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u};
+            // (r = this step's draw: loaded when the previous step was applied / the walk was started)
             choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd);
             n_probes += ls.probes;
-            if (choice == LANE_AMBIGUOUS) {
-                A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax; n_amb++;
-#if PW_LANES_REFINE
-                k1 = ls.k1; f1 = ls.f; shifts = ls.shifts;
-#endif
-            }
+            if (choice == LANE_AMBIGUOUS) n_amb++;
         }
         LPROF_T(1);
-        {
-#if PW_LANES_REFINE
+#if PW_LANES_TIGHT == 1
+        // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
+        if (ballot(runnable && choice == LANE_AMBIGUOUS)) {
+            LPROF_C(9, 1);
+            LPROF_C(10, __popcll(ballot(runnable && choice == LANE_AMBIGUOUS)));
+            if (runnable && choice == LANE_AMBIGUOUS) choice = lane_tight(A.d, A.pp, r, wo, w_prev, ls);
+            LPROF_T(2);
+        }
+#endif
+        if (!INPLACE || a.susp) {
+            // park the walk: the chain runs later, at full width (lanes_chain_kernel); this lane takes another walk
+            const bool park = runnable && choice == LANE_AMBIGUOUS;
+            const uint64_t pm = ballot(park);
+            if (pm) {
+                // queue slots come from a wavefront-local reservation too (slots left over at the end are marked void)
+                const uint64_t np = (uint64_t)__popcll(pm);
+                if (sp_hi - sp_lo < np) {
+                    for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;
+                    const unsigned long long chunk = a.susp_chunk > np ? a.susp_chunk : np;
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.susp_count, chunk);
+                    sp_lo = readfirst_u64(base);
+                    sp_hi = sp_lo + chunk;
+                }
+                const uint64_t base = sp_lo;
+                sp_lo += np;
+                if (park) {
+                    uint4 *qp = (uint4 *)(a.susp + (base + (uint64_t)__popcll(pm & lane_lt)));
+                    qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
+                    qp[1] = make_uint4(A.n_in, A.pp, (uint32_t)A.coff, (uint32_t)(A.coff >> 32));
+                    qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
+                    qp[3] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
+                                       (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
+                    const uint32_t slot = (A.j - 1u) & 3u;          // staged output cells: written out now
+                    uint32_t *cell = a.out + (uint64_t)A.job * W + (A.j - slot);
+                    if (slot >= 1u) cell[0] = ob.v[0];
+                    if (slot >= 2u) cell[1] = ob.v[1];
+                    if (slot >= 3u) cell[2] = ob.v[2];
+                    A.flags = 0;
+                }
+            }
+        } else if (INPLACE && runnable && choice == LANE_AMBIGUOUS) {
+            A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax;
+#if PW_LANES_STAGE1
+            k1 = ls.k1; f1 = ls.f; shifts = ls.shifts; p_next = ls.p_next;
+#endif
+        }
+        if (A.flags == (F_ACTIVE | F_PRE)) { choice = pre; A.flags = F_ACTIVE; }   // resumed walk: its parked step
+        if (INPLACE) {
+#if PW_LANES_STAGE1
+            // stage 1 for the waiting lanes, once enough have gathered: the interval decision (PW_LANES_TIGHT == 2),
+            // then the refined decision (PW_LANES_REFINE)
             const uint64_t w1 = ballot((A.flags & F_WAIT) != 0);
             if (w1 != 0 && ((uint32_t)__popcll(w1) >= PW_LANES_WAIT || ballot(runnable && choice != LANE_AMBIGUOUS) == 0)) {
                 LPROF_C(9, 1);
                 LPROF_C(10, __popcll(w1));
                 if (A.flags & F_WAIT) {
-                    LaneStep ls{tot, kmax, 0u, k1, f1, shifts};
-                    uint32_t reads = 0;
-                    const uint32_t res = lane_refine(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, reads);
-                    n_probes += reads;
+                    LaneStep lw{tot, kmax, 0u, k1, f1, shifts, p_next};
+                    uint32_t res = LANE_AMBIGUOUS;
+#if PW_LANES_TIGHT == 2
+                    res = lane_tight(A.d, A.pp, r, wo, w_prev, lw);
+#endif
+#if PW_LANES_REFINE
+                    if (res == LANE_AMBIGUOUS) {
+                        uint32_t reads = 0;
+                        res = lane_refine(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, lw, reads);
+                        n_probes += reads;
+                    }
+#endif
                     if (res != LANE_AMBIGUOUS) { choice = res; A.flags = F_ACTIVE; }
                     else A.flags = F_ACTIVE | F_WAIT2;
                 }
                 LPROF_T(2);
             }
 #else
-            if (A.flags & F_WAIT) A.flags = F_ACTIVE | F_WAIT2;   // no refinement stage: straight to the chain queue
+            if (A.flags & F_WAIT) A.flags = F_ACTIVE | F_WAIT2;   // no stage 1: straight to the chain queue
 #endif
             const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
             if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_WAIT2 || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0) &&
@@ -281,6 +404,8 @@ walk_lanes_kernel(LanesArgs a) {
         LPROF_T(3);
     }
 #undef PW_LANE_APPLY
+    if (a.susp)
+        for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES
     if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
 #endif
@@ -298,6 +423,38 @@ walk_lanes_kernel(LanesArgs a) {
         if (n_probes) atomicAdd(a.stats + 6, n_probes);
         if (n_amb) atomicAdd(a.stats + 7, n_amb);
         if (n_wave) atomicAdd(a.stats + 9, n_wave);
+    }
+}
+
+// ---- the float32 chains of a whole queue of parked walks, one lane each, every lane busy ------------------------------
+__global__ void __launch_bounds__(256)
+lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, float w_prev, unsigned long long *stats) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long reads_l = 0, done = 0;
+    if (i < n) {
+        const uint4 *qp = (const uint4 *)(q + i);
+        const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+        if (q0.x != NOT_FOUND) {
+        const float tot = __uint_as_float(q3.x), wo = __uint_as_float(q3.y);
+        const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
+        const float x_in = 1.0f / tot;
+        uint32_t reads = 0;
+        const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev, clist + (((uint64_t)q1.w << 32) | q1.z),
+                                        reads, nullptr, 0u, 0u, 0u, nullptr, 0u);
+        uint32_t choice = res;
+        if (res == LANE_CHAIN_END || res == LANE_TIE) choice = q0.w;   // overflow read / tie budget: the wave kernel redoes the walk
+        q[i].choice = choice;
+        reads_l = reads;
+        done = 1;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        reads_l += (unsigned long long)__shfl_down((long long)reads_l, (unsigned)off, WAVE);
+        done += (unsigned long long)__shfl_down((long long)done, (unsigned)off, WAVE);
+    }
+    if (lane_id() == 0 && done) {
+        atomicAdd(stats + 6, reads_l);
+        atomicAdd(stats + 9, done);
     }
 }
 

@@ -40,7 +40,7 @@ for s in scales:
         nbad = int((a != b).any(dim=1).sum().item())
         print(f"  p={p} q={q}: equal={same} bad_rows={nbad} lanes {sa['walk_kernel_ms']:.1f} ms (lane kernel {sa['lane_kernel_ms']:.1f}) "
               f"wave {sb['walk_kernel_ms']:.1f} ms  steps {sa['total_steps']} / {sb['total_steps']}  overflow {sa['overflow_reads']}/{sb['overflow_reads']} "
-              f"redo {sa['redo_walks']} amb {sa['ambiguous_steps']} probes {sa['list_entries_read']} lane_kernel={sa['lane_kernel']}  "
+              f"redo {sa['redo_walks']} amb {sa['ambiguous_steps']} chain {sa['wave_chain_steps']} probes {sa['list_entries_read']} lane_kernel={sa['lane_kernel']}  "
               f"-> {sa['total_steps'] / sa['walk_kernel_ms'] / 1e3:.0f} vs {sb['total_steps'] / sb['walk_kernel_ms'] / 1e3:.0f} Msteps/s", flush=True)
         if not same:
             rows = (a != b).any(dim=1).nonzero()[:3, 0].tolist()
