@@ -318,10 +318,13 @@ def main():
         # 8-byte draw, one 4-byte output cell, 4 bytes per common-neighbour list entry actually read (counted in
         # the kernel); per walk: start 4 + stream offset 8 + vertex record 16 + header/length cells 8
         entries = int(acc["list_entries_read"][-1])
-        declared = steps0 * (32 + 8 + 4) + entries * 4 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) + (hi - lo - walks0) * 8
-        kernel = "walk_lanes_kernel"
+        # ... and 128 bytes per step that needs the float32 chain (the walk's queue record, written and read back)
+        chain_steps = int(acc["wave_chain_steps"][-1])
+        declared = (steps0 * (32 + 8 + 4) + entries * 4 + chain_steps * 128 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
+                    (hi - lo - walks0) * 8)
+        kernel = "walk_lanes_kernel (every round of a pass) + lanes_chain_kernel"
         fmt = ("32 B edge record + 8 B draw + 4 B output per step, 4 B per common-neighbour list entry read "
-               "(in-kernel counter), 36 B per walk")
+               "(in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
     elif cfg["graph"] == "er":
         wpr = (n_nodes + 63) // 64
         declared = steps0 * (3 * wpr * 8 + 12)
@@ -357,6 +360,10 @@ def main():
         roofline["float_chain_step_frac"] = round(acc["wave_chain_steps"][-1] / max(steps0, 1), 5)
         roofline["list_entries_per_step"] = round(acc["list_entries_read"][-1] / max(steps0, 1), 2)
         roofline["redo_walks"] = int(acc["redo_walks"][-1])
+        roofline["lane_rounds"] = int(st["lane_rounds"])
+        roofline["launch_note"] = ("one pass = lane_rounds launches of walk_lanes_kernel (walks whose step needs the float32 chain "
+                                   "are parked and resumed by the next round) + one lanes_chain_kernel launch per queue; "
+                                   "avg_launch_ms and declared_bytes_per_launch are per PASS (sum over these launches)")
 
     cpu = None
     if not args.no_cpu_baseline and world == 1 and cfg["graph"] == "rmat" and not extend:

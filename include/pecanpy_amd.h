@@ -67,12 +67,13 @@ typedef struct {
                                    (fallback on sink-heavy directed graphs) */
     /* lane kernel (one walk per lane, csrc/walk_lanes.hip.h): unit-weight CSR graphs, 1/p and 1/q powers of two */
     uint32_t lane_kernel;       /* 1 when the call ran on the lane kernel */
-    uint32_t reserved;
+    uint32_t lane_rounds;       /* lane kernel launches of the call: walks whose step needs the float32 chain are parked,
+                                   the chains of a whole queue run in one launch, the next round resumes the walks */
     uint64_t redo_walks;        /* walks the lane kernel handed to the wave-per-walk kernel (overflow reads, ...) */
     uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
-    uint64_t ambiguous_steps;   /* steps decided by the float32 chain instead of exact integer arithmetic */
+    uint64_t ambiguous_steps;   /* steps the a-priori rounding bound left open (settled by the interval decision or the chain) */
     double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
-    uint64_t wave_chain_steps;  /* of the ambiguous steps, those the per-lane chain could not afford (walk redone) */
+    uint64_t wave_chain_steps;  /* of the ambiguous steps, those that needed the float32 chain itself */
     double param_index_ms;      /* device time spent in THIS call building an index that depends on (p, q, extend):
                                    per-edge normalisers of weighted graphs, hint tables; 0 when cached in the handle */
 } pw_stats;

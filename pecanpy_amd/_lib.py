@@ -24,7 +24,7 @@ class PwStats(C.Structure):
         ("walk_kernel_launches", C.c_uint32),
         ("stream_addressing", C.c_uint32),
         ("lane_kernel", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("lane_rounds", C.c_uint32),
         ("redo_walks", C.c_uint64),
         ("list_entries_read", C.c_uint64),
         ("ambiguous_steps", C.c_uint64),

@@ -804,6 +804,7 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
 static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     wa.tot_e = nullptr;
     wa.tot_v = nullptr;
+    wa.resume = 0;
     if (g->kind != 0 || g->unit || !g->nnz || g->tot_failed || getenv("PECANPY_AMD_NO_TOT")) return 0;
     const bool fresh = g->tot_extend == (extend ? 1 : 0) && g->tot_p == wa.p && g->tot_q == wa.q &&
                        (!extend || g->tot_thr_version == g->thr_version);
@@ -963,7 +964,6 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
-    g->lane_rounds = 0;
     for (int round = 0;; round++) {
         const bool queue_out = use_queue && todo > tail && round < 64;
         la.susp = queue_out ? g->susp[round & 1].p : nullptr;
@@ -975,6 +975,13 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         uint64_t grid = (uint64_t)g->n_cu * (uint64_t)(queue_out ? occ : occ_in);
         if (grid > want) grid = want;
         if (grid < 1) grid = 1;
+        {   // consecutive jobs share pages of the draw stream and of the output: a wavefront reserves runs of them, at
+            // most a quarter of its share of the work (balance), a power of two in [64, PW_LANES_CHUNK]
+            const uint64_t share = todo / (grid * pw::WAVES_PER_BLOCK * 4);
+            uint32_t c = 64;
+            while (c * 2 <= PW_LANES_CHUNK && (uint64_t)c * 2 <= share) c *= 2;
+            la.job_chunk = c;
+        }
         HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipMemsetAsync(g->counters.p + 32, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipEventRecord(g->ev[4], g->stream));
@@ -1095,11 +1102,15 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *re
     // whole job arrays go step-synchronously (walk_bsp.hip.h); repair passes over job lists keep the persistent kernel
     const bool bsp = !wa.job_list && getenv("PECANPY_AMD_BSP") && (uint64_t)wa.L * 64 * sizeof(uint32_t) < 60000;
     int rc = bsp ? launch_bsp_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
+    // Walks the lane kernel cannot step (overflow reads, rows outside the exact range) go to walk_kernel, which resumes
+    // them at that step.  (Handing them BACK once they are on a CSR entry again was tried: such walks overflow again
+    // and again, and the extra rounds on a nearly empty GPU cost more than walk_kernel's whole-row chains -- 198 vs 189 ms.)
     if (rc || !n_redo) return rc;
     if (redo_total) *redo_total += n_redo;
     pw::WalkArgs wr = wa;
     wr.job_list = g->redo.p;
     wr.n_list = n_redo;
+    wr.resume = bsp ? 0u : 1u;   // from the step the lane kernel stopped at (its rows hold the walks so far)
     return launch_wave_walks(g, wr, extend);
 }
 
@@ -1218,6 +1229,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.stats = g->counters.p + 1;
     wa.tot_e = nullptr;
     wa.tot_v = nullptr;
+    wa.resume = 0;
     {
         // unit-weight biases exactly as the kernels form them: fl32(f64(1.0f) / q) (sparse_rw.py:59-62)
         wa.w_out = (float)(1.0 / q);
@@ -1234,6 +1246,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     uint64_t redo_total = 0;
     const bool lanes = lanes_eligible(g, wa);
     g->lane_ms = 0;
+    g->lane_rounds = 0;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
     // the lane kernel only writes the cells a walk fills: the matrix starts zeroed (pecanpy.py:182-187)
     if (lanes) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
@@ -1324,6 +1337,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.wave_chain_steps = h[10];
     st.param_index_ms = g->param_ms_call;
     st.lane_kernel_ms = g->lane_ms;
+    st.lane_rounds = g->lane_rounds;
     if (stats) *stats = st;
     return PW_OK;
 }

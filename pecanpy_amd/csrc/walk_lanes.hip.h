@@ -79,6 +79,7 @@ struct LanesArgs {
     SuspRec *susp;                            // queue for walks that need the float chain (nullptr: chains run in-kernel)
     unsigned long long *susp_count;
     uint32_t susp_chunk;                      // queue slots a wavefront reserves at a time (1: exact, no void slots)
+    uint32_t job_chunk;                       // jobs a wavefront reserves at a time while plenty are left
     const SuspRec *resume;                    // walks to take up again (their `choice` settled) INSTEAD of fresh jobs
     uint64_t n_resume;
 };
@@ -110,7 +111,8 @@ __device__ unsigned long long g_lprof[16];
 #define PW_LANES_REFINE 0  // 1: waiting lanes first try lane_refine (seqscan.h); measured 6 % slower -- DESIGN.md 9b
 #endif
 #ifndef PW_LANES_CHUNK
-#define PW_LANES_CHUNK 1024   // jobs a wavefront reserves per access to the shared job counter
+#define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
+                              // its share of the work at most)
 #endif
 #ifndef PW_LANES_REFILL_MIN
 #define PW_LANES_REFILL_MIN 1   // idle lanes that trigger a refill
@@ -127,10 +129,15 @@ __device__ unsigned long long g_lprof[16];
 // otherwise one 32-byte record names the next vertex and everything the next step needs.
 #define PW_LANE_APPLY()                                                                         \
     do {                                                                                        \
-        if (choice >= A.d) {                                                                    \
+        if (choice >= A.d) {   /* walk_kernel takes the walk over AT THIS STEP (WalkArgs::resume) */ \
             const unsigned long long slot_ = atomicAdd(a.redo_count, 1ull);                     \
             a.redo_list[slot_] = A.job;                                                         \
-            n_steps -= (A.j - 1);                                                               \
+            const uint32_t st_ = (A.j - 1u) & 3u;   /* staged cells out, length cell = A.j */     \
+            uint32_t *row_ = a.out + (uint64_t)A.job * W;                                       \
+            if (st_ >= 1u) row_[A.j - st_] = ob.v[0];                                           \
+            if (st_ >= 2u) row_[A.j - st_ + 1u] = ob.v[1];                                      \
+            if (st_ >= 3u) row_[A.j - st_ + 2u] = ob.v[2];                                      \
+            row_[L + 1] = A.j;                                                                  \
             A.flags = 0;                                                                        \
         } else {                                                                                \
             const uint4 *rp_ = (const uint4 *)(a.erec + ((uint64_t)A.s0 + choice));             \
@@ -233,8 +240,8 @@ walk_lanes_kernel(LanesArgs a) {
             // L2 channel, not the walks, set the pace).  Near the end of the work the chunks shrink to what is needed.
             if (pool_lo == pool_hi) {
                 const uint64_t left = n_work > pool_hi ? n_work - pool_hi : 0;   // (as far as this wavefront knows)
-                const unsigned long long chunk = left > 16ull * grid_lanes ? (unsigned long long)PW_LANES_CHUNK
-                                                                          : (unsigned long long)__popcll(need);
+                const unsigned long long chunk = left > 4ull * grid_lanes ? (unsigned long long)a.job_chunk
+                                                                         : (unsigned long long)__popcll(need);
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(a.job_counter, chunk);
                 base = readfirst_u64(base);

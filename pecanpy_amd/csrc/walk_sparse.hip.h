@@ -122,6 +122,9 @@ struct WalkArgs {
     // walker that arrived by CSR entry e = (u -> v); tot_v[v] = the unbiased row sum of a first step), or nullptr
     const float *__restrict__ tot_e;
     const float *__restrict__ tot_v;
+    // walks handed over by the lane kernel in mid-walk: the row holds cells 0 .. len - 1 and len (>= 1) in its length
+    // cell; the walk goes on from there instead of being walked again from its start
+    uint32_t resume;
 };
 #define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
 
@@ -1358,6 +1361,19 @@ walk_kernel(WalkArgs a) {
         uint32_t len_out = L + 1;
         uint32_t prev_edge = NOT_FOUND;   // CSR entry the walker arrived by (NOT_FOUND: first step / mirrored overflow read)
         uint32_t j = 1;
+        if (!DENSE && PW_KARG(uint32_t, resume) != 0) {
+            const sptr<uint32_t> row_in = as_scalar<uint32_t>(PW_KARG(uint64_t, out));
+            const uint32_t j0 = row_in[job * W + L + 1];
+            if (j0 >= 2 && j0 <= L) {   // (the edge prev -> cur is not looked up: the first step here is an eager one)
+                prev = row_in[job * W + j0 - 2];
+                cur = row_in[job * W + j0 - 1];
+                enter(prev);
+                vp = vc;
+                enter(cur);
+                j = j0;
+            }
+        }
+        const uint32_t j_first = j;
         for (; j <= L; j++) {
             const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
             if (d == 0) {
@@ -1439,7 +1455,7 @@ walk_kernel(WalkArgs a) {
         if (lane == 0) {
             row[0] = start;
             row[L + 1] = len_out;
-            stat[0] += j - 1;   // transitions sampled by this walk
+            stat[0] += j - j_first;   // transitions sampled here
         }
         for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
     }

@@ -237,3 +237,65 @@ def test_step_synchronous_path_equals_persistent_lane_kernel(monkeypatch):
     monkeypatch.setenv("PECANPY_AMD_BSP", "1")
     got = deng.simulate("SparseOTF", 0.25, 4, False, st, 12, seed=3)
     assert np.array_equal(got, want)
+
+
+def _hub_graph(rng, n=60000, hub_deg=40000):
+    hub = np.arange(1, hub_deg + 1)
+    src = [np.zeros(hub.size, dtype=np.int64), rng.integers(1, n, 300000), np.full(3000, 7, dtype=np.int64)]
+    dst = [hub, rng.integers(1, n, 300000), rng.integers(1, n, 3000)]
+    s, d = np.concatenate(src), np.concatenate(dst)
+    keep = s != d
+    s, d = s[keep], d[keep]
+    return csr_from_edges(np.concatenate([s, d]), np.concatenate([d, s]), n)
+
+
+@pytest.mark.parametrize("p,q", [(0.5, 2), (4, 0.25)])
+def test_parked_walks_and_chain_kernel_equal_in_place_chains_and_oracle(p, q, monkeypatch):
+    """Steps that need the float32 chain: (a) the walk is parked, the chains of the whole queue run in one launch
+    (lanes_chain_kernel) and the next round resumes the walks -- forced here for every round (PECANPY_AMD_CHAIN_TAIL=0);
+    (b) the chain runs in place, inside the lane kernel (PECANPY_AMD_NO_CHAIN_QUEUE=1); (c) the default mix.  All three
+    give the oracle's walks and count the same chain steps."""
+    rng = np.random.default_rng(13)
+    indptr, indices, data = _hub_graph(rng)
+    n = indptr.size - 1
+    starts = np.concatenate([np.zeros(200, dtype=np.uint32), rng.integers(0, n, 6000).astype(np.uint32)])
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 24, 4, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    runs = {}
+    for name, env in (("queue", {"PECANPY_AMD_CHAIN_TAIL": "0"}), ("in_place", {"PECANPY_AMD_NO_CHAIN_QUEUE": "1"}), ("default", {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = eng.simulate("SparseOTF", p, q, False, starts, 24, seed=4)
+        for k in env:
+            monkeypatch.delenv(k)
+        st = dict(eng.last_stats)
+        assert st["lane_kernel"] == 1
+        assert np.array_equal(got, want), name
+        assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
+        runs[name] = st
+    assert runs["queue"]["lane_rounds"] > 1 and runs["in_place"]["lane_rounds"] == 1
+    assert runs["queue"]["wave_chain_steps"] == runs["in_place"]["wave_chain_steps"] > 0
+    assert runs["queue"]["ambiguous_steps"] == runs["in_place"]["ambiguous_steps"] > runs["queue"]["wave_chain_steps"]
+
+
+def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
+    """Directed graph with sinks: the repair passes run the lane kernel on job lists; with every chain step parked the
+    rounds resume walks of a job list."""
+    rng = np.random.default_rng(8)
+    n = 3000
+    src = rng.integers(0, n, 24000)
+    dst = rng.integers(0, n, 24000)
+    keep = (src != dst) & (src % 50 != 0)
+    indptr, indices, data = csr_from_edges(src[keep], dst[keep], n)
+    starts = orc.shuffled_starts(n, 2, 3)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    ref = eng.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
+    st0 = dict(eng.last_stats)
+    monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "0")
+    got = eng.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
+    monkeypatch.delenv("PECANPY_AMD_CHAIN_TAIL")
+    assert np.array_equal(got, ref)
+    assert eng.last_stats["total_steps"] == st0["total_steps"] and eng.last_stats["repair_rounds"] == st0["repair_rounds"]
+    if st0["stream_addressing"] == 0:
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3)
+        assert np.array_equal(got, want)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r02_traffic.json, the file
 bench.py reads the HBM-side traffic and the issue counters of a workload from.
-usage: pmc_to_json.py <dir with pass*.txt> <workload key> <kernel substring> <steps per launch> [note]"""
+usage: pmc_to_json.py <dir with pass*.txt> <workload key> <kernel substring[+substring...]> <steps per pass> [note]"""
 import glob
 import json
 import os
@@ -12,20 +12,24 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main(d, key, kernel, steps, note=""):
     steps = float(steps)
-    c = {}
+    kernels = kernel.split("+")     # several kernels that make up one pass (e.g. every round of the lane kernel + the
+    c = {}                          # chain kernel): counters and TOTAL times are summed over them
     ms = []
     for f in sorted(glob.glob(os.path.join(d, "pass*.txt"))):
+        tot = 0.0
         for line in open(f):
             parts = [p.strip() for p in line.split("|")]
-            if len(parts) == 4 and kernel in parts[0]:
+            if len(parts) == 4 and any(k in parts[0] for k in kernels):
                 try:
                     if parts[1].isdigit():
-                        ms.append(float(parts[3]))
+                        tot += float(parts[2])      # calls | total_ms | avg_ms
                     else:
-                        c[parts[1]] = float(parts[2])
+                        c[parts[1]] = c.get(parts[1], 0.0) + float(parts[2])
                 except ValueError:
                     pass
-    k_ms = sum(ms) / len(ms)
+        if tot:
+            ms.append(tot)
+    k_ms = sum(ms) / len(ms)        # per pass (bench.py --steps 1 --warmup 0)
     cyc = k_ms * 1e-3 * 2.4e9
     rec = {
         "kernel": kernel,
