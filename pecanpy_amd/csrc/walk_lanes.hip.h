@@ -19,11 +19,18 @@
 // runs of "out" neighbours whose mass is a closed form), no membership work at all.  64 walks advance per
 // wavefront instruction; a step costs one 32-byte record, ~log2(n_common) list probes, one draw and one store.
 //
-// Steps the exact decision cannot settle (a partial sum of the exact CDF lies within the float32 drift bound of
-// the target, ~8 % of the steps) are resolved by the whole wave for one lane at a time with the bit-exact float32
-// chain of walk_sparse.hip.h (seq_head + unit_chain) over an LDS mask scattered from the same list.  The rare
-// rest -- the mirrored overflow read (choice == degree, App. D quirk 1), rows whose total is not exact in
-// float32 -- is not handled here: the job is appended to a redo list and walked again by walk_kernel.
+// Steps the a-priori bound cannot settle (a partial sum of the exact CDF lies within the float32 drift bound of
+// the target, 12 % of the steps at RMAT-22) go through two more routines of seqscan.h, both evaluated by the lane:
+//   lane_tight : the chain's SYSTEMATIC drift bounded from the class counts the decision already has -- arithmetic
+//                only, settles nine in ten of them on the spot;
+//   lane_chain : the float32 chain itself.  Not run in place: a chain with a handful of the wavefront's lanes enabled
+//                costs the others ~300 us.  The walk is PARKED (SuspRec into a queue), the lane takes another walk,
+//                lanes_chain_kernel settles a whole queue at full width and the next ROUND of this kernel resumes the
+//                walks (host loop: pecanpy_amd.hip, launch_lane_walks).  The last, small round runs them in place.
+// The rare rest -- the mirrored overflow read (choice == degree, App. D quirk 1), rows whose total is not exact in
+// float32 -- is not handled here: the job is appended to a redo list and walk_kernel takes the walk over at that step.
+// Registers decide everything here: at 6 waves/SIMD (80 VGPRs) the compiler spilled 160 registers into the hot loop
+// and the kernel ran at half its speed; 96 VGPRs / 5 waves (queueing form), 128 / 4 (in-place form) hold it all.
 #pragma once
 #include "walk_sparse.hip.h"
 
@@ -69,8 +76,8 @@ struct LanesArgs {
     uint32_t *out;                            // [n_jobs, L + 2], zero-filled by the caller before the first launch
     unsigned long long *job_counter;
     unsigned long long *stats;                // [0] steps [1] overflow reads [2] clamped reads [3] dead-end walks
-                                              // [6] list entries read [7] ambiguous steps (float chain)
-                                              // [9] ambiguous steps left to the wave-cooperative chain
+                                              // [6] list entries read [7] steps the a-priori bound left open
+                                              // [9] of those, steps that needed the float32 chain
     uint32_t *redo_list;                      // jobs handed to walk_kernel
     unsigned long long *redo_count;
     float w_out, w_prev;                      // fl32(1/q), fl32(1/p): powers of two (host checked)
@@ -291,11 +298,9 @@ walk_lanes_kernel(LanesArgs a) {
         LPROF_C(8, 1);
 
         // ---- one step for every runnable lane ------------------------------------------------------------------
-        // A lane whose step the exact decision cannot settle WAITS (keeps its draw and thresholds) while the other
-        // lanes go on stepping.  Waiting lanes are served in two stages, each once enough of them have gathered (or
-        // nothing else can run), so that the long divergent code runs with several lanes enabled:
-        //   1. lane_refine: the chain's drift computed from per-binade class counts (settles ~97 %),
-        //   2. lane_chain : the float32 chain itself, for what the refinement leaves open.
+        // decision -> interval decision -> (still open:) the walk is parked for lanes_chain_kernel, or -- in-place form --
+        // the lane WAITS (keeps its draw and prefix bound) while the others go on stepping, and the waiting lanes run
+        // their chains together once a few have gathered or nothing else can run (optionally lane_refine first).
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
