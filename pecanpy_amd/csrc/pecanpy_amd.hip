@@ -229,6 +229,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     g->redo.release();
+    g->susp[0].release();
+    g->susp[1].release();
     g->bsp_job.release(); g->bsp_ecur.release(); g->bsp_len.release(); g->bsp_outT.release(); g->bsp_chainq.release();
     g->bsp_rngT.release(); g->bsp_amb.release();
     g->stream_off.release();

@@ -299,3 +299,23 @@ def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
     if st0["stream_addressing"] == 0:
         want = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3)
         assert np.array_equal(got, want)
+
+
+def test_graph_handle_releases_its_device_memory(monkeypatch):
+    """pw_graph_destroy frees everything a handle allocated on the way -- index, stream, redo list, the queues of parked
+    walks: creating, walking and closing handles in a loop must not eat device memory."""
+    import torch
+
+    indptr, indices, data = rmat_csr(15, seed=2)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 4)
+    monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "0")       # the queues are allocated
+    torch.cuda.synchronize()
+    free = []
+    for _ in range(4):
+        eng = WalkEngine.from_csr(indptr, indices, None)
+        eng.simulate("SparseOTF", 0.5, 2, False, starts, 40, seed=1)
+        assert eng.last_stats["lane_kernel"] == 1 and eng.last_stats["lane_rounds"] > 1
+        eng.close()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert free[0] - free[-1] < (32 << 20), free
