@@ -76,6 +76,12 @@ typedef struct {
     uint64_t wave_chain_steps;  /* of the ambiguous steps, those that needed the float32 chain itself */
     double param_index_ms;      /* device time spent in THIS call building an index that depends on (p, q, extend):
                                    per-edge normalisers of weighted graphs, hint tables; 0 when cached in the handle */
+    /* PECANPY_AMD_VERIFY_TIGHT=1 (test mode of the lane kernel): every step the interval decision settled is decided
+     * again by the sequential float32 chain on the device */
+    uint64_t verify_checked;    /* steps re-decided */
+    uint64_t verify_mismatch;   /* of those, steps where the chain picked a different neighbour (must be 0) */
+    uint64_t verify_dropped;    /* steps not recorded because the record buffer was full */
+    uint64_t verify_ties;       /* steps the chain declined (rounding-tie budget): not compared */
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */
@@ -218,7 +224,7 @@ int pw_edgelist_export(const pw_edgelist *e, uint32_t *indptr, uint32_t *indices
                        double *data64, uint64_t *id_offsets, char *id_chars);
 void pw_edgelist_destroy(pw_edgelist *e);
 
-/* ---- self test hooks (host only, no GPU needed) ------------------------------------------ */
+/* ---- self test hooks (host only, no GPU needed -- except pw_selftest_lane with on_device) -- */
 /* Runs the binade-scan emulation of csrc/seqscan.h on a host array: returns through *index the
  * position np.searchsorted(np.cumsum(x), r) would return under sequential float32 semantics
  * (n if never reached) and through *sum the sequential float32 sum.  chunk = elements per pass. */
@@ -235,25 +241,22 @@ int pw_selftest_seqscan_f64(const double *x, uint32_t n, double r, int use_targe
  * 0xffffffff when a partial sum lies inside the drift bound (the kernel then runs the float chain). */
 int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                uint32_t n_r, uint32_t *chain, uint32_t *exact);
-/* The same decision as one thread of the lane kernel takes it (csrc/seqscan.h: lane_decide), from the ascending
- * positions of the common neighbours: lane[i] = decided index, 0xfffffffd when the float chain has to decide (then
- * kmax[i] = number of leading positions the chain may need: chain[i] < kmax[i] or chain[i] == n), 0xfffffffc when
- * the row is outside the exact range.  chain_lane (may be NULL) = the float32 chain as ONE thread evaluates it
- * (csrc/seqscan.h: lane_chain) over the first kmax[i] positions (the whole row when lane[i] is decided):
- * position, 0xfffffffb when that prefix never reaches r[i], 0xfffffffa on a rounding tie the thread cannot afford
- * (the walk is then redone by the wavefront kernel).  use_hints != 0: both searches start from the per-list hint
- * table (csrc/seqscan.h: build_list_hints) -- same results, fewer list reads; probes (may be NULL) = list / hint
- * entries read per target.  refined (may be NULL) = lane[i] after the refined decision of ambiguous targets
- * (csrc/seqscan.h: lane_refine, the chain's drift computed from per-binade class counts): decided index or still
- * 0xfffffffd. */
-int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
-                            uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
-                            int use_hints, uint32_t *probes, uint32_t *refined);
-/* The list-free interval decision of ambiguous targets (csrc/seqscan.h: lane_tight -- the chain's systematic drift
- * bounded from the class counts lane_decide already knows): chain / lane as above, tight[i] = lane[i] when that is
- * decided, else lane_tight's answer (an index, or still 0xfffffffd). */
-int pw_selftest_lane_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
-                           uint32_t *chain, uint32_t *lane, uint32_t *tight);
+/* The same decision as one thread of the lane kernel takes it, from the ascending positions of the common neighbours
+ * (csrc/seqscan.h: lane_decide -> lane_tight -> lane_chain), beside the sequential float32 chain:
+ *   chain[i]      = np.searchsorted(np.cumsum(float32 probs), r[i]) (n if never reached),
+ *   lane[i]       = lane_decide: decided index, 0xfffffffd when a partial sum of the exact CDF lies inside the a-priori
+ *                   drift bound (then kmax[i] = number of leading positions the chain may need: chain[i] < kmax[i] or
+ *                   chain[i] == n), 0xfffffffc when the row is outside the exact range,
+ *   tight[i]      = lane[i] when that is decided, else the list-free interval decision (lane_tight: the chain's
+ *                   systematic drift bounded from the class counts lane_decide already knows): index or 0xfffffffd,
+ *   chain_lane[i] = (may be NULL) the float32 chain as ONE thread evaluates it (lane_chain) over the first kmax[i]
+ *                   positions (the whole row when lane[i] is decided): position, 0xfffffffb when that prefix never
+ *                   reaches r[i], 0xfffffffa on a rounding tie the thread cannot afford.
+ * on_device != 0: every target is decided by one thread of a kernel on `device` (the sequential chain included), i.e.
+ * by the code the walk kernels run -- device code generation, v_rcp_f32 -- instead of the host build of the same
+ * routines.  Rows of more than 65536 entries use uint32 positions, shorter ones uint16 (the lane index's formats). */
+int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                     uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *tight, uint32_t *chain_lane);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

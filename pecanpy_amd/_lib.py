@@ -31,6 +31,10 @@ class PwStats(C.Structure):
         ("lane_kernel_ms", C.c_double),
         ("wave_chain_steps", C.c_uint64),
         ("param_index_ms", C.c_double),
+        ("verify_checked", C.c_uint64),
+        ("verify_mismatch", C.c_uint64),
+        ("verify_dropped", C.c_uint64),
+        ("verify_ties", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -84,10 +88,8 @@ SYMBOLS = {
     "pw_edgelist_destroy": (None, [C.c_void_p]),
     "pw_selftest_exact_decision": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
                                              C.c_void_p, C.c_void_p]),
-    "pw_selftest_lane_decide": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "pw_selftest_lane_tight": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
-                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pw_selftest_lane": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pw_selftest_exact_decision_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p,
                                                  C.c_uint32, C.c_void_p, C.c_void_p]),
     "pw_selftest_seqscan_f32": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32,

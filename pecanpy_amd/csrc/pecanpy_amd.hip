@@ -27,7 +27,6 @@
 #include "walk_seq.hip.h"
 #include "walk_sparse.hip.h"
 #include "walk_lanes.hip.h"
-#include "walk_bsp.hip.h"
 #include "sgns.hip.h"
 
 #define PW_EXPORT extern "C" __attribute__((visibility("default")))
@@ -95,10 +94,6 @@ struct pw_graph {
     uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
     pw::ERec *d_erec = nullptr;                         // lane kernel (walk_lanes.hip.h): 32-byte record per CSR entry
     uint32_t *d_clist = nullptr;                        // lane kernel: per-edge positions of the common neighbours
-    uint32_t *d_hint = nullptr;                         // lane kernel: hint words of the guided list search
-    int hint_in = -1, hint_out = -1;                    // mass units the hints were built for (-1: none yet)
-    bool hint_failed = false;                           // no memory for the hints: plain bisection
-    double hint_build_ms = 0;
     float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
     double tot_p = 0, tot_q = 0;                        // ... built for these parameters
     int tot_extend = -1;                                // -1: none yet
@@ -126,10 +121,9 @@ struct pw_graph {
     struct MtCache { bool valid = false; uint32_t seed = 0, n_gen = 0; uint64_t first_block = 0; int per_gen_log = 0; uint64_t stamp = 0;
                      DevBuf<uint32_t> states; } mt_cache[8];
     uint64_t mt_stamp = 0;
-    // step-synchronous lane path (walk_bsp.hip.h): walk slots, state, step-major draws / output, queues
-    DevBuf<uint32_t> bsp_job, bsp_ecur, bsp_len, bsp_outT, bsp_chainq;
-    DevBuf<double> bsp_rngT;
-    DevBuf<pw::AmbRec> bsp_amb;
+    // verification mode of the lane kernel (PECANPY_AMD_VERIFY_TIGHT=1): steps the interval decision settled
+    DevBuf<pw::VerRec> ver, ver_bad;
+    uint64_t ver_checked = 0, ver_mismatch = 0, ver_dropped = 0, ver_ties = 0;   // ... of the current call
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
     bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
@@ -225,14 +219,13 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_vrec) (void)hipFree(g->d_vrec);
     if (g->d_erec) (void)hipFree(g->d_erec);
     if (g->d_clist) (void)hipFree(g->d_clist);
-    if (g->d_hint) (void)hipFree(g->d_hint);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     g->redo.release();
     g->susp[0].release();
     g->susp[1].release();
-    g->bsp_job.release(); g->bsp_ecur.release(); g->bsp_len.release(); g->bsp_outT.release(); g->bsp_chainq.release();
-    g->bsp_rngT.release(); g->bsp_amb.release();
+    g->ver.release();
+    g->ver_bad.release();
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -310,13 +303,14 @@ static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
     }
     cleanup();
     if (e != hipSuccess) {
+        // no lane index: the wave-per-walk kernel serves every call (an allocation failure is not an error)
+        const bool oom = e == hipErrorOutOfMemory;
         if (g->d_clist) (void)hipFree(g->d_clist);
-    if (g->d_hint) (void)hipFree(g->d_hint);
-    if (g->d_tot_e) (void)hipFree(g->d_tot_e);
-    if (g->d_tot_v) (void)hipFree(g->d_tot_v);
         if (g->d_erec) (void)hipFree(g->d_erec);
         g->d_clist = nullptr;
         g->d_erec = nullptr;
+        (void)hipGetLastError();
+        if (oom) return 0;
         return fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e));
     }
     g->n_clist = total;
@@ -327,6 +321,7 @@ static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
 PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                             uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out) {
     if (!indptr || !out || (nnz && !indices)) return fail(PW_ERR_INVALID, "null pointer");
+    if (indptr[0] != 0) return fail(PW_ERR_INVALID, "indptr[0] != 0");
     if (indptr[n_nodes] != nnz) return fail(PW_ERR_INVALID, "indptr[n_nodes] != nnz");
     pw_graph *g = new pw_graph();
     int rc = graph_common_init(g, device);
@@ -810,6 +805,9 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     if (g->kind != 0 || g->unit || !g->nnz || g->tot_failed || getenv("PECANPY_AMD_NO_TOT")) return 0;
     const bool fresh = g->tot_extend == (extend ? 1 : 0) && g->tot_p == wa.p && g->tot_q == wa.q &&
                        (!extend || g->tot_thr_version == g->thr_version);
+    // The table costs one row scan per CSR entry and saves one per sampled step: a call that samples fewer steps than
+    // the graph has entries is faster through the two-pass step (an existing table is used whatever the call's size)
+    if (!fresh && wa.n_jobs * (uint64_t)wa.L < (uint64_t)g->nnz && !getenv("PECANPY_AMD_FORCE_TOT")) return 0;
     if (!fresh) {
         if (!g->d_tot_e) {
             hipError_t e = hipMalloc((void **)&g->d_tot_e, sizeof(float) * (size_t)g->nnz);
@@ -821,7 +819,6 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
         hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, d_edge_row);
         pw::WalkArgs ba = wa;
         ba.job_counter = g->counters.p + 11;
-        ba.L = getenv("PW_DEBUG_TOT_MODE") ? (uint32_t)atoi(getenv("PW_DEBUG_TOT_MODE")) : 0u;
         hipError_t e = hipMemsetAsync(g->counters.p + 11, 0, sizeof(unsigned long long), g->stream);
         if (e == hipSuccess) e = hipEventRecord(g->ev[4], g->stream);
         if (e == hipSuccess) {
@@ -831,16 +828,6 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(g->ev[5], g->stream);
-        if (e == hipSuccess && getenv("PW_DEBUG_TOT")) {   // watchdog: report progress instead of hanging
-            for (int w = 0; w < 300 && hipEventQuery(g->ev[5]) == hipErrorNotReady; w++) usleep(10000);
-            if (hipEventQuery(g->ev[5]) == hipErrorNotReady) {
-                unsigned long long c = 0;
-                (void)hipMemcpy(&c, g->counters.p + 11, sizeof(c), hipMemcpyDeviceToHost);
-                fprintf(stderr, "[tot] build kernel stuck: item counter %llu of %llu items (+ %d waves)\n", c,
-                        (unsigned long long)g->nnz + g->n_nodes, g->n_cu * 8 * 4);
-                _exit(3);
-            }
-        }
         if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         (void)hipFree(d_edge_row);
         if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("normaliser table: ") + hipGetErrorString(e));
@@ -852,12 +839,6 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
         g->tot_p = wa.p;
         g->tot_q = wa.q;
         g->tot_thr_version = g->thr_version;
-        if (getenv("PW_DEBUG_TOT")) {
-            float he[8] = {0}, hv[8] = {0};
-            (void)hipMemcpy(he, g->d_tot_e, sizeof(float) * (g->nnz < 8 ? g->nnz : 8), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hv, g->d_tot_v, sizeof(float) * (g->n_nodes < 8 ? g->n_nodes : 8), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[tot] built in %.3f ms: tot_e %g %g %g %g %g %g  tot_v %g %g %g %g\n", ms, he[0], he[1], he[2], he[3], he[4], he[5], hv[0], hv[1], hv[2], hv[3]);
-        }
     }
     wa.tot_e = g->d_tot_e;
     wa.tot_v = g->d_tot_v;
@@ -892,39 +873,7 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
-    // hint table of the guided list search, for this call's ratio of the "in" and "out" weights
-    int ea = 0;
-    (void)std::frexp(wa.w_out, &ea);   // w_out = 2^(ea - 1)
-    const int hs_out = ea - 1 > 0 ? ea - 1 : 0, hs_in = ea - 1 < 0 ? 1 - ea : 0;
-    // (off unless PECANPY_AMD_HINTS=1: the guided search removes a third of the list reads but the kernel is bound
-    //  by the instructions of the float chains, not by those reads -- DESIGN.md section 9)
-    const bool want_hints = getenv("PECANPY_AMD_HINTS") != nullptr;
-    if (want_hints && !g->hint_failed && g->n_clist && (g->hint_in != hs_in || g->hint_out != hs_out)) {
-        if (!g->d_hint && hipMalloc((void **)&g->d_hint, sizeof(uint32_t) * (size_t)g->n_clist) != hipSuccess) {
-            g->d_hint = nullptr;
-            g->hint_failed = true;
-            (void)hipGetLastError();
-        }
-        if (g->d_hint) {
-            HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-            hipLaunchKernelGGL(pw::hint_build_kernel, dim3((unsigned)(((uint64_t)g->nnz + 255) / 256)), dim3(256), 0, g->stream,
-                               g->d_erec, g->d_clist, g->nnz, (uint32_t)hs_in, (uint32_t)hs_out, g->d_hint);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(g->ev[5], g->stream));
-            HIP_TRY(hipStreamSynchronize(g->stream));
-            float hms = 0;
-            HIP_TRY(hipEventElapsedTime(&hms, g->ev[4], g->ev[5]));
-            g->hint_build_ms = hms;
-            g->param_ms_call += hms;
-            g->hint_in = hs_in;
-            g->hint_out = hs_out;
-        }
-    }
-    const bool use_hints = want_hints && g->d_hint && g->hint_in == hs_in && g->hint_out == hs_out;
     pw::LanesArgs la;
-    la.hint = use_hints ? g->d_hint : nullptr;
-    la.hs_in = (uint32_t)hs_in;
-    la.hs_out = (uint32_t)hs_out;
     la.erec = g->d_erec;
     la.clist = g->d_clist;
     la.vrec = g->d_vrec;
@@ -945,10 +894,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     la.w_out = wa.w_out;
     la.w_prev = wa.w_prev;
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     int occ_in = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_in < 1) occ_in = 1;
     const uint64_t lanes_resident = (uint64_t)g->n_cu * (uint64_t)occ * pw::WAVES_PER_BLOCK * pw::WAVE;
     // Steps that need the float32 chain (~1 % on RMAT-22 after lane_tight) are not run in place -- a chain with a few
@@ -958,12 +907,27 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const char *tail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
     uint64_t tail = tail_env ? (uint64_t)strtoull(tail_env, nullptr, 10) : lanes_resident / 2;
     bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
-    const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;   // + the void slots of every wavefront's last reservation
+    // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
+    const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;
     if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
         (void)hipGetLastError();
         use_queue = false;              // no room for the queues: chains run in place
     }
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+    // verification mode: every step the interval decision settles is recorded and decided again by the float chain
+    const char *ver_env = getenv("PECANPY_AMD_VERIFY_TIGHT");
+    const bool verify = ver_env != nullptr;
+    la.ver_poison = (verify && strcmp(ver_env, "poison") == 0) ? 1u : 0u;
+    la.ver = nullptr;
+    la.ver_count = g->counters.p + 40;
+    la.ver_cap = 0;
+    if (verify) {
+        const char *cap_env = getenv("PECANPY_AMD_VERIFY_CAP");
+        const uint64_t cap = cap_env ? (uint64_t)strtoull(cap_env, nullptr, 10) : n_work * (uint64_t)wa.L / 4 + 4096;
+        if (g->ver.ensure(cap) || g->ver_bad.ensure(16)) return PW_ERR_NOMEM;
+        la.ver = g->ver.p;
+        la.ver_cap = cap;
+    }
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
@@ -987,11 +951,40 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipMemsetAsync(g->counters.p + 32, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-        if (queue_out)
-            hipLaunchKernelGGL(pw::walk_lanes_kernel<false>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
-        else
-            hipLaunchKernelGGL(pw::walk_lanes_kernel<true>, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+        if (verify) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
+        const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
+        if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false>), lgrid, lblock, 0, g->stream, la);
+        else if (verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, true>), lgrid, lblock, 0, g->stream, la);
+        else hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false>), lgrid, lblock, 0, g->stream, la);
         HIP_TRY(hipGetLastError());
+        if (verify) {   // the chain decides this round's recorded steps again
+            unsigned long long n_rec = 0;
+            HIP_TRY(hipMemcpyAsync(&n_rec, g->counters.p + 40, sizeof(n_rec), hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            const unsigned long long n_chk = n_rec < la.ver_cap ? n_rec : la.ver_cap;
+            g->ver_dropped += n_rec - n_chk;
+            if (n_chk) {
+                HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
+                hipLaunchKernelGGL(pw::lanes_verify_kernel, dim3((unsigned)((n_chk + 255) / 256)), dim3(256), 0, g->stream, g->ver.p,
+                                   (uint64_t)n_chk, g->d_clist, wa.w_prev, g->counters.p + 40, g->ver_bad.p, 16u);
+                HIP_TRY(hipGetLastError());
+                unsigned long long vc[4] = {0, 0, 0, 0};
+                HIP_TRY(hipMemcpyAsync(vc, g->counters.p + 40, sizeof(vc), hipMemcpyDeviceToHost, g->stream));
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                g->ver_checked += vc[0];
+                g->ver_mismatch += vc[1];
+                g->ver_ties += vc[2];
+                if (vc[1]) {
+                    pw::VerRec bad[16];
+                    const unsigned nb = vc[3] < 16 ? (unsigned)vc[3] : 16u;
+                    HIP_TRY(hipMemcpy(bad, g->ver_bad.p, sizeof(pw::VerRec) * nb, hipMemcpyDeviceToHost));
+                    for (unsigned i = 0; i < nb; i++)
+                        fprintf(stderr, "[verify] MISMATCH d=%u n_in=%u pp=%u kmax=%u tot=%.9g wo=%g r=%.17g: interval decision %u, float chain %u\n",
+                                bad[i].d, bad[i].n_in, bad[i].pp, bad[i].kmax, (double)bad[i].tot, (double)bad[i].wo, bad[i].r, bad[i].choice, bad[i].pad);
+                }
+            }
+        }
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         if (parked) {   // settle the queue just filled
@@ -1030,80 +1023,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     return 0;
 }
 
-// Step-synchronous lane path (walk_bsp.hip.h): whole job arrays of the lane kernel's regime.  counters: [12] walk
-// slots [13] ambiguous queue [14] chain queue; the redo list / count are shared with the lane kernel.
-static int launch_bsp_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
-    const uint64_t n_jobs = wa.n_jobs;
-    const uint32_t L = wa.L;
-    if (g->redo.ensure(n_jobs) || g->bsp_job.ensure(n_jobs) || g->bsp_ecur.ensure(n_jobs) || g->bsp_len.ensure(n_jobs)) return PW_ERR_NOMEM;
-    pw::BspArgs a;
-    memset(&a, 0, sizeof(a));
-    a.erec = g->d_erec;
-    a.clist = g->d_clist;
-    a.vrec = g->d_vrec;
-    a.starts = wa.starts;
-    a.stream_off = wa.stream_off;
-    a.rng = wa.rng;
-    a.rng_base = wa.rng_base;
-    a.out = wa.out;
-    a.n_jobs = n_jobs;
-    a.L = L;
-    a.w_out = wa.w_out;
-    a.w_prev = wa.w_prev;
-    a.act_job = g->bsp_job.p;
-    a.n_act = g->counters.p + 12;
-    a.e_cur = g->bsp_ecur.p;
-    a.len = g->bsp_len.p;
-    a.amb_count = g->counters.p + 13;
-    a.chain_count = g->counters.p + 14;
-    a.redo_list = g->redo.p;
-    a.redo_count = g->counters.p + 6;
-    a.stats = g->counters.p + 1;
-    HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
-    HIP_TRY(hipMemsetAsync(g->counters.p + 12, 0, 3 * sizeof(unsigned long long), g->stream));
-    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-    hipLaunchKernelGGL(pw::bsp_compact_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, g->stream, a);
-    HIP_TRY(hipGetLastError());
-    unsigned long long n_act64 = 0;
-    HIP_TRY(hipMemcpyAsync(&n_act64, g->counters.p + 12, sizeof(n_act64), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    const uint32_t n_act = (uint32_t)n_act64;
-    *n_redo = 0;
-    if (n_act) {
-        if (g->bsp_rngT.ensure((size_t)n_act * L) || g->bsp_outT.ensure((size_t)n_act * L) || g->bsp_amb.ensure(n_act) ||
-            g->bsp_chainq.ensure(n_act))
-            return PW_ERR_NOMEM;
-        a.rngT = g->bsp_rngT.p;
-        a.outT = g->bsp_outT.p;
-        a.amb = g->bsp_amb.p;
-        a.chainq = g->bsp_chainq.p;
-        const unsigned gw = (n_act + 255) / 256, gq = (unsigned)(g->n_cu * 8);
-        hipLaunchKernelGGL(pw::bsp_rng_transpose_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act);
-        for (uint32_t j = 1; j <= L; j++) {
-            HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, 2 * sizeof(unsigned long long), g->stream));
-            hipLaunchKernelGGL(pw::bsp_step_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act, j);
-            hipLaunchKernelGGL(pw::bsp_refine_kernel, dim3(gq), dim3(256), 0, g->stream, a);
-            hipLaunchKernelGGL(pw::bsp_chain_kernel, dim3(gq), dim3(256), 0, g->stream, a);
-        }
-        hipLaunchKernelGGL(pw::bsp_final_kernel, dim3(gw), dim3(256), 0, g->stream, a, n_act);
-        hipLaunchKernelGGL(pw::bsp_out_transpose_kernel, dim3((n_act + 63) / 64), dim3(256), (size_t)64 * (L + 1) * sizeof(uint32_t),
-                           g->stream, a, n_act);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
-    unsigned long long nr = 0;
-    HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));
-    *n_redo = nr;
-    return 0;
-}
-
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    // whole job arrays go step-synchronously (walk_bsp.hip.h); repair passes over job lists keep the persistent kernel
-    const bool bsp = !wa.job_list && getenv("PECANPY_AMD_BSP") && (uint64_t)wa.L * 64 * sizeof(uint32_t) < 60000;
-    int rc = bsp ? launch_bsp_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
+    int rc = launch_lane_walks(g, wa, &n_redo);
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range) go to walk_kernel, which resumes
     // them at that step.  (Handing them BACK once they are on a CSR entry again was tried: such walks overflow again
     // and again, and the extra rounds on a nearly empty GPU cost more than walk_kernel's whole-row chains -- 198 vs 189 ms.)
@@ -1112,7 +1035,7 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *re
     pw::WalkArgs wr = wa;
     wr.job_list = g->redo.p;
     wr.n_list = n_redo;
-    wr.resume = bsp ? 0u : 1u;   // from the step the lane kernel stopped at (its rows hold the walks so far)
+    wr.resume = 1u;   // from the step the lane kernel stopped at (its rows hold the walks so far)
     return launch_wave_walks(g, wr, extend);
 }
 
@@ -1249,6 +1172,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     const bool lanes = lanes_eligible(g, wa);
     g->lane_ms = 0;
     g->lane_rounds = 0;
+    g->ver_checked = g->ver_mismatch = g->ver_dropped = g->ver_ties = 0;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
     // the lane kernel only writes the cells a walk fills: the matrix starts zeroed (pecanpy.py:182-187)
     if (lanes) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
@@ -1340,6 +1264,10 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.param_index_ms = g->param_ms_call;
     st.lane_kernel_ms = g->lane_ms;
     st.lane_rounds = g->lane_rounds;
+    st.verify_checked = g->ver_checked;
+    st.verify_mismatch = g->ver_mismatch;
+    st.verify_dropped = g->ver_dropped;
+    st.verify_ties = g->ver_ties;
     if (stats) *stats = st;
     return PW_OK;
 }
@@ -1669,113 +1597,154 @@ PW_EXPORT int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, dou
     return PW_OK;
 }
 
-// ---- host self test of the lane kernel's per-thread decision (seqscan.h: lane_decide) ----------------------------
-PW_EXPORT int pw_selftest_lane_decide(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
-                                      uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *chain_lane,
-                                      int use_hints, uint32_t *probes, uint32_t *refined) {
-    if (!cls || !r || !chain || !lane || !kmax || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+// ---- self tests of the lane kernel's per-thread routines (seqscan.h: lane_decide, lane_tight, lane_chain) ----------
+// One row given by its classes (0 out, 1 common, 2 prev), many targets.  The same routine runs on the host and -- in
+// lane_selftest_kernel, one thread per target -- on the DEVICE, where the compiler's code generation and the hardware's
+// arithmetic (v_rcp_f32 in lane_tight, -ffp-contract=off adds) are what the walk kernels actually execute.
+namespace {
+
+struct LaneRow {
+    std::vector<uint16_t> cl16;
+    std::vector<uint32_t> cl32;
+    uint32_t n_cl = 0, pp = 0xffffffffu, wide = 0;
+    float tot = 0, x_in = 0, x_out = 0, x_prev = 0;
+    pw::ListView view() const { return pw::ListView{wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide}; }
+};
+
+int lane_row_setup(const uint8_t *cls, uint32_t n, float w_out, float w_prev, LaneRow &row) {
     auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
     if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
-    std::vector<uint32_t> cl;
-    uint32_t pp = 0xffffffffu, cnt[3] = {0, 0, 0};
+    uint32_t cnt[3] = {0, 0, 0};
+    row.wide = n > 65536u ? 1u : 0u;   // positions of rows up to 65536 entries are uint16 (walk_lanes.hip.h)
     for (uint32_t k = 0; k < n; k++) {
         if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
         cnt[cls[k]]++;
-        if (cls[k] == 1) cl.push_back(k);
-        if (cls[k] == 2) pp = k;
+        if (cls[k] == 1) { if (row.wide) row.cl32.push_back(k); else row.cl16.push_back((uint16_t)k); }
+        if (cls[k] == 2) row.pp = k;
     }
     if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
-    const double td = (double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev;
-    const float tot = (float)td;
-    const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
-    // hint table of this list, as the device builds it (units: the smaller of w_out and 1)
-    int ea = 0;
-    (void)std::frexp(w_out, &ea);   // w_out = 2^(ea - 1)
-    const uint32_t hs_out = ea - 1 > 0 ? (uint32_t)(ea - 1) : 0u, hs_in = ea - 1 < 0 ? (uint32_t)(1 - ea) : 0u;
-    const uint32_t n_cl = (uint32_t)cl.size();
-    std::vector<uint32_t> hints(n_cl ? n_cl : 1, 0u);
-    cl.resize((size_t)n_cl + 4, 0xffffffffu);   // the search window may read up to 3 entries past the list end
-    if (use_hints) pw::build_list_hints(cl.data(), n_cl, n, hs_in, hs_out, hints.data());
-    const uint32_t *hp = use_hints ? hints.data() : nullptr;
-    const uint32_t wd = pw::hint_bucket_width(n, n_cl, hs_in, hs_out);
-    for (uint32_t i = 0; i < n_r; i++) {
-        float c = 0.0f;
-        uint32_t kc = n;
-        for (uint32_t k = 0; k < n; k++) {   // the reference: sequential float32 cumsum + searchsorted
-            c = c + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
-            if ((double)c >= r[i]) { kc = k; break; }
-        }
-        chain[i] = kc;
-        pw::LaneStep ls{0.0f, 0u, 0u, 0u, 0u, 0u};
-        lane[i] = pw::lane_decide(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls, hp, hs_in, hs_out, wd);
-        if (probes) probes[i] = ls.probes;
-        kmax[i] = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : 0u;
-        if (lane[i] != pw::LANE_REDO && ls.tot != tot) return fail(PW_ERR_INVALID, "row total mismatch");
-        if (refined) {      // the refined decision of ambiguous steps (seqscan.h: lane_refine)
-            uint32_t rr = 0;
-            refined[i] = lane[i] == pw::LANE_AMBIGUOUS ? pw::lane_refine(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls, rr) : lane[i];
-        }
-        if (chain_lane) {   // the per-thread float chain: over the ambiguous prefix, or the whole row when decided
-            const uint32_t kend = lane[i] == pw::LANE_AMBIGUOUS ? ls.kmax : n;
-            uint32_t reads = 0;
-            uint32_t pf[5 * pw::LANE_PF];
-            chain_lane[i] = pw::lane_chain(kend, n_cl, pp, r[i], x_in, x_out, x_prev, cl.data(), reads, hp, hs_in, hs_out, wd,
-                                           use_hints ? pf : nullptr, 1u);
-            if (probes) probes[i] += reads;
-#if !defined(__HIP_DEVICE_COMPILE__)
-            if (getenv("PW_LANE_STATS")) {
-                fprintf(stderr, "chain n=%u kend=%u seq=%llu binades=%llu res=%u\n", n, kend, (unsigned long long)pw::g_lane_seq_elems,
-                        (unsigned long long)pw::g_lane_binades, chain_lane[i]);
-                pw::g_lane_seq_elems = 0;
-                pw::g_lane_binades = 0;
-            }
-#endif
-        }
-    }
-    return PW_OK;
+    row.n_cl = cnt[1];
+    row.cl16.resize(row.cl16.size() + 8, 0xffffu);       // a list window may read past the end of the list
+    row.cl32.resize(row.cl32.size() + 8, 0xffffffffu);
+    row.tot = (float)((double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev);
+    row.x_in = 1.0f / row.tot;
+    row.x_out = row.x_in * w_out;
+    row.x_prev = row.x_in * w_prev;
+    return 0;
 }
 
-// Host run of lane_decide + lane_tight (the list-free interval decision) beside the sequential float32 chain.
-PW_EXPORT int pw_selftest_lane_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
-                                     uint32_t *chain, uint32_t *lane, uint32_t *tight) {
-    if (!cls || !r || !chain || !lane || !tight || n == 0) return fail(PW_ERR_INVALID, "bad argument");
-    auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
-    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
-    std::vector<uint32_t> cl;
-    uint32_t pp = 0xffffffffu, cnt[3] = {0, 0, 0};
-    for (uint32_t k = 0; k < n; k++) {
-        if (cls[k] > 2) return fail(PW_ERR_INVALID, "class must be 0 (out), 1 (common) or 2 (prev)");
-        cnt[cls[k]]++;
-        if (cls[k] == 1) cl.push_back(k);
-        if (cls[k] == 2) pp = k;
-    }
-    if (cnt[2] > 1) return fail(PW_ERR_INVALID, "at most one prev");
-    const float tot = (float)((double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev);
+}  // namespace
+
+namespace pw {
+// lane_decide -> lane_tight -> lane_chain for one target; out = { lane, kmax, tight, chain_lane }
+PW_HD void lane_selftest_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint32_t pp, float w_out, float w_prev, double r,
+                             uint32_t *out) {
+    LaneStep ls{0.0f, 0u, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t lane = lane_decide(n, n_cl, pp, r, w_out, w_prev, cl, ls);
+    out[0] = lane;
+    out[1] = lane == LANE_AMBIGUOUS ? ls.kmax : 0u;
+    out[2] = lane == LANE_AMBIGUOUS ? lane_tight(n, pp, r, w_out, w_prev, ls) : lane;
+    // the per-thread float chain: over the ambiguous prefix, or the whole row when decided
+    if (lane == LANE_REDO) { out[3] = LANE_REDO; return; }
+    const uint32_t kend = lane == LANE_AMBIGUOUS ? ls.kmax : n;
+    const float x_in = 1.0f / ls.tot;
+    uint32_t reads = 0;
+    out[3] = lane_chain(kend, n_cl, pp, r, x_in, x_in * w_out, x_in * w_prev, cl, reads);
+}
+
+__global__ void __launch_bounds__(256)
+lane_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t n_cl, uint32_t pp, float w_out,
+                     float w_prev, const double *r, uint32_t n_r, uint32_t *chain, uint32_t *out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_r) return;
+    // the reference: sequential float32 cumsum + searchsorted (pecanpy.py:556-557), by this thread
+    uint32_t cnt_in = 0, cnt_out = 0, cnt_pv = 0;
+    for (uint32_t k = 0; k < n; k++) { const uint8_t c = cls[k]; cnt_in += c == 1; cnt_out += c == 0; cnt_pv += c == 2; }
+    const float tot = (float)((double)cnt_in + (double)cnt_out * (double)w_out + (double)cnt_pv * (double)w_prev);
     const float x_in = 1.0f / tot, x_out = x_in * w_out, x_prev = x_in * w_prev;
-    const uint32_t n_cl = (uint32_t)cl.size();
-    cl.resize((size_t)n_cl + 4, 0xffffffffu);
-    // the chain once: prefix sums, then one binary search per draw (the sums are non-decreasing)
-    std::vector<float> c(n);
-    float acc = 0.0f;
+    float c = 0.0f;
+    uint32_t kc = n;
     for (uint32_t k = 0; k < n; k++) {
-        acc = acc + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
-        c[k] = acc;
+        c = c + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
+        if ((double)c >= r[i]) { kc = k; break; }
     }
-    for (uint32_t i = 0; i < n_r; i++) {
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
-        chain[i] = lo;
-        pw::LaneStep ls{0.0f, 0u, 0u, 0u, 0u, 0u, 0u};
-        lane[i] = pw::lane_decide(n, n_cl, pp, r[i], w_out, w_prev, cl.data(), ls);
-        tight[i] = lane[i] == pw::LANE_AMBIGUOUS ? pw::lane_tight(n, pp, r[i], w_out, w_prev, ls) : lane[i];
-    }
+    chain[i] = kc;
+    uint32_t o[4];
+    lane_selftest_one(n, ListView{cl, wide}, n_cl, pp, w_out, w_prev, r[i], o);
+    out4[4 * i] = o[0]; out4[4 * i + 1] = o[1]; out4[4 * i + 2] = o[2]; out4[4 * i + 3] = o[3];
+}
+}  // namespace pw
+
+PW_EXPORT int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
+                               uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *tight,
+                               uint32_t *chain_lane) {
+    if (!cls || !r || !chain || !lane || !kmax || !tight || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    LaneRow row;
+    int rc = lane_row_setup(cls, n, w_out, w_prev, row);
+    if (rc) return rc;
+    if (!on_device) {
+        // the chain once: prefix sums, then one binary search per draw (the sums are non-decreasing)
+        std::vector<float> c(n);
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < n; k++) {
+            acc = acc + (cls[k] == 1 ? row.x_in : (cls[k] == 0 ? row.x_out : row.x_prev));
+            c[k] = acc;
+        }
+        for (uint32_t i = 0; i < n_r; i++) {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+            chain[i] = lo;
+            uint32_t o[4];
+            pw::lane_selftest_one(n, row.view(), row.n_cl, row.pp, w_out, w_prev, r[i], o);
+            lane[i] = o[0]; kmax[i] = o[1]; tight[i] = o[2];
+            if (chain_lane) chain_lane[i] = o[3];
+        }
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if (getenv("PW_TIGHT_STATS")) {
-        fprintf(stderr, "tight bail reasons:");
-        for (int k = 1; k < 24; k++) if (pw::g_tight_reason[k]) fprintf(stderr, " [%d]=%llu", k, (unsigned long long)pw::g_tight_reason[k]);
-        fprintf(stderr, "\n");
-    }
+        if (getenv("PW_TIGHT_STATS")) {
+            fprintf(stderr, "tight bail reasons:");
+            for (int k = 1; k < 24; k++) if (pw::g_tight_reason[k]) fprintf(stderr, " [%d]=%llu", k, (unsigned long long)pw::g_tight_reason[k]);
+            fprintf(stderr, "\n");
+        }
 #endif
+        return PW_OK;
+    }
+    int ndev = pw_device_count();
+    if (ndev <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(PW_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_cls = nullptr;
+    void *d_cl = nullptr;
+    double *d_r = nullptr;
+    uint32_t *d_chain = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_cls, d_cl, (void *)d_r, (void *)d_chain, (void *)d_out})
+            if (q) (void)hipFree(q);
+    };
+    const size_t cl_bytes = row.wide ? row.cl32.size() * sizeof(uint32_t) : row.cl16.size() * sizeof(uint16_t);
+    const void *cl_host = row.wide ? (const void *)row.cl32.data() : (const void *)row.cl16.data();
+    hipError_t e = hipMalloc((void **)&d_cls, n);
+    if (e == hipSuccess) e = hipMalloc(&d_cl, cl_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_r, sizeof(double) * (size_t)(n_r ? n_r : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_chain, sizeof(uint32_t) * (size_t)(n_r ? n_r : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(uint32_t) * 4 * (size_t)(n_r ? n_r : 1));
+    if (e == hipSuccess) e = hipMemcpy(d_cls, cls, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cl, cl_host, cl_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_r) e = hipMemcpy(d_r, r, sizeof(double) * (size_t)n_r, hipMemcpyHostToDevice);
+    std::vector<uint32_t> out4((size_t)4 * n_r);
+    if (e == hipSuccess && n_r) {
+        hipLaunchKernelGGL(pw::lane_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.n_cl, row.pp,
+                           w_out, w_prev, d_r, n_r, d_chain, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(chain, d_chain, sizeof(uint32_t) * (size_t)n_r, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out4.data(), d_out, sizeof(uint32_t) * 4 * (size_t)n_r, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("pw_selftest_lane: ") + hipGetErrorString(e));
+    for (uint32_t i = 0; i < n_r; i++) {
+        lane[i] = out4[4 * (size_t)i]; kmax[i] = out4[4 * (size_t)i + 1]; tight[i] = out4[4 * (size_t)i + 2];
+        if (chain_lane) chain_lane[i] = out4[4 * (size_t)i + 3];
+    }
     return PW_OK;
 }
 

@@ -236,27 +236,36 @@ PW_HD uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t pr
     return k;
 }
 
-// ---- guided search over a common-neighbour list ---------------------------------------------------------------
-// Both per-thread routines below look for the first list entry whose (monotone) partial mass reaches a target.  A
-// plain bisection costs log2(n) DEPENDENT scattered loads -- the lane kernel's critical path -- so the search starts
-// from a guess: one unaligned 16-byte load fetches entries [g - 1, g + 3) around the guessed index g, and when the
-// guess is right (entry g - 1 below the target, one of the next three at or above it) the search is over after that
-// single access.  Whatever the window does not settle is finished by bisection, so a wrong guess costs time, never
-// correctness.  The guesses come from a per-edge HINT table (csrc/walk_lanes.hip.h: hint_build_kernel): bucket b
-// of width Wd holds the first index whose prev-less mass m_i = ((P_i - i) << hs_out) + ((i + 1) << hs_in) reaches
-// b * Wd, Wd = M / n + 1, M = ((d - n) << hs_out) + (n << hs_in); one 4-byte word packs hint[b] | hint[b+1] << 16.
+// ---- per-edge lists of common-neighbour positions -----------------------------------------------------------------
+// The lane kernel's index (walk_lanes.hip.h) stores, for every CSR entry e = (u -> v), the ascending positions in
+// row v of the common neighbours of u and v.  Positions of rows of at most 65536 entries are uint16, of longer rows
+// uint32; a list starts at a 16-byte boundary (or inside the entry's 64-byte edge line: 8-byte boundary).
 struct ListWin {
     uint32_t v[4];
 };
-struct __attribute__((packed, aligned(4))) ListWinRaw {
-    uint32_t v[4];
+struct ListView {
+    const void *p;      // first entry
+    uint32_t wide;      // 1: uint32 entries, 0: uint16 entries
+    PW_HD uint32_t at(uint32_t i) const {
+        return wide ? ((const uint32_t *)p)[i] : (uint32_t)((const uint16_t *)p)[i];
+    }
+    // entries [i & ~3, (i & ~3) + 4) in one access (16 / 8 bytes, aligned to 4 entries); entries past the end of
+    // the list are garbage the callers never use (the allocations are padded)
+    PW_HD ListWin window(uint32_t i) const {
+        const uint32_t w0 = i & ~3u;
+        ListWin w;
+        if (wide) {
+            struct __attribute__((packed, aligned(4))) Raw { uint32_t v[4]; };
+            const Raw raw = *(const Raw *)((const uint32_t *)p + w0);
+            w.v[0] = raw.v[0]; w.v[1] = raw.v[1]; w.v[2] = raw.v[2]; w.v[3] = raw.v[3];
+        } else {
+            struct __attribute__((aligned(8))) Raw2 { uint32_t x, y; };
+            const Raw2 raw = *(const Raw2 *)((const uint16_t *)p + w0);
+            w.v[0] = raw.x & 0xffffu; w.v[1] = raw.x >> 16; w.v[2] = raw.y & 0xffffu; w.v[3] = raw.y >> 16;
+        }
+        return w;
+    }
 };
-PW_HD ListWin load_list_window(const uint32_t *p) {
-    const ListWinRaw raw = *(const ListWinRaw *)p;   // one 16-byte load, 4-byte aligned
-    ListWin w;
-    w.v[0] = raw.v[0]; w.v[1] = raw.v[1]; w.v[2] = raw.v[2]; w.v[3] = raw.v[3];
-    return w;
-}
 
 // floor(a / b) for a, b < 2^52, b > 0, through one float64 division (a 64-bit integer division costs ~200
 // instructions on the GPU; this is ~35)
@@ -266,127 +275,25 @@ PW_HD uint64_t div_floor_small(uint64_t a, uint64_t b) {
     else if ((q + 1u) * b <= a) q++;
     return q;
 }
-PW_HD uint32_t hint_bucket_width(uint32_t d, uint32_t n, uint32_t hs_in, uint32_t hs_out) {
-    const uint64_t m = ((uint64_t)(d - n) << hs_out) + ((uint64_t)n << hs_in);
-    return n ? (uint32_t)div_floor_small(m, n) + 1u : 1u;
-}
-
-struct ListHints {
-    const uint32_t *h;    // this edge's hint words (nullptr: none)
-    uint32_t hs_in, hs_out;
-    float wd;             // bucket width in hint units
-    // index the search should start from for mass tau (float arithmetic: the bucket may be off by one now and
-    // then -- the search verifies its guess)
-    PW_HD uint32_t guess(float tau, uint32_t n, uint32_t &reads) const {
-        if (!h) return 0xffffffffu;
-        const float bf = tau / wd;
-        uint32_t b = bf >= (float)(n - 1u) ? n - 1u : (bf > 0.0f ? (uint32_t)bf : 0u);
-        reads++;
-        return h[b] & 0xffffu;
-    }
-};
-// wd = the bucket width the table was built with (hint_bucket_width; the lane kernel keeps it in the edge record)
-PW_HD ListHints make_hints(const uint32_t *h, uint32_t hs_in, uint32_t hs_out, uint32_t wd, uint32_t n) {
-    ListHints lh;
-    lh.h = (h && n > 0 && n <= 0xffffu && wd) ? h : nullptr;
-    lh.hs_in = hs_in;
-    lh.hs_out = hs_out;
-    lh.wd = (float)wd;
-    return lh;
-}
-
-// Hint words of one list (n entries at positions cl[], row degree d): out[b] = hint[b] | hint[b + 1] << 16 for
-// b in [0, n), hint[b] = number of entries whose prev-less mass is below b * Wd (hint[n] = n).  Lists longer than
-// 65535 entries get no hints (make_hints ignores the table for them); out[] is left untouched.
-PW_HD void build_list_hints(const uint32_t *cl, uint32_t n, uint32_t d, uint32_t hs_in, uint32_t hs_out, uint32_t *out) {
-    if (n == 0 || n > 0xffffu) return;
-    const uint64_t wd = hint_bucket_width(d, n, hs_in, hs_out);
-    uint32_t i = 0, prev = 0;   // prev = hint[b - 1]
-    for (uint32_t b = 1; b <= n; b++) {
-        uint32_t hb = n;
-        if (b < n) {
-            const uint64_t lim = (uint64_t)b * wd;
-            while (i < n && (((uint64_t)(cl[i] - i) << hs_out) + ((uint64_t)(i + 1u) << hs_in)) < lim) i++;
-            hb = i;
-        }
-        out[b - 1] = prev | (hb << 16);
-        prev = hb;
-    }
-}
 
 // First index f in [lo_min, n) with ev(f, P_f) >= target (n when none); ev monotone non-decreasing in the index.
 // below: entry f - 1 and its value (has_below == false when f == lo_min); at: entry f and its value (p_at ==
-// 0xffffffff when f == n).  g = guessed index (0xffffffff: none).
+// 0xffffffff when f == n).  Plain bisection: ~log2(n) dependent probes.  (Hint tables, galloping from a guessed
+// window and sampled skip arrays were measured neutral at RMAT-22 and removed -- DESIGN.md section 9b.)
 struct SearchResult {
     uint32_t f;
     uint32_t p_below, p_at;
     uint64_t v_below, v_at;
     bool has_below;
-    ListWin win;     // the window the search loaded: entries [w0, w0 + 4), w0 == 0xffffffff: none
-    uint32_t w0;
 };
 template <class Eval>
-PW_HD SearchResult guided_search(const uint32_t *cl, uint32_t lo_min, uint32_t n, uint32_t g, const Eval &ev, uint64_t target,
-                                 uint32_t &reads, const ListWin *pre = nullptr, uint32_t pre_w0 = 0xffffffffu) {
+PW_HD SearchResult list_search(const ListView &cl, uint32_t lo_min, uint32_t n, const Eval &ev, uint64_t target, uint32_t &reads) {
     SearchResult r;
     r.p_below = 0; r.v_below = 0; r.has_below = false; r.p_at = 0xffffffffu; r.v_at = 0;
-    r.w0 = 0xffffffffu;
-    r.win = ListWin{{0, 0, 0, 0}};
     uint32_t lo = lo_min, hi = n;
-    if (lo < hi && (g != 0xffffffffu || pre_w0 != 0xffffffffu)) {
-        uint32_t w0;
-        ListWin w;
-        if (pre_w0 != 0xffffffffu) {   // window fetched ahead of time (lane_chain's prefetch)
-            w0 = pre_w0;
-            w = *pre;
-        } else {
-            if (g < lo_min) g = lo_min;
-            if (g > n) g = n;
-            w0 = g > lo_min ? g - 1u : g;
-            if (w0 >= n) w0 = n - 1u;
-            w = load_list_window(cl + w0);   // may run past the list end: the lists are padded
-            reads += 4;
-        }
-        r.win = w;
-        r.w0 = w0;
-        bool any_below = false, any_at = false;
-#pragma unroll
-        for (uint32_t t = 0; t < 4; t++) {
-            const uint32_t idx = w0 + t;
-            if (idx < hi && idx >= lo) {
-                const uint64_t v = ev(idx, w.v[t]);
-                if (v >= target) { hi = idx; r.p_at = w.v[t]; r.v_at = v; any_at = true; }
-                else { lo = idx + 1u; r.p_below = w.v[t]; r.v_below = v; r.has_below = true; any_below = true; }
-            }
-        }
-        // a near miss is finished by galloping away from the window instead of bisecting the whole list
-        if (lo < hi && any_below && !any_at) {          // guess too low: probe lo + 3, lo + 11, lo + 27, ...
-            uint32_t step = 4;
-            while (lo < hi) {
-                const uint32_t idx = hi - lo > step ? lo + step - 1u : hi - 1u;
-                const uint32_t P = cl[idx];
-                reads++;
-                const uint64_t v = ev(idx, P);
-                if (v >= target) { hi = idx; r.p_at = P; r.v_at = v; break; }
-                lo = idx + 1u; r.p_below = P; r.v_below = v; r.has_below = true;
-                step <<= 1;
-            }
-        } else if (lo < hi && any_at && !any_below) {   // guess too high: probe hi - 4, hi - 12, ...
-            uint32_t step = 4;
-            while (lo < hi) {
-                const uint32_t idx = hi - lo > step ? hi - step : lo;
-                const uint32_t P = cl[idx];
-                reads++;
-                const uint64_t v = ev(idx, P);
-                if (v < target) { lo = idx + 1u; r.p_below = P; r.v_below = v; r.has_below = true; break; }
-                hi = idx; r.p_at = P; r.v_at = v;
-                step <<= 1;
-            }
-        }
-    }
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t P = cl[mid];
+        const uint32_t P = cl.at(mid);
         reads++;
         const uint64_t v = ev(mid, P);
         if (v >= target) { hi = mid; r.p_at = P; r.v_at = v; }
@@ -404,7 +311,7 @@ PW_HD SearchResult guided_search(const uint32_t *cl, uint32_t lo_min, uint32_t n
 // (the float chain then needs the first `kmax` positions at most); LANE_REDO when the row is outside the exact
 // range.  The run structure: the i-th common neighbour sits at P_i with exact mass
 //   E(P_i) = ((P_i - i - [pp < P_i]) << sh_out) + ((i + 1) << sh_in) + ([pp < P_i] << sh_prev),
-// monotone in i, so the first i with E(P_i) >= lo is found by a (guided) search; between P_{i-1} and P_i the row
+// monotone in i, so the first i with E(P_i) >= lo is found by a bisection; between P_{i-1} and P_i the row
 // consists of "out" positions (and possibly prev), where the first position reaching lo is a closed form
 // (solve_out_run).
 constexpr uint32_t LANE_AMBIGUOUS = 0xfffffffdu;
@@ -413,7 +320,7 @@ constexpr uint32_t LANE_REDO = 0xfffffffcu;
 struct LaneStep {
     float tot;        // exact row total (float32)
     uint32_t kmax;    // ambiguous steps: leading positions the float chain can need
-    uint32_t probes;  // list / hint entries read
+    uint32_t probes;  // list entries read
     uint32_t k1;      // ambiguous steps: every position below k1 is known to stay below r
     uint32_t f;       // ... number of common neighbours before k1
     uint32_t shifts;  // ... sh_in | sh_out << 8 | sh_prev << 16 (weights in units of the smallest)
@@ -429,8 +336,7 @@ struct MassEval {   // E(P_i) in units of the smallest weight
 };
 
 PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
-                           const uint32_t *cl, LaneStep &ls, const uint32_t *hint = nullptr, uint32_t hs_in = 0,
-                           uint32_t hs_out = 0, uint32_t hint_wd = 0) {
+                           const ListView &cl, LaneStep &ls) {
     const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
     ls.probes = 0;
     if (n_in + n_pv > d) return LANE_REDO;
@@ -454,13 +360,8 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     // first common neighbour whose exact mass reaches lo_th
     uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0, f_below = 0;
     if (n_in) {
-        uint32_t g = 0xffffffffu;
-        if (hint && sh_in >= hs_in) {   // hint units are 2^(sh_in - hs_in) of this step's units
-            const ListHints lh = make_hints(hint, hs_in, hs_out, hint_wd, n_in);
-            g = lh.guess((float)(lo_th >> (sh_in - hs_in)), n_in, ls.probes);
-        }
         const MassEval ev{pp, sh_in, sh_out, sh_prev};
-        const SearchResult sr = guided_search(cl, 0u, n_in, g, ev, (uint64_t)lo_th, ls.probes);
+        const SearchResult sr = list_search(cl, 0u, n_in, ev, (uint64_t)lo_th, ls.probes);
         if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
         if (sr.f < n_in) { p_f = sr.p_at; e_f = (uint32_t)sr.v_at; }
         f_below = sr.f;   // entries whose mass stays below lo_th: exactly the common neighbours before k1
@@ -502,7 +403,6 @@ static thread_local uint64_t g_lane_seq_elems = 0, g_lane_binades = 0;
 #define PW_LANE_STAT(x)
 #endif
 constexpr uint32_t LANE_HEAD = 32;        // leading elements added one by one
-constexpr uint32_t LANE_PF = 6;           // binades whose list window is fetched ahead of time (5 words each)
 constexpr uint32_t LANE_TIE_BUDGET = 4096;  // runs walked one by one inside binades with a rounding tie
 
 struct ChainEval {   // partial sum (in ulps of the current binade) after common neighbour i at position P
@@ -516,60 +416,25 @@ struct ChainEval {   // partial sum (in ulps of the current binade) after common
 };
 
 PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
-                          const uint32_t *cl, uint32_t &reads, const uint32_t *hint = nullptr, uint32_t hs_in = 0,
-                          uint32_t hs_out = 0, uint32_t hint_wd = 0, uint32_t *pf = nullptr, uint32_t pf_stride = 1) {
+                          const ListView &cl, uint32_t &reads) {
     using B = Binade<float>;
-    const ListHints lh = make_hints(hint, hs_in, hs_out, hint_wd, n_in);
-    const float hint_units_per_one = ldexpf(1.0f / x_in, (int)hs_in);   // hint units of mass per unit of the sum
-    // Prefetch.  The chain is a sequence of binades, each ending with a search of the list -- a chain of dependent
-    // scattered loads (hint word -> window -> cursor), ~60 memory round trips per chain.  Where the sum leaves a
-    // binade hardly depends on the roundings before it: the top of binade eb is the value 2^(eb - 126), so the hint
-    // word and the list window every binade will need can be requested NOW, all at once (two rounds of independent
-    // loads); the windows wait in `pf` (LDS on the device: slot j = words [5 j, 5 j + 5) = {w0, entries}) and the
-    // searches below only touch memory again when a window does not settle them.
-    const int eb_t = B::eb_of((float)r);                 // binade of the target
-    const int eb_lo = eb_t - (int)LANE_PF + 1;
-    if (pf && lh.h) {
-        uint32_t g[LANE_PF];
-#pragma unroll
-        for (int j = 0; j < (int)LANE_PF; j++) {
-            const int eb = eb_lo + j;
-            g[j] = 0xffffffffu;
-            if (eb >= 1) g[j] = lh.guess((eb == eb_t ? (float)r : ldexpf(1.0f, eb - 126)) * hint_units_per_one, n_in, reads);
-        }
-#pragma unroll
-        for (int j = 0; j < (int)LANE_PF; j++) {
-            uint32_t w0 = 0xffffffffu;
-            ListWin w = ListWin{{0, 0, 0, 0}};
-            if (g[j] != 0xffffffffu) {
-                w0 = g[j] > 0 ? g[j] - 1u : 0u;
-                if (w0 >= n_in) w0 = n_in - 1u;
-                w = load_list_window(cl + w0);
-                reads += 4;
-            }
-            uint32_t *slot = pf + (size_t)(5 * j) * pf_stride;
-            slot[0] = w0;
-            slot[pf_stride] = w.v[0]; slot[2 * pf_stride] = w.v[1]; slot[3 * pf_stride] = w.v[2]; slot[4 * pf_stride] = w.v[3];
-        }
-    }
     float c = 0.0f;
     uint32_t k = 0;    // next element to add
     uint32_t i0 = 0;   // number of common neighbours before k
     // cursor over the list: position of common neighbour i0, served from a cached 4-entry window so that walking
     // the list costs one (dependent) load per four entries instead of one per entry
     ListWin cw = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
-    uint32_t cw0 = 0, next_in = 0xffffffffu;
+    uint32_t cw0 = 0xffffffffu, next_in = 0xffffffffu;
     reads = 0;   // list entries read (statistics)
 #define PW_LANE_CURSOR()                                                              \
     do {                                                                              \
         if (i0 >= n_in) next_in = 0xffffffffu;                                        \
         else {                                                                        \
-            if (i0 < cw0 || i0 - cw0 >= 4u) { cw = load_list_window(cl + i0); cw0 = i0; reads += 4; } \
-            const uint32_t o_ = i0 - cw0;                                             \
+            if ((i0 & ~3u) != cw0) { cw = cl.window(i0); cw0 = i0 & ~3u; reads += 4; } \
+            const uint32_t o_ = i0 & 3u;                                              \
             next_in = o_ == 0 ? cw.v[0] : (o_ == 1 ? cw.v[1] : (o_ == 2 ? cw.v[2] : cw.v[3])); \
         }                                                                             \
     } while (0)
-    if (n_in) { cw = load_list_window(cl); reads += 4; }
     PW_LANE_CURSOR();
     // PW_LANE_SEQ(n, stay): n elements one by one (real float32 additions); stops early when the sum leaves binade
     // `stay` (0: never); `hit` = the target was reached at element k.  (A macro, not a lambda: state captured by
@@ -670,21 +535,9 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         const uint64_t ii = qi.a0, io = qo.a0;
         PW_LANE_STAT(g_lane_binades++);
         // first common neighbour in [k, lim) whose partial sum reaches Tt; the run of "out" neighbours before it
-        // starts at s_run with partial sum `base`.  Guess from the hint table: the exact mass at which the sum
-        // equals Tt ulps (the float drift only shifts the true index by a few entries, which the window absorbs).
-        uint32_t g = 0xffffffffu, pre_w0 = 0xffffffffu;
-        ListWin pre = ListWin{{0, 0, 0, 0}};
-        if (lh.h) {
-            const int slot = eb - eb_lo;
-            if (pf && slot >= 0 && slot < (int)LANE_PF) {
-                const uint32_t *sp = pf + (size_t)(5 * slot) * pf_stride;
-                pre_w0 = sp[0];
-                pre.v[0] = sp[pf_stride]; pre.v[1] = sp[2 * pf_stride]; pre.v[2] = sp[3 * pf_stride]; pre.v[3] = sp[4 * pf_stride];
-            }
-            if (pre_w0 == 0xffffffffu) g = lh.guess(ldexpf((float)Tt, eb - 150) * hint_units_per_one, n_in, reads);
-        }
+        // starts at s_run with partial sum `base`
         const ChainEval ev{C, ii, io, k, i0, lim};
-        const SearchResult sr = guided_search(cl, i0, n_in, g, ev, Tt, reads, &pre, pre_w0);
+        const SearchResult sr = list_search(cl, i0, n_in, ev, Tt, reads);
         const uint32_t lo = sr.f;
         uint32_t s_run = k, p_f = 0xffffffffu;
         uint64_t base = C, g_f = 0;
@@ -705,7 +558,6 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
                 c = B::make((uint32_t)(base + (uint64_t)(lim - s_run) * io), eb);
                 k = lim;
                 i0 = lo;
-                if (sr.w0 != 0xffffffffu) { cw = sr.win; cw0 = sr.w0; }
                 PW_LANE_CURSOR();
                 continue;
             }
@@ -721,7 +573,6 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         if ((double)c >= r) return kf;
         k = kf + 1u;
         i0 = lo + (kf == p_f ? 1u : 0u);
-        if (sr.w0 != 0xffffffffu) { cw = sr.win; cw0 = sr.w0; }
         PW_LANE_CURSOR();
     }
     return LANE_CHAIN_END;
@@ -729,196 +580,10 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
 #undef PW_LANE_CURSOR
 }
 
-// ---- refined decision of an ambiguous step: the drift of the float32 chain, computed instead of bounded ---------
-// lane_decide's bound treats every rounding as a worst case; but the chain's roundings are SYSTEMATIC.  While the
-// sum stays in binade e, adding a value of class c moves it by inc_{e,c} ulps exactly (no tie), i.e. errs by the
-// constant  delta_{e,c} = inc_{e,c} * ulp_e - x_c;  the only other roundings are the one addition per binade that
-// crosses its top (|error| <= ulp/2 of the binade entered).  Hence with n_{e,c} = number of class-c additions inside
-// binade e before position k0,
-//      c_k0 = E(k0) * x_unit  +  sum_e sum_c n_{e,c} * delta_{e,c}  +  (crossing errors),
-// and the n_{e,c} follow from the POSITIONS where the sum enters each binade, which lie within the a-priori drift of
-// where the exact mass reaches 2^e: an E-space search per binade (mass_locate), independent of one another.  The top
-// LANE_RF binades are evaluated this way, everything below is bounded (its ulps are 2^LANE_RF times smaller).  Error
-// budget eps (all provable): crossings <= ulp_top; additions below the evaluated binades <= count * ulp/2;
-// a boundary misplaced by m positions <= m * 0.75 ulp of its binade; float64 evaluation 2^-45.  The interval
-// [c - eps, c + eps] pins the integer significand C of c_k0 to a few candidates; the step is decided when its
-// lowest and highest candidate agree on the element that reaches r inside the top binade (closed form, as in
-// lane_chain).  Anything else -- ties, prev next in line, a crossing before r, candidates that disagree -- returns
-// LANE_AMBIGUOUS and the chain decides.  About 12 % of the RMAT-22 steps enter; ~0.x % leave undecided.
-constexpr int LANE_RF = 5;
-
-struct MassPos {
-    uint32_t pos;      // first position whose exact mass reaches the target (d when none)
-    uint32_t rank;     // common neighbours before pos
-    bool common;       // pos is a common neighbour
-};
-PW_HD MassPos mass_locate(const uint32_t *cl, uint32_t n_in, uint32_t d, uint32_t pp, uint32_t sh_in, uint32_t sh_out,
-                          uint32_t sh_prev, uint64_t target, uint32_t &reads) {
-    MassPos m;
-    uint32_t s_run = 0, base = 0, p_f = 0xffffffffu;
-    m.rank = 0;
-    if (n_in) {
-        const MassEval ev{pp, sh_in, sh_out, sh_prev};
-        const SearchResult sr = guided_search(cl, 0u, n_in, 0xffffffffu, ev, target, reads);
-        if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
-        if (sr.f < n_in) p_f = sr.p_at;
-        m.rank = sr.f;
-    }
-    uint32_t e1;
-    const uint32_t th = target > 0xffffffffull ? 0xffffffffu : (uint32_t)target;
-    uint32_t k = solve_out_run(s_run, base, th, (pp != 0xffffffffu && pp >= s_run) ? pp : 0xffffffffu, sh_out, 1u << sh_prev, e1);
-    m.common = false;
-    if (p_f != 0xffffffffu && k >= p_f) { k = p_f; m.common = true; }
-    m.pos = k < d ? k : d;
-    return m;
-}
-
-PW_HD uint32_t lane_refine(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev, const uint32_t *cl,
-                           const LaneStep &ls, uint32_t &reads) {
-    using B = Binade<float>;
-    const uint32_t sh_in = ls.shifts & 0xffu, sh_out = (ls.shifts >> 8) & 0xffu, sh_prev = (ls.shifts >> 16) & 0xffu;
-    const uint32_t k1 = ls.k1, i1 = ls.f, kend = ls.kmax;
-    if (k1 == 0 || k1 >= kend) return LANE_AMBIGUOUS;
-    const bool has_pv = pp != 0xffffffffu;   // (k0 = k1 - 1 is the last position known to stay below r)
-    const float x_in = 1.0f / ls.tot, x_out = x_in * w_out, x_pv = x_in * w_prev;
-    const double x_u = ldexp((double)x_in, -(int)sh_in);   // float value of one unit of mass (exact)
-    const uint32_t pv0 = (has_pv && pp < k1) ? 1u : 0u;
-    const uint64_t E0 = ((uint64_t)(k1 - i1 - pv0) << sh_out) + ((uint64_t)i1 << sh_in) + ((uint64_t)pv0 << sh_prev);
-    const double v0 = (double)E0 * x_u;                     // exact: 24 x 24 bits
-    int ex = 0;
-    (void)frexp(v0, &ex);                                   // v0 = m * 2^ex, m in [0.5, 1)
-    const int e_t = ex - 1 + 127;                           // binade (biased float32 exponent) of the exact mass value
-    if (e_t < 2 || e_t > 126) return LANE_AMBIGUOUS;
-    uint32_t sh_max = sh_in > sh_out ? sh_in : sh_out;
-    if (sh_prev > sh_max) sh_max = sh_prev;
-    // where the sum enters each of the top binades: LANE_RF independent E-space searches, run as ONE bisection loop
-    // (every trip issues the probes of all searches before it waits: one memory round trip per level, not LANE_RF)
-    MassPos bnd[LANE_RF];
-    double eps = ldexp(1.0, e_t - 150);                     // crossing additions: sum of ulp_e / 2 over all binades
-    int n_b = 0;
-    uint64_t T[LANE_RF];
-    uint32_t lo[LANE_RF], hi[LANE_RF], pb[LANE_RF], pa[LANE_RF];   // bisection bounds, entries below / at the target
-    uint64_t vb[LANE_RF];
-#pragma unroll
-    for (int j = 0; j < LANE_RF; j++) {
-        const int e = e_t - j;                              // bnd[j] = entry into binade e_t - j
-        T[j] = 0; lo[j] = 0; hi[j] = 0; pb[j] = 0xffffffffu; pa[j] = 0xffffffffu; vb[j] = 0;
-        if (e < 1) continue;
-        const double tau = ldexp(1.0, e - 127) / x_u;       // mass (units) at which the exact sum reaches 2^(e - 127)
-        T[j] = (uint64_t)ceil(tau);
-        hi[j] = n_in;
-        // the float sum enters the binade within the a-priori drift of that position
-        const double zeta = 1.01 * drift_bound_f32(tau + (double)(2u << sh_max), d, 1u << sh_max);
-        const double m_e = ceil(zeta) + 2.0;
-        eps += m_e * 0.75 * ldexp(1.0, e - 150);
-        n_b = j + 1;
-    }
-    {
-        const MassEval ev{pp, sh_in, sh_out, sh_prev};
-        bool more = true;
-        while (more) {
-            uint32_t P[LANE_RF];
-#pragma unroll
-            for (int j = 0; j < LANE_RF; j++) P[j] = lo[j] < hi[j] ? cl[(lo[j] + hi[j]) >> 1] : 0u;
-            more = false;
-#pragma unroll
-            for (int j = 0; j < LANE_RF; j++) {
-                if (lo[j] < hi[j]) {
-                    const uint32_t mid = (lo[j] + hi[j]) >> 1;
-                    const uint64_t v = ev(mid, P[j]);
-                    reads++;
-                    if (v >= T[j]) { hi[j] = mid; pa[j] = P[j]; }
-                    else { lo[j] = mid + 1u; pb[j] = P[j]; vb[j] = v; }
-                    more = more || lo[j] < hi[j];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < LANE_RF; j++) {
-        bnd[j].pos = 0; bnd[j].rank = 0; bnd[j].common = false;
-        if (j >= n_b) continue;
-        const uint32_t s_run = pb[j] != 0xffffffffu ? pb[j] + 1u : 0u;
-        const uint32_t base = pb[j] != 0xffffffffu ? (uint32_t)vb[j] : 0u;
-        uint32_t e1;
-        const uint32_t th = T[j] > 0xffffffffull ? 0xffffffffu : (uint32_t)T[j];
-        uint32_t k = solve_out_run(s_run, base, th, (has_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, 1u << sh_prev, e1);
-        if (lo[j] < n_in && pa[j] != 0xffffffffu && k >= pa[j]) { k = pa[j]; bnd[j].common = true; }
-        bnd[j].pos = k < d ? k : d;
-        bnd[j].rank = lo[j];
-    }
-    if (n_b == 0) return LANE_AMBIGUOUS;
-    // additions before the lowest evaluated binade: bounded, half an ulp of the binade below it each
-    {
-        const int e_lo = e_t - (n_b - 1);
-        eps += ((double)bnd[n_b - 1].pos + 1.0) * 0.5 * ldexp(1.0, e_lo - 1 - 150);
-    }
-    // drift of the additions inside the evaluated binades
-    double drift = 0.0;
-#pragma unroll
-    for (int j = 0; j < LANE_RF; j++) {
-        if (j >= n_b) continue;
-        const int e = e_t - j;
-        const uint32_t a = bnd[j].pos;                                     // the crossing addition itself is in eps
-        // positions a < pos < b (b = entry into the next binade), or a < pos <= k0 in the top binade
-        const uint32_t b = j == 0 ? k1 : bnd[j - 1].pos;
-        if (b <= a + 1u) continue;
-        const uint32_t n = b - a - 1u;
-        const uint32_t rank_b = j == 0 ? i1 : bnd[j - 1].rank;
-        const uint32_t c_in = rank_b - bnd[j].rank - (bnd[j].common ? 1u : 0u);
-        const uint32_t c_pv = (has_pv && pp > a && pp < b) ? 1u : 0u;
-        if (c_in + c_pv > n) return LANE_AMBIGUOUS;                         // (cannot happen)
-        const uint32_t c_out = n - c_in - c_pv;
-        const Inc<float> qi = B::quantize(x_in, e), qo = B::quantize(x_out, e), qp = B::quantize(x_pv, e);
-        if ((c_in && qi.a0 != qi.a1) || (c_out && qo.a0 != qo.a1) || (c_pv && qp.a0 != qp.a1)) return LANE_AMBIGUOUS;
-        const double ulp = ldexp(1.0, e - 150);
-        drift += (double)c_in * ((double)qi.a0 * ulp - (double)x_in) + (double)c_out * ((double)qo.a0 * ulp - (double)x_out) +
-                 (double)c_pv * ((double)qp.a0 * ulp - (double)x_pv);
-    }
-    eps += ldexp(1.0, -45) + 1e-9 * fabs(drift);
-    // integer significand of c_k0 in the top binade: candidates [C_lo, C_hi]
-    const double ulp_t = ldexp(1.0, e_t - 150);
-    const double c_lo = v0 + drift - eps, c_hi = v0 + drift + eps;
-    if (!(c_lo >= ldexp(1.0, e_t - 127)) || !(c_hi < ldexp(1.0, e_t - 126))) return LANE_AMBIGUOUS;   // near a binade boundary
-    const uint64_t C_lo = (uint64_t)ceil(c_lo / ulp_t), C_hi = (uint64_t)floor(c_hi / ulp_t);
-    if (C_lo > C_hi || C_hi - C_lo > 64) return LANE_AMBIGUOUS;
-    // continue inside the top binade from position k1 for both ends of the interval: same element => decided
-    const uint64_t Tt = B::threshold(r, e_t);
-    if (Tt >= (uint64_t)B::TOP) return LANE_AMBIGUOUS;                     // r lies beyond this binade
-    if (has_pv && pp == k1) return LANE_AMBIGUOUS;                          // prev is next: a single real addition
-    const uint32_t lim = (has_pv && pp > k1 && pp < kend) ? pp : kend;
-    const Inc<float> qi = B::quantize(x_in, e_t), qo = B::quantize(x_out, e_t);
-    if (qi.a0 != qi.a1 || qo.a0 != qo.a1) return LANE_AMBIGUOUS;
-    const uint64_t ii = qi.a0, io = qo.a0;
-    uint32_t answer = LANE_AMBIGUOUS;
-    for (int side = 0; side < 2; side++) {
-        const uint64_t C = side == 0 ? C_lo : C_hi;
-        if (side == 1 && C_hi == C_lo) break;
-        if (C >= Tt) return LANE_AMBIGUOUS;                                 // c_k0 >= r would contradict the a-priori bound
-        const ChainEval ev{C, ii, io, k1, i1, lim};
-        const SearchResult sr = guided_search(cl, i1, n_in, i1 < n_in ? i1 : 0xffffffffu, ev, Tt, reads);
-        uint32_t s_run = k1, p_f = 0xffffffffu;
-        uint64_t base = C;
-        if (sr.has_below) { s_run = sr.p_below + 1u; base = sr.v_below; }
-        if (sr.f < n_in && sr.v_at != ~0ull) p_f = sr.p_at;
-        const uint32_t run_end = p_f != 0xffffffffu ? p_f : lim;
-        const uint64_t need = Tt > base ? Tt - base : 0ull;
-        uint64_t cnt = io ? div_floor_small(need + io - 1ull, io) : 0xffffffffull;
-        if (cnt == 0) cnt = 1;
-        const uint64_t jpos = (uint64_t)s_run + cnt - 1ull;
-        uint32_t kf;
-        if (jpos >= run_end) {
-            if (p_f == 0xffffffffu) return LANE_AMBIGUOUS;                  // not reached before prev / the prefix end
-            kf = p_f;
-        } else kf = (uint32_t)jpos;
-        if (side == 0) answer = kf;
-        else if (kf != answer) return LANE_AMBIGUOUS;
-    }
-    return answer;
-}
-
 // ---- interval decision of an ambiguous step: the chain's drift bounded WITHOUT touching the list -------------------
-// Same facts as lane_refine -- inside binade e an addition of class c errs by the constant delta_{e,c} -- but the
+// The chain's roundings are SYSTEMATIC: while the sum stays in binade e, adding a value of class c moves it by
+// inc_{e,c} ulps exactly (no tie), i.e. errs by the constant delta_{e,c} = inc_{e,c} * ulp_e - x_c; the only other
+// roundings are the one addition per binade that crosses its top (|error| <= ulp/2 of the binade entered).  The
 // per-binade class counts are not looked up: they are eliminated.  The non-crossing additions inside binade e obey
 //      a_e X_in + o_e X_out + p_e X_pv = W_e        (X = x + delta: the quantised increments; W_e = span of the sum)
 // so their drift is   D_e = (delta_out / X_out) W_e  +  a_e g_e  +  p_e h_e,   g_e = delta_in - delta_out X_in / X_out,
@@ -1095,11 +760,6 @@ PW_HD uint32_t lane_tight(uint32_t d, uint32_t pp, double r, float w_out, float 
     lo_off -= 4e-6f * (fabsf(lo_off) + 1.0f);
     hi_off += 4e-6f * (fabsf(hi_off) + 1.0f);
     if (!(voff + lo_off >= 0.0f) || !(voff + hi_off + 2.0f < 8388608.0f) || !(lo_off <= hi_off)) TIGHT_BAIL(9);
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (getenv("PW_TIGHT_DEBUG"))
-        fprintf(stderr, "tight k1=%u i1=%u pv0=%u width=%.1f ulps: base=%.1f g=%.1f h=%.1f eps=%.1f io=%u Z=%.1f\n", k1, i1, pv0, hi_off - lo_off,
-                d_hi - d_lo, gi * (g_hi - g_lo), h_hi - h_lo, 2 * eps, B::quantize(x_out, e_t).a0, Z);
-#endif
     uint64_t C_lo = (uint64_t)((int64_t)V + (int64_t)ceilf(fr + lo_off)), C_hi = (uint64_t)((int64_t)V + (int64_t)floorf(fr + hi_off));
     const uint64_t Tt = B::threshold(r, e_t);
     if (Tt >= (uint64_t)B::TOP) TIGHT_BAIL(10);                     // r lies beyond this binade

@@ -44,7 +44,7 @@ struct ERec {
     uint32_t s0;        // indptr[v]
     uint32_t coff_lo;   // clist offset of this edge's list (64 bit)
     uint32_t coff_hi;
-    uint32_t hint_wd;   // bucket width of this edge's hint words (seqscan.h: hint_bucket_width), 0: no hints built
+    uint32_t pad;
 };
 static_assert(sizeof(ERec) == 32, "edge record is two 16-byte loads");
 
@@ -59,6 +59,15 @@ struct SuspRec {
     double r;
 };
 static_assert(sizeof(SuspRec) == 64, "queue record is four 16-byte accesses");
+
+// A step the interval decision (lane_tight) settled, kept for verification: what lane_chain needs to decide it again.
+struct VerRec {
+    uint32_t kmax, n_in, pp, choice;
+    uint32_t coff_lo, coff_hi, d, pad;
+    float tot, wo;
+    double r;
+};
+static_assert(sizeof(VerRec) == 48, "verification record is three 16-byte stores");
 
 struct LanesArgs {
     const ERec *__restrict__ erec;
@@ -81,14 +90,19 @@ struct LanesArgs {
     uint32_t *redo_list;                      // jobs handed to walk_kernel
     unsigned long long *redo_count;
     float w_out, w_prev;                      // fl32(1/q), fl32(1/p): powers of two (host checked)
-    const uint32_t *__restrict__ hint;        // per-edge hint words of the guided search (seqscan.h), or nullptr
-    uint32_t hs_in, hs_out;                   // mass units the hints were built for
     SuspRec *susp;                            // queue for walks that need the float chain (nullptr: chains run in-kernel)
     unsigned long long *susp_count;
     uint32_t susp_chunk;                      // queue slots a wavefront reserves at a time (1: exact, no void slots)
     uint32_t job_chunk;                       // jobs a wavefront reserves at a time while plenty are left
     const SuspRec *resume;                    // walks to take up again (their `choice` settled) INSTEAD of fresh jobs
     uint64_t n_resume;
+    // verification mode (PECANPY_AMD_VERIFY_TIGHT=1, kernels instantiated with VERIFY): every step lane_tight settles
+    // is ALSO recorded here and re-decided by the float32 chain itself (lanes_verify_kernel)
+    VerRec *ver;
+    unsigned long long *ver_count;            // [0] records appended (may exceed ver_cap: the excess is dropped and counted)
+    uint64_t ver_cap;
+    uint32_t ver_poison;                      // PECANPY_AMD_VERIFY_TIGHT=poison: every 1024th RECORD (not the walk) gets a wrong
+                                              // position, which the check must report -- proves the check is live
 };
 
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
@@ -106,30 +120,17 @@ __device__ unsigned long long g_lprof[16];
 #endif
 
 #ifndef PW_LANES_MIN_WAVES
-#define PW_LANES_MIN_WAVES 4   // 128 VGPRs: the kernel needs ~130 (float64 interval arithmetic); at 5-6 waves it spills in the hot loop and runs 1.6-2x slower
+#define PW_LANES_MIN_WAVES 4   // 128 VGPRs: the in-place form needs ~130 (chain code); at 5-6 waves it spills in the hot loop and runs 1.6-2x slower
 #endif
 #ifndef PW_LANES_MIN_WAVES_Q
 #define PW_LANES_MIN_WAVES_Q 5   // ... of the queueing form (no chain code): ~100 VGPRs, fits 5 waves without spilling
-#endif
-#ifndef PW_LANES_WAIT
-#define PW_LANES_WAIT 16   // ambiguous lanes that gather before the refined decision runs
-#endif
-#ifndef PW_LANES_REFINE
-#define PW_LANES_REFINE 0  // 1: waiting lanes first try lane_refine (seqscan.h); measured 6 % slower -- DESIGN.md 9b
 #endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
                               // its share of the work at most)
 #endif
-#ifndef PW_LANES_REFILL_MIN
-#define PW_LANES_REFILL_MIN 1   // idle lanes that trigger a refill
-#endif
-#ifndef PW_LANES_TIGHT
-#define PW_LANES_TIGHT 1   // ambiguous steps first try lane_tight (seqscan.h), which settles ~9 in 10 without a memory
-#endif                     // access: 1 = right away, 2 = once PW_LANES_WAIT of them have gathered (stage 1), 0 = off
-#define PW_LANES_STAGE1 (PW_LANES_REFINE || PW_LANES_TIGHT == 2)
 #ifndef PW_LANES_WAIT2
-#define PW_LANES_WAIT2 (PW_LANES_STAGE1 ? 8 : (PW_LANES_TIGHT ? 2 : PW_LANES_WAIT))   // lanes that gather before their float chains run in place
+#define PW_LANES_WAIT2 2      // in-place form: ambiguous lanes that gather before their float chains run
 #endif
 
 // Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
@@ -157,7 +158,7 @@ __device__ unsigned long long g_lprof[16];
                 ob.v[3] = slot_ == 3u ? r0_.x : ob.v[3];                                        \
                 const bool last_ = A.j + 1u > L || r0_.w == 0u;                                 \
                 uint32_t *cell_ = a.out + (uint64_t)A.job * W + (A.j - slot_);                  \
-                if (slot_ == 3u) *(ListWinRaw *)cell_ = ob;                                     \
+                if (slot_ == 3u) *(OutCells *)cell_ = ob;                                       \
                 else if (last_) {                                                               \
                     cell_[0] = ob.v[0];                                                         \
                     if (slot_ >= 1u) cell_[1] = ob.v[1];                                        \
@@ -165,7 +166,7 @@ __device__ unsigned long long g_lprof[16];
                 }                                                                               \
             }                                                                                   \
             A.n_in = r0_.y; A.pp = r0_.z; A.d = r0_.w;                                          \
-            A.s0 = r1_.x; A.coff = ((uint64_t)r1_.z << 32) | r1_.y; A.wd = r1_.w;               \
+            A.s0 = r1_.x; A.coff = ((uint64_t)r1_.z << 32) | r1_.y;                             \
             n_steps++;                                                                          \
             A.j++;                                                                              \
             if (A.j > L || A.d == 0) {                                                          \
@@ -180,20 +181,18 @@ __device__ unsigned long long g_lprof[16];
         }                                                                                       \
     } while (0)
 
+struct __attribute__((packed, aligned(4))) OutCells {   // four staged output cells: one 16-byte store, 4-byte aligned
+    uint32_t v[4];
+};
+
 // INPLACE: steps the interval decision leaves open run their float chain in the kernel (waiting lanes, below) -- the
 // form used when no queue is given (a.susp == nullptr: short job lists, the last round).  !INPLACE: such walks are
 // always parked (a.susp != nullptr); without the chain code the kernel needs fewer registers.
-template <bool INPLACE>
+// VERIFY: steps settled by lane_tight are recorded for lanes_verify_kernel (test mode, PECANPY_AMD_VERIFY_TIGHT=1).
+template <bool INPLACE, bool VERIFY>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : PW_LANES_MIN_WAVES_Q)
 walk_lanes_kernel(LanesArgs a) {
     const int lane = lane_id();
-#ifdef PW_LANES_PREFETCH
-    // per-lane slots of lane_chain's prefetched list windows (seqscan.h), lane-interleaved: conflict free
-    __shared__ uint32_t s_pf[WAVES_PER_BLOCK][5 * LANE_PF][WAVE];
-    uint32_t *const pf = &s_pf[threadIdx.x / WAVE][0][lane];
-#else
-    uint32_t *const pf = nullptr;   // (measured: no gain)
-#endif
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.resume ? a.n_resume : (a.job_list ? a.n_list : a.n_jobs);
@@ -210,13 +209,12 @@ walk_lanes_kernel(LanesArgs a) {
         uint64_t soff;
         uint32_t s0, d, n_in, pp;        // row of the current vertex; edge it was entered by
         uint64_t coff;
-        uint32_t wd;                     // hint bucket width of that edge's list
-        uint32_t flags;                  // bit 0: active, bit 1: waiting for the float chain
+        uint32_t flags;                  // bit 0: active, bit 2: waiting for the float chain, bit 3: resumed
     };
-    constexpr uint32_t F_ACTIVE = 1u, F_WAIT = 2u, F_WAIT2 = 4u;   // waiting for the refinement / for the float chain
-    constexpr uint32_t F_PRE = 8u;                                 // resumed walk: the pending step's choice is known (pre)
+    constexpr uint32_t F_ACTIVE = 1u, F_WAIT2 = 4u;   // waiting for the float chain (in-place form)
+    constexpr uint32_t F_PRE = 8u;                    // resumed walk: the pending step's choice is known (pre)
     uint32_t pre = 0;
-    Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
+    Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0};
     bool exhausted = false;
     uint64_t pool_lo = 0, pool_hi = 0;   // wavefront-uniform: job indices reserved from the shared counter
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
@@ -224,24 +222,15 @@ walk_lanes_kernel(LanesArgs a) {
     unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0, n_wave = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
-    ListWinRaw ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
+    OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
-#if PW_LANES_STAGE1
-    uint32_t k1 = 0, f1 = 0, shifts = 0, p_next = 0;
-#endif
-    const uint32_t *const hint = a.hint;
-    const uint32_t hs_in = a.hs_in, hs_out = a.hs_out;
 
     for (;;) {
         // ---- refill idle lanes from the job counter -------------------------------------------------------
         for (;;) {
             const uint64_t need = ballot(!(A.flags & F_ACTIVE) && !exhausted);
             if (!need) break;
-#if PW_LANES_REFILL_MIN > 1
-            // a refill is three dependent loads for the whole wavefront: wait until a few lanes are idle
-            if ((uint32_t)__popcll(need) < PW_LANES_REFILL_MIN && ballot((A.flags & F_ACTIVE) != 0) != 0) break;
-#endif
             // jobs are taken from a wavefront-local pool; the shared counter is touched once per PW_LANES_CHUNK jobs
             // (one atomic per refill made every wavefront queue on ONE address ~40 M times a second -- the counter's
             // L2 channel, not the walks, set the pace).  Near the end of the work the chunks shrink to what is needed.
@@ -268,10 +257,13 @@ walk_lanes_kernel(LanesArgs a) {
                     if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
                         A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
                         A.n_in = q1.x; A.pp = q1.y; A.coff = ((uint64_t)q1.w << 32) | q1.z;
-                        A.wd = 0; pre = q2.y;                       // (wd: refreshed by the parked step's edge record)
+                        pre = q2.y;
                         A.soff = ((uint64_t)q2.w << 32) | q2.z;
                         const uint32_t slot = (A.j - 1u) & 3u;      // staged output cells of the group in progress
-                        if (slot) ob = *(const ListWinRaw *)(a.out + (uint64_t)A.job * W + (A.j - slot));
+                        const uint32_t *cell = a.out + (uint64_t)A.job * W + (A.j - slot);
+                        if (slot >= 1u) ob.v[0] = cell[0];
+                        if (slot >= 2u) ob.v[1] = cell[1];
+                        if (slot >= 3u) ob.v[2] = cell[2];
                         A.flags = F_ACTIVE | F_PRE;
                     }
                 } else {
@@ -286,7 +278,7 @@ walk_lanes_kernel(LanesArgs a) {
                             for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                     } else {
                         A.soff = a.stream_off[A.job] - a.rng_base;
-                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.coff = 0; A.wd = 0; A.j = 1;
+                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.coff = 0; A.j = 1;
                         r = a.rng[A.soff];
                         A.flags = F_ACTIVE;
                     }
@@ -300,46 +292,67 @@ walk_lanes_kernel(LanesArgs a) {
         // ---- one step for every runnable lane ------------------------------------------------------------------
         // decision -> interval decision -> (still open:) the walk is parked for lanes_chain_kernel, or -- in-place form --
         // the lane WAITS (keeps its draw and prefix bound) while the others go on stepping, and the waiting lanes run
-        // their chains together once a few have gathered or nothing else can run (optionally lane_refine first).
+        // their chains together once a few have gathered or nothing else can run.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
         if (runnable) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
             // (r = this step's draw: loaded when the previous step was applied / the walk was started)
-            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, ls, hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd);
+            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, ListView{a.clist + A.coff, 1u}, ls);
             n_probes += ls.probes;
             if (choice == LANE_AMBIGUOUS) n_amb++;
         }
         LPROF_T(1);
-#if PW_LANES_TIGHT == 1
         // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
-        if (ballot(runnable && choice == LANE_AMBIGUOUS)) {
+        const bool amb0 = runnable && choice == LANE_AMBIGUOUS;
+        if (ballot(amb0)) {
             LPROF_C(9, 1);
-            LPROF_C(10, __popcll(ballot(runnable && choice == LANE_AMBIGUOUS)));
-            if (runnable && choice == LANE_AMBIGUOUS) choice = lane_tight(A.d, A.pp, r, wo, w_prev, ls);
+            LPROF_C(10, __popcll(ballot(amb0)));
+            if (amb0) choice = lane_tight(A.d, A.pp, r, wo, w_prev, ls);
+            if (VERIFY) {
+                // keep what the float chain needs to decide this step again (lanes_verify_kernel)
+                const bool rec = amb0 && choice != LANE_AMBIGUOUS;
+                const uint64_t vm = ballot(rec);
+                if (vm) {
+                    unsigned long long vb = 0;
+                    if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                    vb = readfirst_u64(vb);
+                    const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
+                    if (rec && slot < a.ver_cap) {
+                        uint4 *vp = (uint4 *)(a.ver + slot);
+                        vp[0] = make_uint4(ls.kmax, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
+                        vp[1] = make_uint4((uint32_t)A.coff, (uint32_t)(A.coff >> 32), A.d, 0u);
+                        vp[2] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
+                                           (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
+                    }
+                }
+            }
             LPROF_T(2);
         }
-#endif
         if (!INPLACE || a.susp) {
             // park the walk: the chain runs later, at full width (lanes_chain_kernel); this lane takes another walk
             const bool park = runnable && choice == LANE_AMBIGUOUS;
             const uint64_t pm = ballot(park);
             if (pm) {
-                // queue slots come from a wavefront-local reservation too (slots left over at the end are marked void)
+                // queue slots come from a wavefront-local reservation too; what is left of the previous reservation is
+                // used up first (only a wavefront's LAST reservation leaves void slots: the queue never holds more
+                // than parked walks + susp_chunk slots per wavefront -- the host sizes it for that)
                 const uint64_t np = (uint64_t)__popcll(pm);
-                if (sp_hi - sp_lo < np) {
-                    for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;
-                    const unsigned long long chunk = a.susp_chunk > np ? a.susp_chunk : np;
+                const uint64_t left = sp_hi - sp_lo;
+                const uint64_t old_lo = sp_lo;
+                uint64_t new_lo = 0;
+                if (left < np) {
+                    const unsigned long long chunk = a.susp_chunk > np - left ? a.susp_chunk : np - left;
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(a.susp_count, chunk);
-                    sp_lo = readfirst_u64(base);
-                    sp_hi = sp_lo + chunk;
-                }
-                const uint64_t base = sp_lo;
-                sp_lo += np;
+                    new_lo = readfirst_u64(base);
+                    sp_lo = new_lo + (np - left);
+                    sp_hi = new_lo + chunk;
+                } else sp_lo += np;
                 if (park) {
-                    uint4 *qp = (uint4 *)(a.susp + (base + (uint64_t)__popcll(pm & lane_lt)));
+                    const uint64_t rk = (uint64_t)__popcll(pm & lane_lt);
+                    uint4 *qp = (uint4 *)(a.susp + (rk < left ? old_lo + rk : new_lo + (rk - left)));
                     qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
                     qp[1] = make_uint4(A.n_in, A.pp, (uint32_t)A.coff, (uint32_t)(A.coff >> 32));
                     qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
@@ -354,52 +367,19 @@ walk_lanes_kernel(LanesArgs a) {
                 }
             }
         } else if (INPLACE && runnable && choice == LANE_AMBIGUOUS) {
-            A.flags |= F_WAIT; tot = ls.tot; kmax = ls.kmax;
-#if PW_LANES_STAGE1
-            k1 = ls.k1; f1 = ls.f; shifts = ls.shifts; p_next = ls.p_next;
-#endif
+            A.flags = F_ACTIVE | F_WAIT2; tot = ls.tot; kmax = ls.kmax;
         }
         if (A.flags == (F_ACTIVE | F_PRE)) { choice = pre; A.flags = F_ACTIVE; }   // resumed walk: its parked step
         if (INPLACE) {
-#if PW_LANES_STAGE1
-            // stage 1 for the waiting lanes, once enough have gathered: the interval decision (PW_LANES_TIGHT == 2),
-            // then the refined decision (PW_LANES_REFINE)
-            const uint64_t w1 = ballot((A.flags & F_WAIT) != 0);
-            if (w1 != 0 && ((uint32_t)__popcll(w1) >= PW_LANES_WAIT || ballot(runnable && choice != LANE_AMBIGUOUS) == 0)) {
-                LPROF_C(9, 1);
-                LPROF_C(10, __popcll(w1));
-                if (A.flags & F_WAIT) {
-                    LaneStep lw{tot, kmax, 0u, k1, f1, shifts, p_next};
-                    uint32_t res = LANE_AMBIGUOUS;
-#if PW_LANES_TIGHT == 2
-                    res = lane_tight(A.d, A.pp, r, wo, w_prev, lw);
-#endif
-#if PW_LANES_REFINE
-                    if (res == LANE_AMBIGUOUS) {
-                        uint32_t reads = 0;
-                        res = lane_refine(A.d, A.n_in, A.pp, r, wo, w_prev, a.clist + A.coff, lw, reads);
-                        n_probes += reads;
-                    }
-#endif
-                    if (res != LANE_AMBIGUOUS) { choice = res; A.flags = F_ACTIVE; }
-                    else A.flags = F_ACTIVE | F_WAIT2;
-                }
-                LPROF_T(2);
-            }
-#else
-            if (A.flags & F_WAIT) A.flags = F_ACTIVE | F_WAIT2;   // no stage 1: straight to the chain queue
-#endif
             const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
-            if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_WAIT2 || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0) &&
-                ballot((A.flags & F_WAIT) != 0) == 0) {
+            if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_WAIT2 || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0)) {
                 LPROF_C(5, 1);
                 LPROF_C(6, __popcll(w2));
                 if (A.flags & F_WAIT2) {
                     // the float32 chain over the first kmax positions, by this lane alone (seqscan.h: lane_chain)
                     const float x_in = 1.0f / tot;
                     uint32_t reads = 0;
-                    const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, a.clist + A.coff, reads,
-                                                    hint ? hint + A.coff : nullptr, hs_in, hs_out, A.wd, pf, (uint32_t)WAVE);
+                    const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, ListView{a.clist + A.coff, 1u}, reads);
                     n_probes += reads;
                     choice = res;
                     if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
@@ -451,8 +431,8 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, f
         const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
         const float x_in = 1.0f / tot;
         uint32_t reads = 0;
-        const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev, clist + (((uint64_t)q1.w << 32) | q1.z),
-                                        reads, nullptr, 0u, 0u, 0u, nullptr, 0u);
+        const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev,
+                                        ListView{clist + (((uint64_t)q1.w << 32) | q1.z), 1u}, reads);
         uint32_t choice = res;
         if (res == LANE_CHAIN_END || res == LANE_TIE) choice = q0.w;   // overflow read / tie budget: the wave kernel redoes the walk
         q[i].choice = choice;
@@ -467,6 +447,43 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, f
     if (lane_id() == 0 && done) {
         atomicAdd(stats + 6, reads_l);
         atomicAdd(stats + 9, done);
+    }
+}
+
+// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------
+// counts: [0] records checked [1] MISMATCHES (lane_tight's position != the chain's) [2] chains that declined (tie budget)
+// bad: the first few mismatching records, for the error message
+__global__ void __launch_bounds__(256)
+lanes_verify_kernel(const VerRec *q, uint64_t n, const uint32_t *__restrict__ clist, float w_prev, unsigned long long *counts,
+                    VerRec *bad, uint32_t bad_cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long chk = 0, mis = 0, tie = 0;
+    if (i < n) {
+        const uint4 *qp = (const uint4 *)(q + i);
+        const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+        const float tot = __uint_as_float(q2.x), wo = __uint_as_float(q2.y);
+        const double r = __longlong_as_double((long long)(((unsigned long long)q2.w << 32) | q2.z));
+        const float x_in = 1.0f / tot;
+        uint32_t reads = 0;
+        const uint32_t res = lane_chain(q0.x, q0.y, q0.z, r, x_in, x_in * wo, x_in * w_prev,
+                                        ListView{clist + (((uint64_t)q1.y << 32) | q1.x), 1u}, reads);
+        chk = 1;
+        if (res == LANE_TIE) tie = 1;
+        else if (res != q0.w) {
+            mis = 1;
+            const unsigned long long slot = atomicAdd(counts + 3, 1ull);
+            if (slot < bad_cap) { bad[slot] = q[i]; bad[slot].pad = res; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        chk += (unsigned long long)__shfl_down((long long)chk, (unsigned)off, WAVE);
+        mis += (unsigned long long)__shfl_down((long long)mis, (unsigned)off, WAVE);
+        tie += (unsigned long long)__shfl_down((long long)tie, (unsigned)off, WAVE);
+    }
+    if (lane_id() == 0 && chk) {
+        atomicAdd(counts + 0, chk);
+        if (mis) atomicAdd(counts + 1, mis);
+        if (tie) atomicAdd(counts + 2, tie);
     }
 }
 
@@ -558,21 +575,8 @@ clist_fill_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const uint64_
     r.s0 = sv;
     r.coff_lo = (uint32_t)c0;
     r.coff_hi = (uint32_t)(c0 >> 32);
-    r.hint_wd = 0;
+    r.pad = 0;
     erec[e] = r;
-}
-
-// Hint words of every edge's list for the mass units (hs_in, hs_out) (seqscan.h: build_list_hints): one lane per
-// CSR entry.  Rebuilt when q changes the ratio of the "in" and "out" weights.
-__global__ void __launch_bounds__(256)
-hint_build_kernel(ERec *erec, const uint32_t *__restrict__ clist, uint32_t nnz, uint32_t hs_in, uint32_t hs_out,
-                  uint32_t *hint) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    const ERec r = erec[e];
-    const uint64_t c0 = ((uint64_t)r.coff_hi << 32) | r.coff_lo;
-    build_list_hints(clist + c0, r.n_in, r.deg, hs_in, hs_out, hint + c0);
-    erec[e].hint_wd = (r.n_in && r.n_in <= 0xffffu) ? hint_bucket_width(r.deg, r.n_in, hs_in, hs_out) : 0u;
 }
 
 }  // namespace pw

@@ -1492,20 +1492,19 @@ tot_build_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused
         const bool is_edge = item < nnz;
         const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
         uint32_t cur = (uint32_t)(item - nnz), prev = 0;
-        const uint32_t dbg = PW_KARG(uint32_t, L);   // debug switches: 1 no edge_row load, 2 no stores, 4 no compute
         if (is_edge) {
             cur = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[item];
-            if (!(dbg & 1u)) prev = as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[item];
+            prev = as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[item];
         }
         const uint32_t s0 = indptr[cur], d = indptr[cur + 1] - s0;
         const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
         float tot = 0.0f;
-        if (d && !(dbg & 4u)) {
+        if (d) {
             const WalkArgs la = reload_walk_args();
             (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur,
                                                      is_edge, prev, t0, dp, 0.0, s0, d, nullptr, &tot);
         }
-        if (lane == 0 && !(dbg & 2u)) {
+        if (lane == 0) {
             if (is_edge) ((gptr_mut<float>)kernarg<uint64_t>(XARG + 8))[item] = tot;
             else ((gptr_mut<float>)kernarg<uint64_t>(XARG + 16))[item - nnz] = tot;
         }

@@ -124,52 +124,55 @@ def test_float64_flavour_of_the_dense_kernel(w_out, w_prev):
         assert ok[:300].mean() > 0.99             # float64 drift is far below one unit: practically always decided
 
 
-# ---- the lane kernel's per-thread form of the same decision (seqscan.h: lane_decide) ---------------------------
+# ---- the lane kernel's per-thread form of the same decision (seqscan.h: lane_decide, lane_tight, lane_chain) -----
+# Every check below runs twice: on the host build of the routines, and (marked gpu) with one DEVICE thread per target,
+# i.e. through the code the walk kernels execute -- device code generation, v_rcp_f32 in lane_tight, -ffp-contract=off.
 LANE_AMBIGUOUS = 0xFFFFFFFD
 LANE_REDO = 0xFFFFFFFC
 LANE_CHAIN_END = 0xFFFFFFFB
 LANE_TIE = 0xFFFFFFFA
 
-
-def lane_decide(cls, w_out, w_prev, r, use_hints=False):
-    lib = _lib.load()
-    cls = np.ascontiguousarray(cls, dtype=np.uint8)
-    r = np.ascontiguousarray(r, dtype=np.float64)
-    chain = np.empty(r.size, dtype=np.uint32)
-    lane = np.empty(r.size, dtype=np.uint32)
-    kmax = np.empty(r.size, dtype=np.uint32)
-    chain_lane = np.empty(r.size, dtype=np.uint32)
-    probes = np.empty(r.size, dtype=np.uint32)
-    refined = np.empty(r.size, dtype=np.uint32)
-    _lib.check(lib.pw_selftest_lane_decide(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
-                                           r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
-                                           lane.ctypes.data_as(C.c_void_p), kmax.ctypes.data_as(C.c_void_p),
-                                           chain_lane.ctypes.data_as(C.c_void_p), int(use_hints),
-                                           probes.ctypes.data_as(C.c_void_p), refined.ctypes.data_as(C.c_void_p)))
-    lane_decide.refined = refined
-    lane_decide.chain_lane = chain_lane
-    lane_decide.probes = probes
-    return chain, lane, kmax
+BACKENDS = [pytest.param(False, id="host"), pytest.param(True, id="device", marks=pytest.mark.gpu)]
 
 
+class LaneRun:
+    def __init__(self, cls, w_out, w_prev, r, device):
+        lib = _lib.load()
+        cls = np.ascontiguousarray(cls, dtype=np.uint8)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        self.chain, self.lane, self.kmax, self.tight, self.chain_lane = (np.empty(r.size, dtype=np.uint32) for _ in range(5))
+        _lib.check(lib.pw_selftest_lane(int(device), 0, cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
+                                        r.ctypes.data_as(C.c_void_p), r.size, *(a.ctypes.data_as(C.c_void_p) for a in
+                                        (self.chain, self.lane, self.kmax, self.tight, self.chain_lane))))
+
+
+def adversarial_targets(rng, cls, w_out, w_prev, n_uniform, stride=1):
+    """Uniform draws + targets exactly on / one ulp around every float32 partial sum and every exact partial sum."""
+    c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
+    cd = c32.astype(np.float64)
+    sub = slice(None, None, stride)
+    targets = [rng.random(n_uniform), cd[sub], np.nextafter(cd[sub], 0.0), np.nextafter(cd[sub], 2.0), exact_cdf[sub],
+               np.nextafter(exact_cdf[sub], 0.0), np.nextafter(exact_cdf[sub], 2.0),
+               np.array([0.0, 1e-300, 1 - 2.0 ** -53, 0.5, 0.25, 0.125, np.nextafter(0.5, 0.0), np.nextafter(0.25, 0.0)])]
+    return np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0)), cd
+
+
+@pytest.mark.parametrize("device", BACKENDS)
 @pytest.mark.parametrize("w_out,w_prev", BIASES)
-def test_lane_decision_from_common_neighbour_positions(w_out, w_prev):
+def test_lane_decision_from_common_neighbour_positions(w_out, w_prev, device):
     """One thread, bisection over the positions of the common neighbours + closed-form "out" runs: decided
     indices equal the float32 chain; undecided ones need no more than kmax leading positions; and the
     decision agrees with the wave kernel's rank-search form on which targets are decided."""
     rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 7)
-    decided = total = ties = chained = reads_plain = reads_hint = 0
+    decided = total = ties = chained = 0
     for n in (1, 2, 3, 7, 40, 64, 65, 300, 1500, 6000):
         for p_common in (0.0, 0.02, 0.3, 0.9, 1.0):
             for with_prev in (False, True):
                 cls = random_row(rng, n, p_common, with_prev)
-                c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
-                cd = c32.astype(np.float64)
-                targets = [rng.random(300), cd, np.nextafter(cd, 0.0), np.nextafter(cd, 2.0), exact_cdf,
-                           np.nextafter(exact_cdf, 0.0), np.nextafter(exact_cdf, 2.0),
-                           np.array([0.0, 1e-300, 1 - 2.0 ** -53])]
-                r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
-                chain, lane, kmax = lane_decide(cls, w_out, w_prev, r)
+                r, cd = adversarial_targets(rng, cls, w_out, w_prev, 300)
+                run = LaneRun(cls, w_out, w_prev, r, device)
+                chain, lane, kmax = run.chain, run.lane, run.kmax
+                assert np.array_equal(chain, np.searchsorted(cd, r, side="left").astype(np.uint32))   # (the hook's own chain)
                 assert not (lane == LANE_REDO).any()
                 ok = lane != LANE_AMBIGUOUS
                 assert np.array_equal(lane[ok], chain[ok]), (n, p_common, with_prev, w_out, w_prev)
@@ -180,87 +183,41 @@ def test_lane_decision_from_common_neighbour_positions(w_out, w_prev):
                 assert np.array_equal(exact != AMBIGUOUS, ok)      # same bound, same verdicts
                 # the per-thread float chain (lane_chain): over the ambiguous prefix / the whole row it returns
                 # the reference's index, "never reached", or declines on a rounding tie
-                cl_ = lane_decide.chain_lane
+                cl_ = run.chain_lane
                 tie = cl_ == LANE_TIE
                 end = cl_ == LANE_CHAIN_END
                 assert np.array_equal(cl_[~tie & ~end], chain[~tie & ~end]), (n, p_common, with_prev, w_out, w_prev)
                 assert (chain[end] == n).all()
+                # the interval decision: whatever it settles is the chain's answer
+                settled = amb & (run.tight != LANE_AMBIGUOUS)
+                assert np.array_equal(run.tight[ok], lane[ok]) and np.array_equal(run.tight[settled], chain[settled])
                 ties += int(tie.sum())
                 chained += int(tie.size)
-                # guided by the hint table: identical answers from fewer list reads
-                plain_reads = int(lane_decide.probes[:300].sum())
-                chain_h, lane_h, kmax_h = lane_decide(cls, w_out, w_prev, r, use_hints=True)
-                assert np.array_equal(lane_h, lane) and np.array_equal(kmax_h, kmax)
-                assert np.array_equal(lane_decide.chain_lane, cl_)
-                reads_plain += plain_reads
-                reads_hint += int(lane_decide.probes[:300].sum())
                 decided += int(ok[:300].sum())
                 total += 300
     assert decided / total > 0.5
     assert ties / chained < 0.2          # the per-thread chain rarely has to decline
-    assert reads_hint < reads_plain      # (entries read; a 4-entry window counts 4 but is ONE access)
 
 
-def test_lane_decision_first_step_row():
-    """First step of a walk: no prev, every neighbour weighs 1 (w_out passed as 1.0)."""
+@pytest.mark.parametrize("device", BACKENDS)
+def test_lane_decision_first_step_row(device):
+    """First step of a walk: no prev, every neighbour weighs 1 (w_out passed as 1.0).  70000 entries: uint32 positions."""
     rng = np.random.default_rng(11)
     for n in (1, 5, 64, 1000, 70000):
         cls = np.zeros(n, dtype=np.uint8)
         r = np.concatenate([rng.random(2000), (np.arange(1, min(n, 500) + 1) / n)])
         r = np.clip(r, 0.0, np.nextafter(1.0, 0.0))
-        chain, lane, kmax = lane_decide(cls, 1.0, 2.0, r)
-        ok = lane != LANE_AMBIGUOUS
-        assert np.array_equal(lane[ok], chain[ok])
-        assert ((chain[~ok] < kmax[~ok]) | (chain[~ok] == n)).all()
+        run = LaneRun(cls, 1.0, 2.0, r, device)
+        ok = run.lane != LANE_AMBIGUOUS
+        assert np.array_equal(run.lane[ok], run.chain[ok])
+        assert ((run.chain[~ok] < run.kmax[~ok]) | (run.chain[~ok] == n)).all()
 
 
 def test_lane_decision_row_outside_exact_range_is_redone():
     cls = np.zeros(40, dtype=np.uint8)
     cls[3] = 2
-    _, lane, _ = lane_decide(cls, 2.0 ** -30, 1.0, np.array([0.3]))   # total 39 * 2^-30 + 1 is not a float32
-    assert lane[0] == LANE_REDO
-
-
-@pytest.mark.parametrize("w_out,w_prev", BIASES)
-def test_refined_decision_of_ambiguous_steps(w_out, w_prev):
-    """lane_refine computes the drift of the float32 chain from per-binade class counts instead of bounding it: whatever
-    it decides must be the chain's answer -- on uniform targets and on targets placed exactly on / one ulp around
-    every float32 partial sum, where a drift estimate that is off by one ulp flips the answer -- and it must settle
-    most of the steps the a-priori bound leaves open."""
-    rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 99)
-    amb_u = res_u = 0
-    for n in (3, 40, 65, 300, 1500, 6000, 20000):
-        for p_common in (0.0, 0.02, 0.3, 0.9):
-            for with_prev in (False, True):
-                cls = random_row(rng, n, p_common, with_prev)
-                c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
-                cd = c32.astype(np.float64)
-                sub = slice(None, None, max(1, n // 600))
-                targets = [rng.random(1500), cd[sub], np.nextafter(cd[sub], 0.0), np.nextafter(cd[sub], 2.0), exact_cdf[sub],
-                           np.nextafter(exact_cdf[sub], 0.0), np.nextafter(exact_cdf[sub], 2.0)]
-                r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
-                chain, lane, _ = lane_decide(cls, w_out, w_prev, r)
-                ref = lane_decide.refined
-                amb = lane == LANE_AMBIGUOUS
-                assert np.array_equal(ref[~amb], lane[~amb])
-                settled = amb & (ref != LANE_AMBIGUOUS)
-                assert np.array_equal(ref[settled], chain[settled]), (n, p_common, with_prev, w_out, w_prev)
-                amb_u += int(amb[:1500].sum())
-                res_u += int(settled[:1500].sum())
-    assert amb_u == 0 or res_u / amb_u > 0.5
-
-
-def lane_tight(cls, w_out, w_prev, r):
-    lib = _lib.load()
-    cls = np.ascontiguousarray(cls, dtype=np.uint8)
-    r = np.ascontiguousarray(r, dtype=np.float64)
-    chain = np.empty(r.size, dtype=np.uint32)
-    lane = np.empty(r.size, dtype=np.uint32)
-    tight = np.empty(r.size, dtype=np.uint32)
-    _lib.check(lib.pw_selftest_lane_tight(cls.ctypes.data_as(C.c_void_p), cls.size, w_out, w_prev,
-                                          r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
-                                          lane.ctypes.data_as(C.c_void_p), tight.ctypes.data_as(C.c_void_p)))
-    return chain, lane, tight
+    run = LaneRun(cls, 2.0 ** -30, 1.0, np.array([0.3]), False)   # total 39 * 2^-30 + 1 is not a float32
+    assert run.lane[0] == LANE_REDO
 
 
 def structured_rows(rng, n):
@@ -285,39 +242,57 @@ def structured_rows(rng, n):
     return rows
 
 
+def lattice_rows(n):
+    """Rows as a 2^k-regular ring lattice / clique-rich graph produces them: power-of-two degrees, the common
+    neighbours in contiguous blocks around prev, prev in the middle -- totals that are powers of two or one unit
+    off, where float32 values tie in every binade."""
+    rows = []
+    for frac in (0.25, 0.5, 0.75):
+        m = int(n * frac)
+        row = np.zeros(n, dtype=np.uint8)
+        row[(n - m) // 2:(n - m) // 2 + m] = 1
+        row[n // 2] = 2
+        rows.append(row)
+        alt = np.zeros(n, dtype=np.uint8)
+        alt[::2] = 1                                                 # every second neighbour common
+        alt[n // 2 + 1 if n > 2 else 0] = 2
+        rows.append(alt)
+    return rows
+
+
+@pytest.mark.parametrize("device", BACKENDS)
 @pytest.mark.parametrize("w_out,w_prev", BIASES)
-def test_interval_decision_of_ambiguous_steps(w_out, w_prev):
+def test_interval_decision_of_ambiguous_steps(w_out, w_prev, device):
     """lane_tight bounds the float32 chain's systematic drift from the class counts alone (no list access): whatever it
     decides must be the chain's answer -- uniform targets, and targets exactly on / one ulp around every float32
     partial sum and every exact partial sum, where an interval that is one ulp too narrow flips the answer."""
     rng = np.random.default_rng(int(w_out * 64 + w_prev * 1024) + 321)
     amb_u = res_u = 0
     for n in (3, 40, 65, 300, 1500, 4096, 6000, 20000, 70000):
-        for cls in structured_rows(rng, n):
-            c32, exact_cdf = float32_prefix(cls, w_out, w_prev)
-            cd = c32.astype(np.float64)
-            sub = slice(None, None, max(1, n // 500))
-            targets = [rng.random(1000), cd[sub], np.nextafter(cd[sub], 0.0), np.nextafter(cd[sub], 2.0), exact_cdf[sub],
-                       np.nextafter(exact_cdf[sub], 0.0), np.nextafter(exact_cdf[sub], 2.0),
-                       np.array([0.5, 0.25, 0.125, np.nextafter(0.5, 0.0), np.nextafter(0.25, 0.0)])]
-            r = np.clip(np.concatenate(targets), 0.0, np.nextafter(1.0, 0.0))
-            chain, lane, tight = lane_tight(cls, w_out, w_prev, r)
+        for cls in structured_rows(rng, n) + (lattice_rows(n) if n in (4096, 65, 1500) else []):
+            r, _ = adversarial_targets(rng, cls, w_out, w_prev, 1000, stride=max(1, n // 500))
+            run = LaneRun(cls, w_out, w_prev, r, device)
+            chain, lane, tight = run.chain, run.lane, run.tight
             amb = lane == LANE_AMBIGUOUS
             assert np.array_equal(tight[~amb], lane[~amb])
             settled = amb & (tight != LANE_AMBIGUOUS)
             assert np.array_equal(tight[settled], chain[settled]), (n, w_out, w_prev, np.flatnonzero(settled & (tight != chain))[:5])
+            cl_ = run.chain_lane
+            good = (cl_ != LANE_TIE) & (cl_ != LANE_CHAIN_END)
+            assert np.array_equal(cl_[good], chain[good])
             amb_u += int(amb[:1000].sum())
             res_u += int(settled[:1000].sum())
     assert amb_u == 0 or res_u / amb_u > 0.15   # (rows here are dense in common neighbours; hub rows of real graphs: ~0.9)
 
 
-def test_interval_decision_power_of_two_totals():
+@pytest.mark.parametrize("device", BACKENDS)
+def test_interval_decision_power_of_two_totals(device):
     """Row totals 2^k: every value is a power of two, every addition exact -- the interval collapses to a point."""
     rng = np.random.default_rng(5)
     for n in (1024, 4096, 32768):
         cls = np.zeros(n, dtype=np.uint8)           # first step of a walk: all weights 1, total n
         r = np.clip(np.concatenate([rng.random(3000), np.arange(1, 400) / n, np.nextafter(np.arange(1, 400) / n, 0.0)]), 0.0,
                     np.nextafter(1.0, 0.0))
-        chain, lane, tight = lane_tight(cls, 1.0, 2.0, r)
-        ok = tight != LANE_AMBIGUOUS
-        assert np.array_equal(tight[ok], chain[ok])
+        run = LaneRun(cls, 1.0, 2.0, r, device)
+        ok = run.tight != LANE_AMBIGUOUS
+        assert np.array_equal(run.tight[ok], run.chain[ok])

@@ -203,42 +203,6 @@ def test_weighted_normaliser_table_equals_the_two_pass_step(monkeypatch):
         assert table.last_stats["overflow_reads"] == plain.last_stats["overflow_reads"]
 
 
-def test_step_synchronous_path_equals_persistent_lane_kernel(monkeypatch):
-    """PECANPY_AMD_BSP=1 runs the same per-thread routines one launch per step over all walks (step-major state,
-    refinement and chain in their own launches, csrc/walk_bsp.hip.h).  Measured slower than the persistent lane kernel
-     and therefore opt-in -- but it must produce the same matrix, incl. dead ends and overflow walks."""
-    import torch
-
-    indptr, indices, data = rmat_csr(15, seed=9)
-    n = indptr.size - 1
-    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 3)
-    np.random.RandomState(4).shuffle(starts)
-    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
-    eng = WalkEngine.from_csr(indptr, indices, None)
-    for p, q in ((0.5, 2.0), (4.0, 0.25)):
-        a = eng.simulate_device("SparseOTF", p, q, False, d_starts, 40, seed=6)
-        sa = dict(eng.last_stats)
-        monkeypatch.setenv("PECANPY_AMD_BSP", "1")
-        b = eng.simulate_device("SparseOTF", p, q, False, d_starts, 40, seed=6)
-        sb = dict(eng.last_stats)
-        monkeypatch.delenv("PECANPY_AMD_BSP")
-        assert torch.equal(a, b)
-        for k in ("total_steps", "overflow_reads", "ambiguous_steps", "dead_end_walks"):
-            assert sa[k] == sb[k], k
-    # directed graph with sinks: early ends and the repair passes (job lists fall back to the persistent kernel)
-    rng = np.random.default_rng(8)
-    m = 3000
-    src, dst = rng.integers(0, m, 24000), rng.integers(0, m, 24000)
-    keep = (src != dst) & (src % 50 != 0)
-    ip, ix, dt = csr_from_edges(src[keep], dst[keep], m)
-    st = orc.shuffled_starts(m, 2, 3)
-    deng = WalkEngine.from_csr(ip, ix, dt)
-    want = deng.simulate("SparseOTF", 0.25, 4, False, st, 12, seed=3)
-    monkeypatch.setenv("PECANPY_AMD_BSP", "1")
-    got = deng.simulate("SparseOTF", 0.25, 4, False, st, 12, seed=3)
-    assert np.array_equal(got, want)
-
-
 def _hub_graph(rng, n=60000, hub_deg=40000):
     hub = np.arange(1, hub_deg + 1)
     src = [np.zeros(hub.size, dtype=np.int64), rng.integers(1, n, 300000), np.full(3000, 7, dtype=np.int64)]

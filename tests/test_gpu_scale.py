@@ -100,6 +100,26 @@ def test_full_size_lazy_step_equals_eager_step(run, monkeypatch):
         assert torch.equal(a, b), (p, q)
 
 
+@pytest.mark.parametrize("p,q", [(0.5, 2.0), (0.25, 4.0), (2.0, 0.5)])
+def test_full_size_interval_decision_verified_by_the_float_chain(run, p, q, monkeypatch):
+    """PECANPY_AMD_VERIFY_TIGHT=1 at BASELINE size: every step the interval decision (lane_tight) settles -- a tenth of
+    the 1.6e9 transitions -- is decided again on the device by the sequential float32 chain; no step may differ
+    (tests/test_gpu_verify.py runs the same check on graph families built to provoke rounding coincidences)."""
+    import torch
+
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_TIGHT", "1")
+    out = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"], L, seed=SEED)
+    st = dict(run["eng"].last_stats)
+    assert st["lane_kernel"] == 1
+    assert st["verify_mismatch"] == 0 and st["verify_dropped"] == 0, st
+    assert st["verify_checked"] > 0.02 * st["total_steps"], st
+    assert st["verify_checked"] + st["wave_chain_steps"] >= st["ambiguous_steps"] - st["redo_walks"] * L
+    if (p, q) == (0.5, 2.0):
+        assert torch.equal(out, run["out"])
+    print(f"[verify] RMAT-{SCALE} p={p} q={q}: {st['total_steps']} transitions, {st['verify_checked']} re-decided by the chain, "
+          f"{st['verify_ties']} declined")
+
+
 @pytest.mark.parametrize("p,q", [(0.5, 2.0), (0.25, 4.0)])
 def test_full_size_oracle_prefix(run, p, q):
     """BASELINE size against the oracle itself: the first 20 000 jobs of the shuffled job array (stream offset 0,

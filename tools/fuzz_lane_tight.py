@@ -1,6 +1,7 @@
 """Offline fuzz of the interval decision (csrc/seqscan.h: lane_tight) against the sequential float32 chain, on the host:
 random / clustered / periodic rows, ten bias pairs, targets uniform and on / one ulp around float32 and exact partial sums.
-usage: fuzz_lane_tight.py <seed> <seconds>      (prints WRONG lines, if any, and a summary; needs the built library)"""
+usage: fuzz_lane_tight.py <seed> <seconds> [device]     (prints WRONG lines, if any, and a summary; needs the built library;
+`device`: one GPU thread per target instead of the host build of the routines)"""
 import ctypes as C
 import os
 import sys
@@ -14,11 +15,11 @@ lib=_lib.load()
 AMB=0xfffffffd
 def run(cls,w_out,w_prev,r):
     cls=np.ascontiguousarray(cls,dtype=np.uint8); r=np.ascontiguousarray(r,dtype=np.float64)
-    ch=np.zeros(r.size,np.uint32); ln=np.zeros_like(ch); tg=np.zeros_like(ch)
-    rc=lib.pw_selftest_lane_tight(cls.ctypes.data,cls.size,w_out,w_prev,r.ctypes.data,r.size,ch.ctypes.data,ln.ctypes.data,tg.ctypes.data)
+    ch=np.zeros(r.size,np.uint32); ln=np.zeros_like(ch); km=np.zeros_like(ch); tg=np.zeros_like(ch)
+    rc=lib.pw_selftest_lane(DEVICE,0,cls.ctypes.data,cls.size,w_out,w_prev,r.ctypes.data,r.size,ch.ctypes.data,ln.ctypes.data,km.ctypes.data,tg.ctypes.data,None)
     assert rc==0
     return ch,ln,tg
-seed=int(sys.argv[1]); tmax=float(sys.argv[2])
+seed=int(sys.argv[1]); tmax=float(sys.argv[2]); DEVICE=int(len(sys.argv)>3 and sys.argv[3]=='device')
 rng=np.random.default_rng(seed)
 t0=time.time(); it=0; amb=0; settled=0; wrong=0
 biases=[(0.5,2.0),(2.0,0.5),(0.25,4.0),(1.0,1.0),(4.0,0.125),(0.0625,16.0),(8.0,1.0),(0.5,0.5),(0.125,8.0),(1.0,4.0)]
