@@ -323,17 +323,19 @@ def main():
         deg_t = torch.from_numpy(np.diff(indptr.astype(np.int64))).to(dev)
         ref_bytes = reference_format_bytes(d_out, deg_t, L)
     if lane:
-        # declared format of the lane kernel: per sampled step one 32-byte edge record, one
-        # 8-byte draw, one 4-byte output cell, 4 bytes per common-neighbour list entry actually read (counted in
-        # the kernel); per walk: start 4 + stream offset 8 + vertex record 16 + header/length cells 8
+        # declared format of the lane kernel: per sampled step one 64-byte edge line (the record
+        # of the edge the walk arrives by and -- for lists of up to 20 entries -- the list itself), one 8-byte draw, one
+        # 4-byte output cell, 2 bytes per common-neighbour list entry read (counted in the kernel; uint16 positions;
+        # entries read inside the edge line are counted twice, rows beyond 65536 entries use 4 bytes); per walk: start
+        # 4 + stream offset 8 + vertex record 16 + header/length cells 8
         entries = int(acc["list_entries_read"][-1])
         # ... and 128 bytes per step that needs the float32 chain (the walk's queue record, written and read back)
         chain_steps = int(acc["wave_chain_steps"][-1])
-        declared = (steps0 * (32 + 8 + 4) + entries * 4 + chain_steps * 128 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
+        declared = (steps0 * (64 + 8 + 4) + entries * 2 + chain_steps * 128 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
                     (hi - lo - walks0) * 8)
         kernel = "walk_lanes_kernel (every round of a pass) + lanes_chain_kernel"
-        fmt = ("32 B edge record + 8 B draw + 4 B output per step, 4 B per common-neighbour list entry read "
-               "(in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
+        fmt = ("64 B edge line (record + inline list) + 8 B draw + 4 B output per step, 2 B per common-neighbour list entry "
+               "read (in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
     elif cfg["graph"] == "er":
         wpr = (n_nodes + 63) // 64
         declared = steps0 * (3 * wpr * 8 + 12)

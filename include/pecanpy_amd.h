@@ -106,6 +106,11 @@ int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *
 /* Device time (ms) of the index kernels pw_csr_create ran, device bytes of the index, and the number of entries
  * of the lane kernel's common-neighbour lists (0: lane index not built).  Any pointer may be NULL. */
 int pw_graph_index_info(const pw_graph *g, double *build_ms, uint64_t *index_bytes, uint64_t *lane_list_entries);
+/* Test hook: the lane index decoded to flat arrays (any pointer may be NULL).  For every CSR entry e = (u -> v):
+ * n_in[e] = |N(u) & N(v)|, rev_pos[e] = position of u in row v (0xffffffff: v -> u is not an edge); entries = the
+ * positions in row v of those common neighbours, ascending, concatenated in entry order (lane_list_entries values,
+ * pw_graph_index_info).  PW_ERR_UNSUPPORTED when the graph has no lane index (weights, self loops). */
+int pw_lane_index_export(pw_graph *g, uint32_t *n_in, uint32_t *rev_pos, uint32_t *entries);
 
 /* Dense adjacency in the reference's DenseGraph layout (graph.py:576-580): float64[n, n]
  * row-major; nonzero mask = (data != 0). */

@@ -62,6 +62,7 @@ SYMBOLS = {
     "pw_csr_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "pw_graph_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pw_lane_index_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pw_dense_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "pw_dense_create_bits": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pw_graph_set_thresholds": (C.c_int, [C.c_void_p, C.c_void_p]),

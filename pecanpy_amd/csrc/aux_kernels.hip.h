@@ -81,17 +81,27 @@ mt_expand_kernel(const uint32_t *__restrict__ states_in, uint32_t *__restrict__ 
 constexpr int MT_SEQ_BLOCKS = 33;
 constexpr int MT_POLY_WORDS = 312;
 
+// `parts` > 1: the taps of g are split over `parts` workgroups per jump (grid = jumps * parts; the early levels of the
+// jump tree have one, two, four ... jumps and would otherwise leave the GPU idle for ~0.4 ms each); every part folds
+// its slice of the polynomial into tmp[jump][624] with atomicXor (tmp zeroed), mt_jump_store_kernel moves the result
+// into place.  parts == 1: the result is written directly.
 __global__ void __launch_bounds__(640)
 mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly, uint32_t src_stride,
-               uint32_t dst_offset) {
+               uint32_t dst_offset, uint32_t parts, uint32_t *tmp) {
     __shared__ uint32_t seq[MT_SEQ_BLOCKS * 624];
     __shared__ uint64_t spoly[MT_POLY_WORDS];
     const int t = threadIdx.x;
-    const uint64_t src = (uint64_t)blockIdx.x * src_stride;
+    const uint32_t jump = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint64_t src = (uint64_t)jump * src_stride;
+    const int per = (MT_POLY_WORDS + (int)parts - 1) / (int)parts;
+    const int jw0 = (int)part * per, jw1 = jw0 + per < MT_POLY_WORDS ? jw0 + per : MT_POLY_WORDS;
     if (t < 624) seq[t] = states[src * 624 + t];
     if (t < MT_POLY_WORDS) spoly[t] = poly[t];
     __syncthreads();
-    for (int blk = 1; blk < MT_SEQ_BLOCKS; blk++) {
+    // this part reads sequence words up to index (jw1 - 1) * 64 + 63 + 623
+    int need = jw1 > jw0 ? ((jw1 - 1) * 64 + 63 + 623) / 624 + 1 : 1;
+    if (need > MT_SEQ_BLOCKS) need = MT_SEQ_BLOCKS;
+    for (int blk = 1; blk < need; blk++) {
         uint32_t *nw = seq + blk * 624;
         const uint32_t *od = nw - 624;
         if (t < 227) nw[t] = mt_mix_dev(od[t], od[t + 1], od[t + 397]);
@@ -103,7 +113,7 @@ mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly,
     }
     if (t < 624) {
         uint32_t acc = 0;
-        for (int jw = 0; jw < MT_POLY_WORDS; jw++) {
+        for (int jw = jw0; jw < jw1; jw++) {
             uint64_t word = spoly[jw];
             const uint32_t *base = seq + t + jw * 64;
             while (word) {
@@ -112,8 +122,18 @@ mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly,
                 acc ^= base[b];
             }
         }
-        states[(src + dst_offset) * 624 + t] = acc;
+        if (parts == 1) states[(src + dst_offset) * 624 + t] = acc;
+        else if (acc) atomicXor(&tmp[(uint64_t)jump * 624 + t], acc);
     }
+}
+
+__global__ void __launch_bounds__(640)
+mt_jump_store_kernel(uint32_t *__restrict__ states, uint32_t *tmp, uint32_t src_stride, uint32_t dst_offset) {
+    const int t = threadIdx.x;
+    if (t >= 624) return;
+    const uint64_t src = (uint64_t)blockIdx.x * src_stride;
+    states[(src + dst_offset) * 624 + t] = tmp[(uint64_t)blockIdx.x * 624 + t];
+    tmp[(uint64_t)blockIdx.x * 624 + t] = 0;   // zero again for the next level
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,37 +186,6 @@ adj_index_build_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__re
             }
         }
     }
-}
-
-// per-edge common-neighbour counts tri[e] = |N(u) & N(v)| for e = (u -> v): one lane per CSR entry walks
-// the shorter of the two rows through the longer row's filter + adjacency index.
-__global__ void __launch_bounds__(256)
-tri_build_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, uint4 *tri) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.nnz) return;
-    const uint32_t u = edge_row[e], v = g.indices[e];
-    const uint32_t su = g.indptr[u], du = g.indptr[u + 1] - su;
-    const uint32_t sv = g.indptr[v], dv = g.indptr[v + 1] - sv;
-    const bool u_short = du <= dv;
-    const uint32_t ks = u_short ? su : sv, kn = u_short ? du : dv;   // keys: the shorter row
-    const uint32_t w = u_short ? v : u;                               // searched vertex
-    const uint32_t f0 = g.foff[w], nw_mask = g.foff[w + 1] - f0 - 1u;
-    const uint64_t tb0 = g.tab_off[w];
-    const uint32_t tmask = (uint32_t)(g.tab_off[w + 1] - tb0) - 1u;
-    uint32_t cnt = 0;
-    for (uint32_t i = 0; i < kn; i++) {
-        const uint2 kfw = g.kf[ks + i];
-        const uint64_t word = g.fbits[f0 + filter_word(kfw.y, nw_mask)];
-        if (filter_pass(word, kfw.y) && adj_lookup(g.slots + tb0, tmask, kfw.x, true) != 0xffffffffu) cnt++;
-    }
-    // position of the reverse edge: u in row v
-    uint32_t rev = 0xffffffffu;
-    if (dv) {   // a vertex without out-edges owns no index slots
-        const uint64_t vtb = g.tab_off[v];
-        const uint32_t vmask = (uint32_t)(g.tab_off[v + 1] - vtb) - 1u;
-        rev = adj_lookup(g.slots + vtb, vmask, u, true);
-    }
-    tri[e] = make_uint4(v, cnt, rev, dv);
 }
 
 // Input checks of pw_csr_create, one lane per CSR entry (the reference's isnotin needs

@@ -90,10 +90,13 @@ struct pw_graph {
     uint64_t *d_fbits = nullptr;
     uint2 *d_kf = nullptr;           // CSR graphs: (neighbour id, filter word) per CSR entry
     uint64_t *d_tab_off = nullptr, *d_slots = nullptr;  // CSR graphs: adjacency index (exact lookups)
-    uint4 *d_tri = nullptr;                             // CSR graphs: per-edge {neighbour, common-neighbour count, reverse position, degree}
     uint4 *d_vrec = nullptr;                            // CSR graphs: per-vertex record (row start, degree, filter, index)
-    pw::ERec *d_erec = nullptr;                         // lane kernel (walk_lanes.hip.h): 32-byte record per CSR entry
-    uint32_t *d_clist = nullptr;                        // lane kernel: per-edge positions of the common neighbours
+    pw::ELine *d_lines = nullptr;                       // lane index (walk_lanes.hip.h): 64-byte edge line per CSR entry; its first 16 bytes
+                                                        // {neighbour, common-neighbour count, reverse position, degree} also serve walk_kernel's lazy step
+    uint8_t *d_clist = nullptr;                         // lane index: the lists too long for their edge line
+    uint64_t clist_bytes = 0;
+    bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
+                                                        // built (the wave kernel's lazy step reads it) but the lane kernel is not used
     float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
     double tot_p = 0, tot_q = 0;                        // ... built for these parameters
     int tot_extend = -1;                                // -1: none yet
@@ -125,6 +128,7 @@ struct pw_graph {
     DevBuf<pw::VerRec> ver, ver_bad;
     uint64_t ver_checked = 0, ver_mismatch = 0, ver_dropped = 0, ver_ties = 0;   // ... of the current call
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
+    DevBuf<uint32_t> jump_tmp;    // partial results of jumps whose taps are split over several workgroups (kept zeroed)
     bool jump_table_ready = false;
     DevBuf<unsigned long long> counters;  // [0] job counter [1..4] stats [5] changed count
     // alias tables (PreComp modes)
@@ -215,9 +219,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_kf) (void)hipFree(g->d_kf);
     if (g->d_tab_off) (void)hipFree(g->d_tab_off);
     if (g->d_slots) (void)hipFree(g->d_slots);
-    if (g->d_tri) (void)hipFree(g->d_tri);
     if (g->d_vrec) (void)hipFree(g->d_vrec);
-    if (g->d_erec) (void)hipFree(g->d_erec);
+    if (g->d_lines) (void)hipFree(g->d_lines);
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
@@ -232,6 +235,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->mt_state.release();
     for (auto &c : g->mt_cache) c.states.release();
     g->jump_table.release();
+    g->jump_tmp.release();
     g->changed.release();
     g->counters.release();
     g->alias_indptr.release();
@@ -265,56 +269,108 @@ static int graph_common_init(pw_graph *g, int device) {
 
 static pw::CsrDev csr_dev(const pw_graph *g);
 
-// Lane-kernel index (walk_lanes.hip.h): per-edge lists of common-neighbour positions + 32-byte edge records, from
-// the per-edge counts of tri_build_kernel.  Skipped (the wave-per-walk kernel then serves every call) when the
-// lists would not fit comfortably into free device memory or PECANPY_AMD_NO_LANES is set.
-static int build_lane_index(pw_graph *g, const uint32_t *d_edge_row) {
-    if (getenv("PECANPY_AMD_NO_LANES") || !g->d_tri || !g->nnz) return 0;
-    const uint32_t nnz = g->nnz;
-    const uint64_t n_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
-    uint64_t *d_tiles = nullptr, *d_coff = nullptr;
-    auto cleanup = [&]() {
-        if (d_tiles) (void)hipFree(d_tiles);
-        if (d_coff) (void)hipFree(d_coff);
-    };
-    hipError_t e = hipMalloc((void **)&d_tiles, sizeof(uint64_t) * (n_tiles + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_coff, sizeof(uint64_t) * (size_t)nnz);
-    uint64_t total = 0;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(pw::clist_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_tri, nnz, d_tiles);
-        hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
-        hipLaunchKernelGGL(pw::clist_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_tri, nnz, d_tiles, d_coff);
-        e = hipMemcpyAsync(&total, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+// Lane-kernel index (walk_lanes.hip.h): one 64-byte edge line per CSR entry (the record of the edge + its list of
+// common-neighbour positions when that is short) and the overflow array of the longer lists.  One set intersection per
+// adjacent pair, row of the larger endpoint in LDS (lane_lists_kernel: count pass, offsets, fill pass).  Skipped (the
+// wave-per-walk kernel then serves every call, eager step) when lines + lists would take more than half of the free
+// device memory.  `indptr` = the caller's host array.
+static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t *d_edge_row) {
+    if (!g->nnz) return 0;
+    const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
+    // work items: one per (vertex, segment of its row, chunk of its neighbours)
+    std::vector<pw::LaneBuildItem> small, large;
+    uint64_t segcnt_total = 0;
+    const uint32_t JCHUNK = 16384;
+    for (uint32_t h = 0; h < n_nodes; h++) {
+        const uint32_t d = indptr[h + 1] - indptr[h];
+        if (d < 2) continue;   // one neighbour k: N(h) & N(k) = {k} & N(k) is empty without self loops
+        if (d <= (uint32_t)pw::LB_SMALL) { small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
+        const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
+        uint32_t m0 = 0;
+        if (nseg > 1) { m0 = (uint32_t)segcnt_total; segcnt_total += (uint64_t)d * nseg; }
+        for (uint32_t sg = 0; sg < nseg; sg++)
+            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
     }
-    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("lane index (offsets): ") + hipGetErrorString(e)); }
+    if (segcnt_total >= 0xffffffffull) return 0;   // (rows this long and this many: no lane index)
+    // the longest rows first (their workgroups run longest)
+    std::stable_sort(large.begin(), large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
+        return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];
+    });
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const uint64_t need = total * sizeof(uint32_t) + (uint64_t)nnz * sizeof(pw::ERec);
-    if (need > free_b / 2) { cleanup(); return 0; }   // leave room for the stream and the walk matrix
-    e = hipMalloc((void **)&g->d_clist, sizeof(uint32_t) * (size_t)(total + 4));   // + the reach of one search window
-    if (e == hipSuccess) e = hipMalloc((void **)&g->d_erec, sizeof(pw::ERec) * (size_t)nnz);
-    if (e == hipSuccess) {
-        pw::CsrDev c = csr_dev(g);
-        hipLaunchKernelGGL(pw::clist_fill_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c,
-                           d_edge_row, d_coff, g->d_clist, g->d_erec);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-    }
-    cleanup();
-    if (e != hipSuccess) {
-        // no lane index: the wave-per-walk kernel serves every call (an allocation failure is not an error)
-        const bool oom = e == hipErrorOutOfMemory;
+    const uint64_t line_bytes = (uint64_t)nnz * sizeof(pw::ELine) + 64;
+    if (line_bytes > free_b / 2) return 0;
+    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
+    uint32_t *d_segcnt = nullptr;
+    uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
+    const uint64_t n_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles})
+            if (q) (void)hipFree(q);
+    };
+    auto drop = [&](int rc) {   // no lane index
+        cleanup();
+        if (g->d_lines) (void)hipFree(g->d_lines);
         if (g->d_clist) (void)hipFree(g->d_clist);
-        if (g->d_erec) (void)hipFree(g->d_erec);
+        g->d_lines = nullptr;
         g->d_clist = nullptr;
-        g->d_erec = nullptr;
         (void)hipGetLastError();
-        if (oom) return 0;
-        return fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e));
-    }
-    g->n_clist = total;
-    g->index_bytes += need;
+        return rc;
+    };
+    hipError_t e = hipMalloc((void **)&g->d_lines, line_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_small, sizeof(pw::LaneBuildItem) * (small.size() + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_large, sizeof(pw::LaneBuildItem) * (large.size() + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_segcnt, sizeof(uint32_t) * (size_t)(segcnt_total + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, sizeof(uint64_t) * (n_tiles + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_etiles, sizeof(uint64_t) * (n_tiles + 1));
+    if (e == hipSuccess && !small.empty())
+        e = hipMemcpyAsync(d_small, small.data(), sizeof(pw::LaneBuildItem) * small.size(), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess && !large.empty())
+        e = hipMemcpyAsync(d_large, large.data(), sizeof(pw::LaneBuildItem) * large.size(), hipMemcpyHostToDevice, g->stream);
+    if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index: ") + hipGetErrorString(e)));
+    pw::CsrDev c = csr_dev(g);
+    pw::LaneBuildArgs ba;
+    ba.indptr = g->d_indptr;
+    ba.indices = g->d_indices;
+    ba.lines = g->d_lines;
+    ba.clist = nullptr;
+    ba.segcnt = d_segcnt;
+    hipLaunchKernelGGL(pw::eline_init_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c, d_edge_row, g->d_lines);
+    auto lists = [&](bool fill) {
+        if (!large.empty()) {
+            if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
+            else hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
+        }
+        if (!small.empty()) {
+            if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, true>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
+            else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
+        }
+    };
+    lists(false);
+    hipLaunchKernelGGL(pw::clist_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles, d_etiles);
+    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
+    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_etiles, n_tiles);
+    hipLaunchKernelGGL(pw::clist_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles);
+    uint64_t units = 0, entries = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&units, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&entries, d_etiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (count pass): ") + hipGetErrorString(e)));
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint64_t list_bytes = units * 16 + 64;
+    if (units >= 0xffffffffull || list_bytes > free_b / 2) return drop(0);   // leave room for the stream and the walk matrix
+    e = hipMalloc((void **)&g->d_clist, list_bytes);
+    if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e)));
+    ba.clist = g->d_clist;
+    lists(true);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (fill pass): ") + hipGetErrorString(e)));
+    cleanup();
+    g->n_clist = entries;
+    g->clist_bytes = list_bytes;
+    g->index_bytes += line_bytes + list_bytes;
     return 0;
 }
 
@@ -426,19 +482,10 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
     if (g->unit && nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {
-        // per-edge common-neighbour counts (lazy membership of the unit-weight kernels); skipped for graphs
-        // with self loops, where "common neighbour" and the reference's prev handling differ
-        e = hipMalloc((void **)&g->d_tri, sizeof(uint4) * (size_t)nnz);
-        if (e == hipSuccess) {
-            pw::CsrDev c = csr_dev(g);
-            hipLaunchKernelGGL(pw::tri_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
-                               c, d_edge_row, g->d_tri);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-        }
-        if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("common-neighbour counts: ") + hipGetErrorString(e));
-        g->index_bytes += sizeof(uint4) * (uint64_t)nnz;
-        rc = build_lane_index(g, d_edge_row);
+        // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel); skipped for
+        // graphs with self loops, where "common neighbour" and the reference's prev handling differ
+        g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
+        rc = build_lane_index(g, indptr, d_edge_row);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
     (void)hipEventRecord(g->ev[1], g->stream);
@@ -455,7 +502,43 @@ PW_EXPORT int pw_graph_index_info(const pw_graph *g, double *build_ms, uint64_t 
     if (!g) return fail(PW_ERR_INVALID, "null pointer");
     if (build_ms) *build_ms = g->index_build_ms;
     if (index_bytes) *index_bytes = g->index_bytes;
-    if (lane_list_entries) *lane_list_entries = g->d_erec ? g->n_clist : 0;
+    if (lane_list_entries) *lane_list_entries = g->d_lines ? g->n_clist : 0;
+    return PW_OK;
+}
+
+// Test hook: the lane index decoded to flat arrays -- per CSR entry e = (u -> v) the number of common neighbours of u
+// and v, the position of u in row v (0xffffffff: no reverse entry), and -- concatenated in entry order -- the positions
+// in row v of the common neighbours.
+PW_EXPORT int pw_lane_index_export(pw_graph *g, uint32_t *n_in, uint32_t *rev_pos, uint32_t *entries) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (!g->d_lines) return fail(PW_ERR_UNSUPPORTED, "this graph has no lane index");
+    if (set_device(g)) return PW_ERR_HIP;
+    const uint32_t nnz = g->nnz;
+    std::vector<pw::ELine> lines(nnz);
+    HIP_TRY(hipMemcpy(lines.data(), g->d_lines, sizeof(pw::ELine) * (size_t)nnz, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off((size_t)nnz + 1, 0);
+    for (uint32_t e = 0; e < nnz; e++) {
+        if (n_in) n_in[e] = lines[e].n_in;
+        if (rev_pos) rev_pos[e] = lines[e].rev_pos;
+        off[e + 1] = off[e] + lines[e].n_in;
+    }
+    if (off[nnz] != g->n_clist) return fail(PW_ERR_HIP, "lane index: entry count mismatch");
+    if (!entries || !off[nnz]) return PW_OK;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_off, sizeof(uint64_t) * off.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(uint32_t) * (size_t)off[nnz]);
+    if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pw::lane_index_export_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                           g->d_lines, g->d_clist, nnz, d_off, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess) e = hipMemcpy(entries, d_out, sizeof(uint32_t) * (size_t)off[nnz], hipMemcpyDeviceToHost);
+    if (d_off) (void)hipFree(d_off);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("pw_lane_index_export: ") + hipGetErrorString(e));
     return PW_OK;
 }
 
@@ -636,7 +719,7 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.kf = g->d_kf;
     c.tab_off = g->d_tab_off;
     c.slots = g->d_slots;
-    c.tri = g->d_tri;
+    c.tri = (const uint4 *)g->d_lines;   // (stride: one 64-byte line per CSR entry)
     c.vrec = g->d_vrec;
     c.words_per_row = g->words_per_row;
     c.n_nodes = g->n_nodes;
@@ -865,7 +948,7 @@ static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
 }
 
 static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
-    return g->kind == 0 && g->unit && g->d_erec && wa.lazy_ok && !getenv("PECANPY_AMD_NO_LANES");
+    return g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && wa.lazy_ok && !getenv("PECANPY_AMD_NO_LANES");
 }
 
 // One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
@@ -874,7 +957,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
     pw::LanesArgs la;
-    la.erec = g->d_erec;
+    la.lines = g->d_lines;
     la.clist = g->d_clist;
     la.vrec = g->d_vrec;
     la.nnz = g->nnz;
@@ -967,7 +1050,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
             if (n_chk) {
                 HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
                 hipLaunchKernelGGL(pw::lanes_verify_kernel, dim3((unsigned)((n_chk + 255) / 256)), dim3(256), 0, g->stream, g->ver.p,
-                                   (uint64_t)n_chk, g->d_clist, wa.w_prev, g->counters.p + 40, g->ver_bad.p, 16u);
+                                   (uint64_t)n_chk, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 40, g->ver_bad.p, 16u);
                 HIP_TRY(hipGetLastError());
                 unsigned long long vc[4] = {0, 0, 0, 0};
                 HIP_TRY(hipMemcpyAsync(vc, g->counters.p + 40, sizeof(vc), hipMemcpyDeviceToHost, g->stream));
@@ -989,7 +1072,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         HIP_TRY(hipStreamSynchronize(g->stream));
         if (parked) {   // settle the queue just filled
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
-                               g->susp[round & 1].p, (uint64_t)parked, g->d_clist, wa.w_prev, g->counters.p + 1);
+                               g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(g->ev[5], g->stream));
@@ -1111,10 +1194,23 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     uint32_t *const mt_states = mc->states.p;
     HIP_TRY(hipEventRecord(g->ev[0], g->stream));
     if (!mt_hit) {
+        // a jump's polynomial taps are split over several workgroups while a level has fewer jumps than CUs
+        if (!g->jump_tmp.p) {
+            if (g->jump_tmp.ensure((size_t)256 * pw::MT_N)) return PW_ERR_NOMEM;
+            HIP_TRY(hipMemsetAsync(g->jump_tmp.p, 0, sizeof(uint32_t) * 256 * pw::MT_N, g->stream));
+        }
+        auto jump = [&](uint32_t jumps, const uint64_t *poly, uint32_t src_stride, uint32_t dst_offset) {
+            uint32_t parts = jumps >= 128 ? 1u : (uint32_t)(g->n_cu > 0 ? g->n_cu : 256) / jumps;
+            if (parts > 39) parts = 39;
+            if (parts < 1) parts = 1;
+            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
+                               dst_offset, parts, g->jump_tmp.p);
+            if (parts > 1)
+                hipLaunchKernelGGL(pw::mt_jump_store_kernel, dim3(jumps), dim3(640), 0, g->stream, mt_states, g->jump_tmp.p,
+                                   src_stride, dst_offset);
+        };
         for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
-            if ((first_block >> m) & 1)
-                hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(1), dim3(640), 0, g->stream, mt_states,
-                                   g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
+            if ((first_block >> m) & 1) jump(1u, g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
         uint32_t top = 1;
         int top_log = 0;
         while (top < n_gen) { top <<= 1; top_log++; }
@@ -1124,8 +1220,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
             uint32_t pairs = (n_gen - s + 2 * s - 1) / (2 * s);
             int m = lvl + per_gen_log;
             if (m > pw::MtJump::MAX_POW2) return fail(PW_ERR_INVALID, "stream too long");
-            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(pairs), dim3(640), 0, g->stream, mt_states,
-                               g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
+            jump(pairs, g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
         }
         mc->valid = true;
         mc->seed = seed; mc->first_block = first_block; mc->per_gen_log = per_gen_log; mc->n_gen = n_gen;
@@ -1221,6 +1316,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
                              &n_changed);
         if (rc) return rc;
         if (give_up) st.stream_addressing = 1;
+        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu: %llu jobs re-addressed%s\n", (unsigned long long)st.repair_rounds, (unsigned long long)n_changed, give_up ? " (nominal slots)" : "");
         if (n_changed == 0) break;
         st.repair_rounds++;
         wa.job_list = g->changed.p;

@@ -36,24 +36,26 @@
 
 namespace pw {
 
-struct ERec {
+// Edge line of CSR entry e = (u -> v): one 64-byte aligned record -- everything a step needs about the edge it
+// arrives by and, for the short lists that most steps meet, the list itself: ONE sector per step for both.
+struct ELine {
     uint32_t nxt;       // v
     uint32_t n_in;      // |N(u) & N(v)|
     uint32_t rev_pos;   // position of u in row v, NOT_FOUND when (v -> u) is not an edge
-    uint32_t deg;       // degree(v)
+    uint32_t deg;       // degree(v)       (these four words: the record walk_kernel's lazy step reads)
     uint32_t s0;        // indptr[v]
-    uint32_t coff_lo;   // clist offset of this edge's list (64 bit)
-    uint32_t coff_hi;
-    uint32_t pad;
+    uint32_t coff;      // list in the overflow array: offset in 16-byte units (n_in > EL_INLINE or degree(v) > 65536)
+    uint16_t inl[20];   // the list itself when n_in <= EL_INLINE and degree(v) <= 65536: uint16 positions in row v
 };
-static_assert(sizeof(ERec) == 32, "edge record is two 16-byte loads");
+static_assert(sizeof(ELine) == 64, "edge line is one 64-byte sector");
+constexpr uint32_t EL_INLINE = 20;
 
 // A walk parked at a step that only the float32 chain can settle: everything the step and the rest of the walk
 // need.  The lane kernel appends these to a queue instead of running the chain with a handful of its 64 lanes enabled;
 // lanes_chain_kernel settles a whole queue at full width (choice), and the next lane launch resumes the walks.
 struct SuspRec {
     uint32_t job, j, s0, d;
-    uint32_t n_in, pp, coff_lo, coff_hi;
+    uint32_t n_in, pp, e, coff;               // (e: CSR entry the walk arrived by -- its edge line may hold the list)
     uint32_t kmax, choice, soff_lo, soff_hi;   // (soff: position of the walk's draws in this call's stream block)
     float tot, wo;
     double r;
@@ -63,15 +65,23 @@ static_assert(sizeof(SuspRec) == 64, "queue record is four 16-byte accesses");
 // A step the interval decision (lane_tight) settled, kept for verification: what lane_chain needs to decide it again.
 struct VerRec {
     uint32_t kmax, n_in, pp, choice;
-    uint32_t coff_lo, coff_hi, d, pad;
+    uint32_t e, coff, d, pad;
     float tot, wo;
     double r;
 };
 static_assert(sizeof(VerRec) == 48, "verification record is three 16-byte stores");
 
+// the list of common-neighbour positions of the edge a walk arrived by (n_in == 0: never dereferenced)
+__device__ __forceinline__ ListView edge_list(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t d, uint32_t n_in,
+                                              uint32_t coff) {
+    const bool narrow = d <= 65536u;
+    const uint8_t *p = (narrow && n_in <= EL_INLINE) ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+    return ListView{p, narrow ? 0u : 1u};
+}
+
 struct LanesArgs {
-    const ERec *__restrict__ erec;
-    const uint32_t *__restrict__ clist;
+    const ELine *__restrict__ lines;
+    const uint8_t *__restrict__ clist;
     const uint4 *__restrict__ vrec;           // { indptr[v], degree(v), .. } (walk_sparse.hip.h)
     uint32_t nnz;
     uint32_t L;
@@ -148,8 +158,10 @@ __device__ unsigned long long g_lprof[16];
             row_[L + 1] = A.j;                                                                  \
             A.flags = 0;                                                                        \
         } else {                                                                                \
-            const uint4 *rp_ = (const uint4 *)(a.erec + ((uint64_t)A.s0 + choice));             \
-            const uint4 r0_ = rp_[0], r1_ = rp_[1];                                             \
+            A.e = A.s0 + choice;                                                                \
+            const uint4 *rp_ = (const uint4 *)(a.lines + A.e);                                  \
+            const uint4 r0_ = rp_[0];                                                           \
+            const uint2 r1_ = *(const uint2 *)(rp_ + 1);                                        \
             {   /* output cells are staged four steps at a time: one 16-byte store instead of four 4-byte ones */ \
                 const uint32_t slot_ = (A.j - 1u) & 3u;                                         \
                 ob.v[0] = slot_ == 0u ? r0_.x : ob.v[0];                                        \
@@ -166,7 +178,7 @@ __device__ unsigned long long g_lprof[16];
                 }                                                                               \
             }                                                                                   \
             A.n_in = r0_.y; A.pp = r0_.z; A.d = r0_.w;                                          \
-            A.s0 = r1_.x; A.coff = ((uint64_t)r1_.z << 32) | r1_.y;                             \
+            A.s0 = r1_.x; A.coff = r1_.y;                                                       \
             n_steps++;                                                                          \
             A.j++;                                                                              \
             if (A.j > L || A.d == 0) {                                                          \
@@ -208,13 +220,13 @@ walk_lanes_kernel(LanesArgs a) {
         uint32_t job, j;                 // j = index of the step being sampled (1..L)
         uint64_t soff;
         uint32_t s0, d, n_in, pp;        // row of the current vertex; edge it was entered by
-        uint64_t coff;
+        uint32_t e, coff;                // ... its CSR entry and the offset of its list
         uint32_t flags;                  // bit 0: active, bit 2: waiting for the float chain, bit 3: resumed
     };
     constexpr uint32_t F_ACTIVE = 1u, F_WAIT2 = 4u;   // waiting for the float chain (in-place form)
     constexpr uint32_t F_PRE = 8u;                    // resumed walk: the pending step's choice is known (pre)
     uint32_t pre = 0;
-    Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0};
+    Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
     bool exhausted = false;
     uint64_t pool_lo = 0, pool_hi = 0;   // wavefront-uniform: job indices reserved from the shared counter
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
@@ -256,7 +268,7 @@ walk_lanes_kernel(LanesArgs a) {
                     const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
                     if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
                         A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
-                        A.n_in = q1.x; A.pp = q1.y; A.coff = ((uint64_t)q1.w << 32) | q1.z;
+                        A.n_in = q1.x; A.pp = q1.y; A.e = q1.z; A.coff = q1.w;
                         pre = q2.y;
                         A.soff = ((uint64_t)q2.w << 32) | q2.z;
                         const uint32_t slot = (A.j - 1u) & 3u;      // staged output cells of the group in progress
@@ -278,7 +290,7 @@ walk_lanes_kernel(LanesArgs a) {
                             for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                     } else {
                         A.soff = a.stream_off[A.job] - a.rng_base;
-                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.coff = 0; A.j = 1;
+                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
                         r = a.rng[A.soff];
                         A.flags = F_ACTIVE;
                     }
@@ -299,7 +311,7 @@ walk_lanes_kernel(LanesArgs a) {
         if (runnable) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
             // (r = this step's draw: loaded when the previous step was applied / the walk was started)
-            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, ListView{a.clist + A.coff, 1u}, ls);
+            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), ls);
             n_probes += ls.probes;
             if (choice == LANE_AMBIGUOUS) n_amb++;
         }
@@ -322,7 +334,7 @@ walk_lanes_kernel(LanesArgs a) {
                     if (rec && slot < a.ver_cap) {
                         uint4 *vp = (uint4 *)(a.ver + slot);
                         vp[0] = make_uint4(ls.kmax, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
-                        vp[1] = make_uint4((uint32_t)A.coff, (uint32_t)(A.coff >> 32), A.d, 0u);
+                        vp[1] = make_uint4(A.e, A.coff, A.d, 0u);
                         vp[2] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                            (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
                     }
@@ -354,7 +366,7 @@ walk_lanes_kernel(LanesArgs a) {
                     const uint64_t rk = (uint64_t)__popcll(pm & lane_lt);
                     uint4 *qp = (uint4 *)(a.susp + (rk < left ? old_lo + rk : new_lo + (rk - left)));
                     qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
-                    qp[1] = make_uint4(A.n_in, A.pp, (uint32_t)A.coff, (uint32_t)(A.coff >> 32));
+                    qp[1] = make_uint4(A.n_in, A.pp, A.e, A.coff);
                     qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
                     qp[3] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                        (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
@@ -379,7 +391,8 @@ walk_lanes_kernel(LanesArgs a) {
                     // the float32 chain over the first kmax positions, by this lane alone (seqscan.h: lane_chain)
                     const float x_in = 1.0f / tot;
                     uint32_t reads = 0;
-                    const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev, ListView{a.clist + A.coff, 1u}, reads);
+                    const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev,
+                                                    edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), reads);
                     n_probes += reads;
                     choice = res;
                     if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
@@ -420,7 +433,8 @@ walk_lanes_kernel(LanesArgs a) {
 
 // ---- the float32 chains of a whole queue of parked walks, one lane each, every lane busy ------------------------------
 __global__ void __launch_bounds__(256)
-lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, float w_prev, unsigned long long *stats) {
+lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
+                   unsigned long long *stats) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long reads_l = 0, done = 0;
     if (i < n) {
@@ -432,7 +446,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, f
         const float x_in = 1.0f / tot;
         uint32_t reads = 0;
         const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev,
-                                        ListView{clist + (((uint64_t)q1.w << 32) | q1.z), 1u}, reads);
+                                        edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w), reads);
         uint32_t choice = res;
         if (res == LANE_CHAIN_END || res == LANE_TIE) choice = q0.w;   // overflow read / tie budget: the wave kernel redoes the walk
         q[i].choice = choice;
@@ -454,8 +468,8 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const uint32_t *__restrict__ clist, f
 // counts: [0] records checked [1] MISMATCHES (lane_tight's position != the chain's) [2] chains that declined (tie budget)
 // bad: the first few mismatching records, for the error message
 __global__ void __launch_bounds__(256)
-lanes_verify_kernel(const VerRec *q, uint64_t n, const uint32_t *__restrict__ clist, float w_prev, unsigned long long *counts,
-                    VerRec *bad, uint32_t bad_cap) {
+lanes_verify_kernel(const VerRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
+                    unsigned long long *counts, VerRec *bad, uint32_t bad_cap) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long chk = 0, mis = 0, tie = 0;
     if (i < n) {
@@ -466,7 +480,7 @@ lanes_verify_kernel(const VerRec *q, uint64_t n, const uint32_t *__restrict__ cl
         const float x_in = 1.0f / tot;
         uint32_t reads = 0;
         const uint32_t res = lane_chain(q0.x, q0.y, q0.z, r, x_in, x_in * wo, x_in * w_prev,
-                                        ListView{clist + (((uint64_t)q1.y << 32) | q1.x), 1u}, reads);
+                                        edge_list(lines, clist, q1.x, q1.z, q0.y, q1.y), reads);
         chk = 1;
         if (res == LANE_TIE) tie = 1;
         else if (res != q0.w) {
@@ -488,37 +502,248 @@ lanes_verify_kernel(const VerRec *q, uint64_t n, const uint32_t *__restrict__ cl
 }
 
 // ---- index build ------------------------------------------------------------------------------------------------
-// clist / erec from the per-edge records of tri_build_kernel (tri[e] = {v, count, reverse position, degree(v)}).
+// One set intersection per adjacent PAIR {h, k}, by the endpoint with the longer row (ties: the larger id): row h
+// waits in LDS (sorted ids, 8192 at a time), the neighbours k of h stream their rows through it (coalesced reads,
+// binary search in LDS -- no hash table, no filter, no global random access), and every common neighbour w yields both
+// lists at once: its position in row k goes to the list of (h -> k), its position in row h to the list of (k -> h).
+// Two passes of the same kernel: COUNT (n_in of both entries), then -- after the offsets of the long lists are known --
+// FILL.  Round 2 ran four intersections per pair (count and fill for each direction) through a global hash index:
+// 323 + 349 ms at RMAT-22.
+//
+// Entries whose reverse edge is absent (directed graphs) are handled by their source.  Rows longer than LB_SEG are
+// processed LB_SEG positions at a time by separate workgroups ("segments": the ids of a segment are a contiguous id
+// range, a neighbour's keys inside that range a contiguous sub-row found by two binary searches); the per-segment
+// counts of such rows are kept (segcnt) so that FILL knows where a segment's block of a list starts.
+constexpr int LB_SEG = 8192;      // row positions per workgroup (32 KB of LDS)
+constexpr int LB_SMALL = 256;     // rows up to this length: one wavefront per row
+constexpr uint32_t LB_SEQ = 32;   // neighbour rows up to this length are walked by ONE thread, longer ones by a wavefront
+
+struct LaneBuildArgs {
+    const uint32_t *__restrict__ indptr;
+    const uint32_t *__restrict__ indices;
+    ELine *lines;
+    uint8_t *clist;                 // FILL only
+    uint32_t *segcnt;               // per-(neighbour, segment) counts of the rows longer than LB_SEG
+};
+
+// ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
+// from one probe of the adjacency index (walk_sparse.hip.h)
+__global__ void __launch_bounds__(256)
+eline_init_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, ELine *lines) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.nnz) return;
+    const uint32_t u = edge_row[e], v = g.indices[e];
+    const uint4 vr = g.vrec[v];
+    uint32_t rev = NOT_FOUND;
+    if (vr.y) {   // a vertex without out-edges owns no index slots
+        const uint64_t vtb = g.tab_off[v];
+        const uint32_t vmask = (uint32_t)(g.tab_off[v + 1] - vtb) - 1u;
+        rev = adj_lookup(g.slots + vtb, vmask, u, true);
+    }
+    uint4 *lp = (uint4 *)(lines + e);
+    lp[0] = make_uint4(v, 0u, rev, vr.y);
+    *(uint2 *)(lp + 1) = make_uint2(vr.x, 0u);
+}
+
+__device__ __forceinline__ bool list_is_narrow(uint32_t deg) { return deg <= 65536u; }
+__device__ __forceinline__ bool list_is_inline(uint32_t deg, uint32_t n_in) { return list_is_narrow(deg) && n_in <= EL_INLINE; }
+__device__ __forceinline__ const uint8_t *list_base(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t deg,
+                                                    uint32_t n_in, uint32_t coff) {
+    return list_is_inline(deg, n_in) ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+}
+
+// first index in keys[0, P) (P a power of two, keys[len..P] = 0xffffffff) whose key is >= w
+__device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *keys, uint32_t P, uint32_t w) {
+    uint32_t lo = 0, len = P;
+    while (len > 1) {
+        const uint32_t half = len >> 1;
+        lo = keys[lo + half - 1u] < w ? lo + half : lo;
+        len -= half;
+    }
+    return lo + (keys[lo] < w ? 1u : 0u);
+}
+
+// work item of the build: vertex h, segment seg of nseg, base of its counts in segcnt (nseg > 1), neighbour range
+struct LaneBuildItem {
+    uint32_t h, seg, nseg, m0;
+    uint32_t j0, j1;   // neighbours (positions of row h) this workgroup takes: the longest rows are split further
+};
+
+template <int THREADS, int CAP, bool FILL>
+__global__ void __launch_bounds__(THREADS)
+lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ uint32_t keys[CAP + 1];
+    __shared__ uint32_t qj[THREADS], qlo[THREADS], qhi[THREADS];
+    __shared__ uint32_t qn;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const LaneBuildItem it = items[blockIdx.x];
+    const uint32_t h = it.h, nseg = it.nseg;
+    const uint32_t s_h = a.indptr[h], d_h = a.indptr[h + 1] - s_h;
+    const uint32_t a0 = it.seg * (uint32_t)CAP;
+    const uint32_t len = d_h - a0 < (uint32_t)CAP ? d_h - a0 : (uint32_t)CAP;
+    uint32_t P = 1;
+    while (P < len) P <<= 1;
+    for (uint32_t i = tid; i <= P; i += THREADS) keys[i] = i < len ? a.indices[s_h + a0 + i] : 0xffffffffu;
+    __syncthreads();
+    const uint32_t id_lo = keys[0], id_hi = keys[len - 1u];
+    const bool h_narrow = list_is_narrow(d_h);
+    const uint64_t lane_lt = (1ull << lane) - 1ull;
+
+    for (uint32_t base = it.j0; base < it.j1; base += THREADS) {
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        const uint32_t j = base + (uint32_t)tid;
+        if (j < it.j1) {
+            const uint32_t e2 = s_h + j;
+            const uint4 r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
+            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
+            const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
+            const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
+            if (mine && d_k) {
+                uint32_t lo_i = 0, hi_i = d_k;
+                if (nseg > 1) {   // keys of row k inside this segment's id range
+                    lo_i = lower_bound_u32(a.indices + s_k, d_k, id_lo);
+                    hi_i = id_hi == 0xffffffffu ? d_k : lower_bound_u32(a.indices + s_k, d_k, id_hi + 1u);
+                }
+                if (hi_i > lo_i) {
+                    if (hi_i - lo_i <= LB_SEQ) {
+                        // ---- a short neighbour row: this thread alone ----
+                        uint32_t cnt = 0;
+                        uint8_t *p2 = nullptr, *p1 = nullptr;
+                        bool k_narrow = true;
+                        if (FILL) {
+                            if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) cnt += a.segcnt[it.m0 + j * nseg + sg];
+                            k_narrow = list_is_narrow(d_k);
+                            p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                            if (rev != NOT_FOUND) {
+                                const uint32_t e1 = s_k + rev;
+                                const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
+                                p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
+                            }
+                        }
+                        for (uint32_t i = lo_i; i < hi_i; i++) {
+                            const uint32_t w = a.indices[s_k + i];
+                            const uint32_t idx = lds_lower_bound(keys, P, w);
+                            if (keys[idx] == w) {
+                                if (FILL) {
+                                    if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
+                                    if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
+                                }
+                                cnt++;
+                            }
+                        }
+                        if (!FILL) {
+                            if (nseg > 1) {
+                                a.segcnt[it.m0 + j * nseg + it.seg] = cnt;
+                                if (cnt) {
+                                    atomicAdd(&a.lines[e2].n_in, cnt);
+                                    if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, cnt);
+                                }
+                            } else {
+                                a.lines[e2].n_in = cnt;
+                                if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = cnt;
+                            }
+                        }
+                    } else {
+                        const uint32_t slot = atomicAdd(&qn, 1u);
+                        qj[slot] = j; qlo[slot] = lo_i; qhi[slot] = hi_i;
+                    }
+                } else if (!FILL && nseg > 1) a.segcnt[it.m0 + j * nseg + it.seg] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- longer neighbour rows: one wavefront each, 64 keys per trip ----
+        const uint32_t nq = qn;
+        for (uint32_t qi = (uint32_t)wv; qi < nq; qi += NW) {
+            const uint32_t jq = qj[qi], lo_i = qlo[qi], hi_i = qhi[qi];
+            const uint32_t e2 = s_h + jq;
+            const uint4 r0 = *(const uint4 *)(a.lines + e2);
+            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);
+            const uint32_t rev = r0.z, d_k = r0.w, s_k = r1.x;
+            uint32_t run = 0;
+            uint8_t *p2 = nullptr, *p1 = nullptr;
+            bool k_narrow = true;
+            if (FILL) {
+                if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) run += a.segcnt[it.m0 + jq * nseg + sg];
+                k_narrow = list_is_narrow(d_k);
+                p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                if (rev != NOT_FOUND) {
+                    const uint32_t e1 = s_k + rev;
+                    const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
+                    p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
+                }
+            }
+            for (uint32_t c0 = lo_i; c0 < hi_i; c0 += WAVE) {
+                const uint32_t i = c0 + (uint32_t)lane;
+                const bool valid = i < hi_i;
+                const uint32_t w = valid ? a.indices[s_k + i] : 0xffffffffu;
+                const uint32_t idx = lds_lower_bound(keys, P, w);
+                const bool hit = valid && keys[idx] == w;
+                const uint64_t m = ballot(hit);
+                if (FILL && hit) {
+                    const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
+                    if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
+                    if (p1) { if (h_narrow) ((uint16_t *)p1)[rk] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[rk] = a0 + idx; }
+                }
+                run += (uint32_t)__popcll(m);
+            }
+            if (!FILL && lane == 0) {
+                if (nseg > 1) {
+                    a.segcnt[it.m0 + jq * nseg + it.seg] = run;
+                    if (run) {
+                        atomicAdd(&a.lines[e2].n_in, run);
+                        if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, run);
+                    }
+                } else {
+                    a.lines[e2].n_in = run;
+                    if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = run;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// 16-byte units the list of entry e takes in the overflow array (0: it lives inside the edge line)
+__device__ __forceinline__ uint32_t list_units(const ELine *lines, uint64_t e) {
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    if (list_is_inline(r0.w, r0.y)) return 0u;
+    return (r0.y * (list_is_narrow(r0.w) ? 2u : 4u) + 15u) >> 4;
+}
+
 constexpr int CL_BLOCK = 256;
 constexpr int CL_ITEMS = 16;
 constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;
 
+// tile_sums[b] = 16-byte units of tile b; entry_sums[b] = list entries of tile b
 __global__ void __launch_bounds__(CL_BLOCK)
-clist_tile_sums_kernel(const uint4 *__restrict__ tri, uint32_t nnz, uint64_t *tile_sums) {
-    __shared__ uint64_t sh[CL_BLOCK];
+clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint64_t *tile_sums, uint64_t *entry_sums) {
+    __shared__ uint64_t sh[CL_BLOCK], sh2[CL_BLOCK];
     const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)threadIdx.x * CL_ITEMS;
-    uint64_t s = 0;
+    uint64_t s = 0, s2 = 0;
     for (int k = 0; k < CL_ITEMS; k++)
-        if (base + k < nnz) s += tri[base + k].y;
+        if (base + k < nnz) { s += list_units(lines, base + k); s2 += lines[base + k].n_in; }
     sh[threadIdx.x] = s;
+    sh2[threadIdx.x] = s2;
     __syncthreads();
     for (int st = CL_BLOCK / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        if ((int)threadIdx.x < st) { sh[threadIdx.x] += sh[threadIdx.x + st]; sh2[threadIdx.x] += sh2[threadIdx.x + st]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) { tile_sums[blockIdx.x] = sh[0]; entry_sums[blockIdx.x] = sh2[0]; }
 }
 
-// coff[e] = exclusive prefix sum of the per-edge counts (tile_sums already scanned: scan_tile_sums_kernel)
+// lines[e].coff = exclusive prefix sum of the units (tile_sums already scanned: scan_tile_sums_kernel)
 __global__ void __launch_bounds__(CL_BLOCK)
-clist_offsets_kernel(const uint4 *__restrict__ tri, uint32_t nnz, const uint64_t *__restrict__ tile_sums, uint64_t *coff) {
+clist_offsets_kernel(ELine *lines, uint32_t nnz, const uint64_t *__restrict__ tile_sums) {
     __shared__ uint64_t sh[CL_BLOCK];
     const int t = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)t * CL_ITEMS;
     uint32_t loc[CL_ITEMS];
     uint64_t s = 0;
     for (int k = 0; k < CL_ITEMS; k++) {
-        loc[k] = base + k < nnz ? tri[base + k].y : 0u;
+        loc[k] = base + k < nnz ? list_units(lines, base + k) : 0u;
         s += loc[k];
     }
     sh[t] = s;
@@ -531,52 +756,21 @@ clist_offsets_kernel(const uint4 *__restrict__ tri, uint32_t nnz, const uint64_t
     }
     uint64_t run = tile_sums[blockIdx.x] + sh[t] - s;
     for (int k = 0; k < CL_ITEMS; k++) {
-        if (base + k < nnz) coff[base + k] = run;
+        if (base + k < nnz) lines[base + k].coff = (uint32_t)run;
         run += loc[k];
     }
 }
 
-// One lane per CSR entry e = (u -> v): walks the shorter of the two rows through the longer row's filter + index
-// (as tri_build_kernel did for the count) and writes the position IN ROW v of every common neighbour, ascending;
-// then the edge record.
+// test hook (pw_lane_index_export): the list of every entry, decoded to uint32, at off[e] of `out`
 __global__ void __launch_bounds__(256)
-clist_fill_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const uint64_t *__restrict__ coff, uint32_t *clist,
-                  ERec *erec) {
+lane_index_export_kernel(const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, uint32_t nnz,
+                         const uint64_t *__restrict__ off, uint32_t *out) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.nnz) return;
-    const uint4 t = g.tri[e];
-    const uint32_t u = edge_row[e], v = t.x;
-    const uint32_t su = g.indptr[u], du = g.indptr[u + 1] - su;
-    const uint32_t sv = g.indptr[v], dv = t.w;
-    const uint64_t c0 = coff[e];
-    if (t.y) {
-        const bool u_short = du <= dv;
-        const uint32_t ks = u_short ? su : sv, kn = u_short ? du : dv;   // keys: the shorter row
-        const uint32_t w = u_short ? v : u;                               // searched vertex
-        const uint32_t f0 = g.foff[w], nw_mask = g.foff[w + 1] - f0 - 1u;
-        const uint64_t tb0 = g.tab_off[w];
-        const uint32_t tmask = (uint32_t)(g.tab_off[w + 1] - tb0) - 1u;
-        uint32_t cnt = 0;
-        for (uint32_t i = 0; i < kn && cnt < t.y; i++) {
-            const uint2 kfw = g.kf[ks + i];
-            const uint64_t word = g.fbits[f0 + filter_word(kfw.y, nw_mask)];
-            if (!filter_pass(word, kfw.y)) continue;
-            const uint32_t gpos = adj_lookup(g.slots + tb0, tmask, kfw.x, true);
-            if (gpos == 0xffffffffu) continue;
-            clist[c0 + cnt] = u_short ? gpos : i;   // keys from row u: position found in row v; keys from row v: i
-            cnt++;
-        }
-    }
-    ERec r;
-    r.nxt = v;
-    r.n_in = t.y;
-    r.rev_pos = t.z;
-    r.deg = dv;
-    r.s0 = sv;
-    r.coff_lo = (uint32_t)c0;
-    r.coff_hi = (uint32_t)(c0 >> 32);
-    r.pad = 0;
-    erec[e] = r;
+    if (e >= nnz) return;
+    const ELine &ln = lines[e];
+    const uint8_t *p = list_base(lines, clist, (uint32_t)e, ln.deg, ln.n_in, ln.coff);
+    const bool narrow = list_is_narrow(ln.deg);
+    for (uint32_t i = 0; i < ln.n_in; i++) out[off[e] + i] = narrow ? (uint32_t)((const uint16_t *)p)[i] : ((const uint32_t *)p)[i];
 }
 
 }  // namespace pw

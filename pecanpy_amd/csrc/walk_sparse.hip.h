@@ -68,7 +68,8 @@ struct CsrDev {
     // vrec[v] = { indptr[v], degree(v), foff[v], tab_off[v] / 2 }: everything the walk needs to know about
     // a vertex in ONE 16-byte scalar load (filter and index sizes follow from the degree).
     const uint4 *__restrict__ vrec;
-    // tri[e] = { v, |N(u) & N(v)|, position of u in row v (or 0xffffffff), degree(v) } for CSR entry e = (u -> v): the
+    // tri[4 e] (the first 16 bytes of the lane index's 64-byte edge line of CSR entry e = (u -> v), walk_lanes.hip.h)
+    // = { v, |N(u) & N(v)|, position of u in row v (or 0xffffffff), degree(v) }: the
     // number of common neighbours of the two endpoints (a per-edge triangle count) and the place of
     // the reverse edge, built once.  With the count the normaliser `tot` of a step is known BEFORE any
     // membership work, so the membership test can stop as soon as the CDF search has found its element
@@ -1432,7 +1433,7 @@ walk_kernel(WalkArgs a) {
             kfw_pre = 0;
             const uint64_t p_tri = (UNIT && !DENSE) ? PW_KARG(uint64_t, g.tri) : 0ull;
             if (p_tri != 0) {
-                const u32x4 er = as_scalar<u32x4>(p_tri)[pos];
+                const u32x4 er = as_scalar<u32x4>(p_tri)[pos * 4u];   // first 16 bytes of the entry's 64-byte edge line
                 nxt = er.x;
                 n_in = er.y;
                 rev_pos = er.z;

@@ -49,6 +49,7 @@ class WalkEngine:
                                      indptr.size - 1, indices.size, int(device), C.byref(h)))
         eng = cls(h, lib, "csr", indptr.size - 1, int(device))
         eng._max_degree = int(np.diff(indptr.astype(np.int64)).max()) if indptr.size > 1 else 0
+        eng._nnz = int(indices.size)
         return eng
 
     @classmethod
@@ -94,6 +95,17 @@ class WalkEngine:
         ms, nbytes, entries = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _lib.check(self._lib.pw_graph_index_info(self._h, C.byref(ms), C.byref(nbytes), C.byref(entries)))
         return {"build_ms": float(ms.value), "index_bytes": int(nbytes.value), "lane_list_entries": int(entries.value)}
+
+    def lane_index(self):
+        """Test hook: ``(n_in, rev_pos, offsets, entries)`` of the lane index (see ``pw_lane_index_export``)."""
+        info = self.index_info()
+        n = self._nnz
+        n_in = np.zeros(n, dtype=np.uint32)
+        rev = np.zeros(n, dtype=np.uint32)
+        entries = np.zeros(max(info["lane_list_entries"], 1), dtype=np.uint32)
+        _lib.check(self._lib.pw_lane_index_export(self._h, _np_ptr(n_in), _np_ptr(rev), _np_ptr(entries)))
+        off = np.concatenate([[0], np.cumsum(n_in, dtype=np.int64)])
+        return n_in, rev, off, entries[: info["lane_list_entries"]]
 
     def close(self):
         if self._h is not None and self._h.value:
