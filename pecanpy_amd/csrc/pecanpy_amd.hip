@@ -472,12 +472,10 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     g->index_bytes = sizeof(uint64_t) * (frun + trun) + sizeof(uint2) * (uint64_t)nnz + sizeof(uint4) * ((uint64_t)n_nodes + 1);
     hipLaunchKernelGGL(pw::vrec_build_kernel, dim3((n_nodes + 256) / 256), dim3(256), 0, g->stream, g->d_indptr, g->d_foff,
                        g->d_tab_off, n_nodes, g->d_vrec);
-    if (n_nodes && nnz) {
-        hipLaunchKernelGGL(pw::filter_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
-                           g->d_indices, g->d_foff, (unsigned long long *)g->d_fbits, g->d_kf, n_nodes, nnz);
-        hipLaunchKernelGGL(pw::adj_index_build_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr,
-                           g->d_indices, g->d_tab_off, (unsigned long long *)g->d_slots, n_nodes);
-    }
+    if (n_nodes && nnz)
+        hipLaunchKernelGGL(pw::membership_build_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
+                           g->d_indptr, g->d_indices, d_edge_row, g->d_foff, g->d_tab_off, (unsigned long long *)g->d_fbits, g->d_kf,
+                           (unsigned long long *)g->d_slots, nnz, 4294967296.0 / (double)nnz);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
@@ -901,11 +899,10 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
         HIP_TRY(hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)g->nnz));
         hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, d_edge_row);
         pw::WalkArgs ba = wa;
-        ba.job_counter = g->counters.p + 11;
-        hipError_t e = hipMemsetAsync(g->counters.p + 11, 0, sizeof(unsigned long long), g->stream);
-        if (e == hipSuccess) e = hipEventRecord(g->ev[4], g->stream);
+        hipError_t e = hipEventRecord(g->ev[4], g->stream);
         if (e == hipSuccess) {
-            const unsigned grid = (unsigned)(g->n_cu * 8);
+            const uint64_t items = (uint64_t)g->nnz + g->n_nodes;
+            const unsigned grid = (unsigned)((items + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK);
             if (extend) hipLaunchKernelGGL(pw::tot_build_kernel<true>, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, ba, d_edge_row, g->d_tot_e, g->d_tot_v);
             else hipLaunchKernelGGL(pw::tot_build_kernel<false>, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, ba, d_edge_row, g->d_tot_e, g->d_tot_v);
             e = hipGetLastError();
@@ -1006,7 +1003,15 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     la.ver_cap = 0;
     if (verify) {
         const char *cap_env = getenv("PECANPY_AMD_VERIFY_CAP");
-        const uint64_t cap = cap_env ? (uint64_t)strtoull(cap_env, nullptr, 10) : n_work * (uint64_t)wa.L / 4 + 4096;
+        // room for every step of the launch (on hub-heavy graphs most steps are ambiguous), within half of the free memory
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        uint64_t cap = n_work * (uint64_t)wa.L + 4096;
+        if (cap > g->ver.cap) {   // (a larger buffer than the handle holds: only as far as memory allows)
+            const uint64_t lim = free_b / 2 / sizeof(pw::VerRec);
+            if (cap > lim) cap = lim > g->ver.cap ? lim : g->ver.cap;
+        }
+        if (cap_env) cap = (uint64_t)strtoull(cap_env, nullptr, 10);
         if (g->ver.ensure(cap) || g->ver_bad.ensure(16)) return PW_ERR_NOMEM;
         la.ver = g->ver.p;
         la.ver_cap = cap;
@@ -1087,6 +1092,21 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     }
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+#ifdef PW_LANES_WATCHDOG
+    {
+        unsigned long long wd[32], zero[32] = {0};
+        HIP_TRY(hipMemcpyFromSymbol(wd, HIP_SYMBOL(pw::g_wd), sizeof(wd)));
+        if (wd[0]) {
+            fprintf(stderr, "[watchdog] %llu wavefronts ran away; first: loop %llu block %llu active %016llx waiting %016llx exhausted %016llx "
+                    "ambiguous %016llx pool [%llu, %llu) of %llu; lane 0: flags %llu j %llu d %llu n_in %llu job %llu\n", wd[0], wd[1], wd[9], wd[2], wd[3], wd[4],
+                    wd[5], wd[6], wd[7], wd[8], wd[10], wd[11], wd[12], wd[13], wd[14]);
+        }
+        if (wd[16])
+            fprintf(stderr, "[watchdog] %llu float chains ran away; first: k %llu kend %llu n_in %llu pp %llu i0 %llu next_in %llu c %08llx r %016llx "
+                    "x_in %08llx x_out %08llx\n", wd[16], wd[17], wd[18], wd[19], wd[20], wd[21], wd[22], wd[23], wd[24], wd[25], wd[26]);
+        if (wd[0] || wd[16]) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pw::g_wd), zero, sizeof(zero)));
+    }
+#endif
 #ifdef PW_PROF_LANES
     {
         unsigned long long hp[16], zero[16] = {0};

@@ -402,6 +402,9 @@ static thread_local uint64_t g_lane_seq_elems = 0, g_lane_binades = 0;
 #else
 #define PW_LANE_STAT(x)
 #endif
+#if defined(PW_LANES_WATCHDOG) && defined(__HIPCC__)
+__device__ unsigned long long g_wd[32];   // debug builds: state of a wavefront / thread whose loop ran away
+#endif
 constexpr uint32_t LANE_HEAD = 32;        // leading elements added one by one
 constexpr uint32_t LANE_TIE_BUDGET = 4096;  // runs walked one by one inside binades with a rounding tie
 
@@ -459,7 +462,20 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
     PW_LANE_SEQ(LANE_HEAD, 0);
     if (hit) return k;
     uint32_t tie_budget = LANE_TIE_BUDGET;
+#if defined(PW_LANES_WATCHDOG) && defined(__HIP_DEVICE_COMPILE__)
+    uint32_t wd_chain = 0;
+#endif
     while (k < kend) {
+#if defined(PW_LANES_WATCHDOG) && defined(__HIP_DEVICE_COMPILE__)
+        if (++wd_chain > 1000000u) {
+            if (atomicAdd(&g_wd[16], 1ull) == 0ull) {
+                g_wd[17] = k; g_wd[18] = kend; g_wd[19] = n_in; g_wd[20] = pp; g_wd[21] = i0; g_wd[22] = next_in;
+                g_wd[23] = (unsigned long long)__float_as_uint(c); g_wd[24] = (unsigned long long)__double_as_longlong(r);
+                g_wd[25] = (unsigned long long)__float_as_uint(x_in); g_wd[26] = (unsigned long long)__float_as_uint(x_out);
+            }
+            return LANE_TIE;
+        }
+#endif
         if (k == pp) {   // prev is a single element: always a real addition (no closed form, no tie question)
             PW_LANE_SEQ(1u, 0);
             if (hit) return k;

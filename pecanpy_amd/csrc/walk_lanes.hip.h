@@ -129,11 +129,30 @@ __device__ unsigned long long g_lprof[16];
 #define LPROF_C(i, n)
 #endif
 
+// -DPW_LANES_WATCHDOG builds: a wavefront whose main / refill loop runs away records its state and leaves
+#ifdef PW_LANES_WATCHDOG
+#define PW_WD(which, limit, counter)                                                                              \
+    do {                                                                                                          \
+        if (++(counter) > (limit)) {                                                                              \
+            const uint64_t act_ = ballot((A.flags & F_ACTIVE) != 0), wt_ = ballot((A.flags & F_WAIT2) != 0);      \
+            const uint64_t ex_ = ballot(exhausted), amb_ = ballot(choice_wd == LANE_AMBIGUOUS);                   \
+            if (lane == 0 && atomicAdd(&g_wd[0], 1ull) == 0ull) {                                                 \
+                g_wd[1] = (which); g_wd[2] = act_; g_wd[3] = wt_; g_wd[4] = ex_; g_wd[5] = amb_;                  \
+                g_wd[6] = pool_lo; g_wd[7] = pool_hi; g_wd[8] = n_work; g_wd[9] = blockIdx.x;                     \
+                g_wd[10] = A.flags; g_wd[11] = A.j; g_wd[12] = A.d; g_wd[13] = A.n_in; g_wd[14] = A.job;          \
+            }                                                                                                     \
+            return;                                                                                               \
+        }                                                                                                         \
+    } while (0)
+#else
+#define PW_WD(which, limit, counter)
+#endif
+
 #ifndef PW_LANES_MIN_WAVES
 #define PW_LANES_MIN_WAVES 4   // 128 VGPRs: the in-place form needs ~130 (chain code); at 5-6 waves it spills in the hot loop and runs 1.6-2x slower
 #endif
 #ifndef PW_LANES_MIN_WAVES_Q
-#define PW_LANES_MIN_WAVES_Q 5   // ... of the queueing form (no chain code): ~100 VGPRs, fits 5 waves without spilling
+#define PW_LANES_MIN_WAVES_Q 6   // ... of the queueing form (no chain code; statistics in scalar registers): 80 VGPRs, six waves without spilling
 #endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
@@ -179,7 +198,6 @@ __device__ unsigned long long g_lprof[16];
             }                                                                                   \
             A.n_in = r0_.y; A.pp = r0_.z; A.d = r0_.w;                                          \
             A.s0 = r1_.x; A.coff = r1_.y;                                                       \
-            n_steps++;                                                                          \
             A.j++;                                                                              \
             if (A.j > L || A.d == 0) {                                                          \
                 uint32_t *row_ = a.out + (uint64_t)A.job * W;                                   \
@@ -231,16 +249,25 @@ walk_lanes_kernel(LanesArgs a) {
     uint64_t pool_lo = 0, pool_hi = 0;   // wavefront-uniform: job indices reserved from the shared counter
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
     const uint64_t grid_lanes = (uint64_t)gridDim.x * (WAVES_PER_BLOCK * WAVE);
-    unsigned long long n_steps = 0, n_dead = 0, n_probes = 0, n_amb = 0, n_wave = 0;
+    // statistics: wave-uniform sums of ballots where a count of lanes is all that is needed (scalar registers), 32-bit
+    // per-lane counters for the rest
+    unsigned long long n_steps = 0, n_amb = 0, n_wave = 0;
+    uint32_t n_dead = 0, n_probes = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
     OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
 
+#ifdef PW_LANES_WATCHDOG
+    unsigned long long wd_main = 0, wd_refill = 0;
+    uint32_t choice_wd = 0;
+#endif
     for (;;) {
+        PW_WD(1, 2000000ull, wd_main);
         // ---- refill idle lanes from the job counter -------------------------------------------------------
         for (;;) {
+            PW_WD(2, 2000000ull, wd_refill);
             const uint64_t need = ballot(!(A.flags & F_ACTIVE) && !exhausted);
             if (!need) break;
             // jobs are taken from a wavefront-local pool; the shared counter is touched once per PW_LANES_CHUNK jobs
@@ -313,12 +340,12 @@ walk_lanes_kernel(LanesArgs a) {
             // (r = this step's draw: loaded when the previous step was applied / the walk was started)
             choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), ls);
             n_probes += ls.probes;
-            if (choice == LANE_AMBIGUOUS) n_amb++;
         }
         LPROF_T(1);
         // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
         const bool amb0 = runnable && choice == LANE_AMBIGUOUS;
         if (ballot(amb0)) {
+            n_amb += (unsigned long long)__popcll(ballot(amb0));
             LPROF_C(9, 1);
             LPROF_C(10, __popcll(ballot(amb0)));
             if (amb0) choice = lane_tight(A.d, A.pp, r, wo, w_prev, ls);
@@ -385,6 +412,7 @@ walk_lanes_kernel(LanesArgs a) {
         if (INPLACE) {
             const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
             if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_WAIT2 || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0)) {
+                n_wave += (unsigned long long)__popcll(w2);                 // (steps decided by the float chain)
                 LPROF_C(5, 1);
                 LPROF_C(6, __popcll(w2));
                 if (A.flags & F_WAIT2) {
@@ -397,15 +425,18 @@ walk_lanes_kernel(LanesArgs a) {
                     choice = res;
                     if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
                     if (res == LANE_TIE) choice = A.d;                      // tie binade too long for one lane -> redo
-                    n_wave++;                                               // (steps decided by the float chain)
                     A.flags = F_ACTIVE;
                 }
                 LPROF_T(4);
             }
         }
+        n_steps += (unsigned long long)__popcll(ballot(A.flags == F_ACTIVE && choice < A.d));   // (LANE_* codes are >= any degree)
         if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {
             PW_LANE_APPLY();
         }
+#ifdef PW_LANES_WATCHDOG
+        choice_wd = choice;
+#endif
         LPROF_T(3);
     }
 #undef PW_LANE_APPLY
@@ -415,17 +446,15 @@ walk_lanes_kernel(LanesArgs a) {
     if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
 #endif
     // wave totals
+    unsigned long long dead_w = n_dead, probes_w = n_probes;
     for (int off = 32; off > 0; off >>= 1) {
-        n_steps += (unsigned long long)__shfl_down((long long)n_steps, (unsigned)off, WAVE);
-        n_dead += (unsigned long long)__shfl_down((long long)n_dead, (unsigned)off, WAVE);
-        n_probes += (unsigned long long)__shfl_down((long long)n_probes, (unsigned)off, WAVE);
-        n_amb += (unsigned long long)__shfl_down((long long)n_amb, (unsigned)off, WAVE);
-        n_wave += (unsigned long long)__shfl_down((long long)n_wave, (unsigned)off, WAVE);
+        dead_w += (unsigned long long)__shfl_down((long long)dead_w, (unsigned)off, WAVE);
+        probes_w += (unsigned long long)__shfl_down((long long)probes_w, (unsigned)off, WAVE);
     }
     if (lane == 0) {
         if (n_steps) atomicAdd(a.stats + 0, n_steps);
-        if (n_dead) atomicAdd(a.stats + 3, n_dead);
-        if (n_probes) atomicAdd(a.stats + 6, n_probes);
+        if (dead_w) atomicAdd(a.stats + 3, dead_w);
+        if (probes_w) atomicAdd(a.stats + 6, probes_w);
         if (n_amb) atomicAdd(a.stats + 7, n_amb);
         if (n_wave) atomicAdd(a.stats + 9, n_wave);
     }

@@ -1470,45 +1470,42 @@ walk_kernel(WalkArgs a) {
 
 // Per-edge normalisers of a weighted CSR graph for one (p, q, extend): work item e < nnz = CSR entry (u -> v):
 // tot_e[e] = pass 1 of sample_step_weighted for cur = v, prev = u; item nnz + v: tot_v[v] = the unbiased row sum of v.
-// One wavefront per item (persistent grid); bit-identical to what the walk step would compute, because it IS the
-// walk step's code.  Cost: sum over edges of the row length of the head = sum of squared degrees -- one pass of
-// ~E[d_visit] elements per CSR entry, against E[d_visit] elements TWICE per sampled step without the table.
+// One wavefront per item, one item per wavefront (grid = items / WAVES_PER_BLOCK: no loop around the step code, so
+// nothing but the item index is live across it -- a persistent-loop form of this kernel hung whenever its register
+// allocation changed); bit-identical to what the walk step would compute, because it IS the walk step's code.
+// Cost: sum over edges of the row length of the head = sum of squared degrees -- one pass of ~E[d_visit] elements per
+// CSR entry, against E[d_visit] elements TWICE per sampled step without the table.
 template <bool EXTEND>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, EXTEND ? PW_MIN_WAVES - 1 : PW_MIN_WAVES)
 tot_build_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused, float *tot_e_unused, float *tot_v_unused) {
-    // (like walk_kernel, every argument is re-read from the kernarg segment at its point of use: values kept live
-    //  across the step code would be spilled, and the allocator's SGPR spill slots do not survive this loop)
+    // (like walk_kernel, every argument is re-read from the kernarg segment at its point of use)
     __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
     __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
     __shared__ uint32_t s_queue[WAVES_PER_BLOCK][2 * QCAP];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;   // edge_row, tot_e, tot_v follow the struct
-    for (;;) {
-        unsigned long long item = 0;
-        if (lane == 0) item = atomicAdd((unsigned long long *)PW_KARG(uint64_t, job_counter), 1ull);
-        item = readfirst_u64(item);
-        const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
-        if (item >= (uint64_t)nnz + PW_KARG(uint32_t, g.n_nodes)) break;
-        const bool is_edge = item < nnz;
-        const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
-        uint32_t cur = (uint32_t)(item - nnz), prev = 0;
-        if (is_edge) {
-            cur = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[item];
-            prev = as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[item];
-        }
-        const uint32_t s0 = indptr[cur], d = indptr[cur + 1] - s0;
-        const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
-        float tot = 0.0f;
-        if (d) {
-            const WalkArgs la = reload_walk_args();
-            (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur,
-                                                     is_edge, prev, t0, dp, 0.0, s0, d, nullptr, &tot);
-        }
-        if (lane == 0) {
-            if (is_edge) ((gptr_mut<float>)kernarg<uint64_t>(XARG + 8))[item] = tot;
-            else ((gptr_mut<float>)kernarg<uint64_t>(XARG + 16))[item - nnz] = tot;
-        }
+    const uint64_t item = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint64_t)wave;
+    const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
+    if (item >= (uint64_t)nnz + PW_KARG(uint32_t, g.n_nodes)) return;
+    const bool is_edge = item < nnz;
+    const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+    uint32_t cur = (uint32_t)(item - nnz), prev = 0;
+    if (is_edge) {
+        cur = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[item];
+        prev = as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[item];
+    }
+    const uint32_t s0 = indptr[cur], d = indptr[cur + 1] - s0;
+    const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
+    float tot = 0.0f;
+    if (d) {
+        const WalkArgs la = reload_walk_args();
+        (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur,
+                                                 is_edge, prev, t0, dp, 0.0, s0, d, nullptr, &tot);
+    }
+    if (lane == 0) {
+        if (is_edge) ((gptr_mut<float>)kernarg<uint64_t>(XARG + 8))[item] = tot;
+        else ((gptr_mut<float>)kernarg<uint64_t>(XARG + 16))[item - nnz] = tot;
     }
 }
 
