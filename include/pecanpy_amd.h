@@ -183,14 +183,20 @@ int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
 /* ---- skip-gram training over a walk matrix (the stage after the walks) ------------------- */
 /* Word2Vec(walks, sg=1, negative, window, epochs) of Base.embed / cli.learn_embeddings (pecanpy.py:276-290,
  * cli.py:307-325) as a HIP kernel: skip-gram with negative sampling, word2vec.c's update rule, unigram^0.75 negative
- * table, subsampling of frequent nodes (sample, 0 = off), window shrunk at random, learning rate alpha -> min_alpha
- * linearly over the run, unsynchronised (hogwild) updates.  Not bit-comparable with gensim (whose result depends on
- * its threads and its own random stream); same model, same defaults.
- *   walks   host uint32[n_walks, walk_length + 2] as pw_simulate returns it (indices into 0..n_nodes-1)
+ * table, walks thinned by the subsampling of frequent nodes (sample, 0 = off) before the windows are taken, window
+ * shrunk at random, learning rate alpha -> min_alpha linearly over the run.  Every random choice is a hash of (seed,
+ * epoch, walk, position, ...): the SET of updates depends on the seed only, their order on `workers`:
+ *   workers = 1  one wavefront, sentence order: deterministic; equals the sequential restatement oracle/sgns_ref.c
+ *                within float tolerance (tests/test_gpu_sgns.py) -- what gensim's workers=1 is to gensim;
+ *   workers = 0  as many wavefronts as the corpus feeds (hogwild, unsynchronised updates, like gensim's threads);
+ *   workers > 1  that many wavefronts.
+ * Not bit-comparable with gensim itself (its own random streams; not installed here).
+ *   walks   host uint32[n_walks, walk_length + 2] as pw_simulate returns it (indices into 0..n_nodes-1; a node id
+ *           >= n_nodes or a length cell > walk_length + 1 is rejected with PW_ERR_INVALID)
  *   vectors host float32[n_nodes, dim] (out), dim <= 512 */
 int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks, uint32_t walk_length, uint32_t n_nodes,
                   uint32_t dim, uint32_t window, uint32_t negative, uint32_t epochs, float alpha, float min_alpha,
-                  float sample, uint32_t seed, float *vectors);
+                  float sample, uint32_t seed, uint32_t workers, float *vectors);
 
 /* ---- random stream service (host side; usable without a GPU) ---------------------------- */
 /* doubles #offset.. of RandomState(seed).random_sample, produced with MT19937 jump-ahead. */

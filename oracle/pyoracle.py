@@ -29,6 +29,8 @@ def build(force=False):
     targets = ["liboracle.so"]
     if os.path.exists(os.path.join(_HERE, "cpu_baseline.c")):
         targets.append("libcpu_baseline.so")
+    if os.path.exists(os.path.join(_HERE, "sgns_ref.c")):
+        targets.append("libsgns_ref.so")
     if force:
         subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", _HERE] + targets, stdout=subprocess.DEVNULL)
@@ -252,3 +254,29 @@ def cpu_baseline_walks(indptr, indices, data, p, q, starts, walk_length, seed, n
 
 def cpu_baseline_max_threads():
     return int(baseline_lib().cpub_max_threads())
+
+
+_SGNS = None
+
+
+def sgns_train(walk_matrix, num_nodes, dim=128, window=10, epochs=1, negative=5, alpha=0.025, min_alpha=1e-4,
+               sample=1e-3, seed=0):
+    """Sequential skip-gram with negative sampling over a walk matrix (oracle/sgns_ref.c: word2vec.c / gensim sg=1,
+    the model of Base.embed, src/pecanpy/pecanpy.py:276-290).  Returns ``(vectors float32[num_nodes, dim], mean loss of
+    the last epoch)``."""
+    global _SGNS
+    if _SGNS is None:
+        path = os.path.join(_HERE, "libsgns_ref.so")
+        if not os.path.exists(path):
+            build()
+        _SGNS = C.CDLL(path)
+    mat = np.ascontiguousarray(walk_matrix, dtype=np.uint32)
+    out = np.zeros((int(num_nodes), int(dim)), dtype=np.float32)
+    loss = C.c_double(0)
+    rc = _SGNS.sgns_ref_train(mat.ctypes.data_as(C.c_void_p), C.c_uint64(mat.shape[0]), C.c_uint32(mat.shape[1] - 2),
+                              C.c_uint32(int(num_nodes)), C.c_uint32(int(dim)), C.c_uint32(int(window)), C.c_uint32(int(negative)),
+                              C.c_uint32(int(epochs)), C.c_float(alpha), C.c_float(min_alpha), C.c_float(sample),
+                              C.c_uint32(int(seed) & 0xFFFFFFFF), out.ctypes.data_as(C.c_void_p), C.byref(loss))
+    if rc != 0:
+        raise ValueError("sgns_ref_train: malformed walk matrix")
+    return out, float(loss.value)

@@ -1092,6 +1092,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     }
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    if (verify) g->ver.release();   // (test mode: up to half of the free memory -- not kept in the handle)
 #ifdef PW_LANES_WATCHDOG
     {
         unsigned long long wd[32], zero[32] = {0};
@@ -1540,7 +1541,7 @@ PW_EXPORT int pw_probs(pw_graph *g, int mode, double p, double q, int extend, ui
 // ---- skip-gram with negative sampling over a walk matrix (sgns.hip.h) -------------------------
 PW_EXPORT int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks, uint32_t walk_length, uint32_t n_nodes,
                             uint32_t dim, uint32_t window, uint32_t negative, uint32_t epochs, float alpha, float min_alpha,
-                            float sample, uint32_t seed, float *vectors) {
+                            float sample, uint32_t seed, uint32_t workers, float *vectors) {
     if (!walks || !vectors || !n_walks || !n_nodes) return fail(PW_ERR_INVALID, "null pointer / empty corpus");
     if (dim == 0 || dim > 64 * pw::SGNS_MAX_PER_LANE) return fail(PW_ERR_INVALID, "dim must be in 1..512");
     if (window == 0 || epochs == 0) return fail(PW_ERR_INVALID, "window and epochs must be positive");
@@ -1557,34 +1558,41 @@ PW_EXPORT int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks,
         for (void *q : {(void *)d_walks, (void *)d_table, (void *)d_cnt, (void *)d_syn0, (void *)d_syn1, (void *)d_keep})
             if (q) (void)hipFree(q);
     };
+    auto bail = [&](int code, const std::string &msg) { cleanup(); return fail(code, msg); };
     hipError_t e = hipMalloc((void **)&d_walks, wbytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof(unsigned long long) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof(unsigned long long) * ((size_t)n_nodes + 1));   // [n_nodes]: first bad walk
     if (e == hipSuccess) e = hipMalloc((void **)&d_syn0, vbytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_syn1, vbytes);
     if (e == hipSuccess) e = hipMemcpy(d_walks, walks, wbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * (size_t)n_nodes);
+    if (e == hipSuccess) e = hipMemset(d_cnt + n_nodes, 0xff, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(d_syn1, 0, vbytes);
-    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
-    // vocabulary statistics
+    if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e));
+    // vocabulary statistics (and the check that the matrix only names nodes of the vocabulary)
     const uint64_t n_items = n_walks * (uint64_t)(L + 1);
-    hipLaunchKernelGGL(pw::sgns_count_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, 0, d_walks, n_walks, L, d_cnt);
-    std::vector<unsigned long long> cnt(n_nodes);
-    e = hipMemcpy(cnt.data(), d_cnt, sizeof(unsigned long long) * (size_t)n_nodes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(pw::sgns_count_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, 0, d_walks, n_walks, L, n_nodes, d_cnt,
+                       d_cnt + n_nodes);
+    std::vector<unsigned long long> cnt((size_t)n_nodes + 1);
+    e = hipMemcpy(cnt.data(), d_cnt, sizeof(unsigned long long) * ((size_t)n_nodes + 1), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e));
+    if (cnt[n_nodes] != ~0ull)
+        return bail(PW_ERR_INVALID, "walk " + std::to_string(cnt[n_nodes]) + ": node id >= n_nodes or length cell > walk_length + 1");
     double total = 0, pow_total = 0;
     for (uint32_t i = 0; i < n_nodes; i++) { total += (double)cnt[i]; pow_total += std::pow((double)cnt[i], 0.75); }
-    if (!(total > 0)) { cleanup(); return fail(PW_ERR_INVALID, "the walk matrix holds no nodes"); }
-    // word2vec's unigram^0.75 table and subsampling probabilities
+    if (!(total > 0)) return bail(PW_ERR_INVALID, "the walk matrix holds no nodes");
+    // word2vec's unigram^0.75 table (a word that never occurs owns no slot) and subsampling probabilities
     const uint32_t table_size = (uint32_t)std::min<uint64_t>(1ull << 26, std::max<uint64_t>(1ull << 16, 16ull * n_nodes));
     std::vector<uint32_t> table(table_size);
     {
-        uint32_t w = 0;
-        double cum = std::pow((double)cnt[0], 0.75) / pow_total;
-        for (uint32_t t = 0; t < table_size; t++) {
-            table[t] = w;
-            if ((double)(t + 1) / table_size > cum && w + 1 < n_nodes) { w++; cum += std::pow((double)cnt[w], 0.75) / pow_total; }
-            while ((double)(t + 1) / table_size > cum && w + 1 < n_nodes) { w++; cum += std::pow((double)cnt[w], 0.75) / pow_total; }
+        uint32_t t = 0, last = 0;
+        double cum = 0;
+        for (uint32_t w = 0; w < n_nodes; w++) {
+            if (!cnt[w]) continue;
+            last = w;
+            cum += std::pow((double)cnt[w], 0.75) / pow_total;
+            while (t < table_size && (double)(t + 1) / table_size <= cum) table[t++] = w;
         }
+        while (t < table_size) table[t++] = last;   // (rounding of the last share)
     }
     std::vector<float> keep;
     if (sample > 0) {
@@ -1609,20 +1617,27 @@ PW_EXPORT int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks,
         e = hipMalloc((void **)&d_keep, sizeof(float) * (size_t)n_nodes);
         if (e == hipSuccess) e = hipMemcpy(d_keep, keep.data(), sizeof(float) * (size_t)n_nodes, hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e)); }
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("pw_sgns_train: ") + hipGetErrorString(e));
     pw::SgnsArgs a;
     a.walks = d_walks; a.n_walks = n_walks; a.L = L; a.dim = dim; a.window = window; a.negative = negative;
     a.syn0 = d_syn0; a.syn1 = d_syn1; a.table = d_table; a.table_size = table_size; a.keep = d_keep;
     a.alpha = alpha; a.min_alpha = min_alpha; a.item_total = n_items * epochs; a.seed = seed;
-    // concurrency: hogwild updates collide when far more wavefronts than vocabulary rows are in flight (a small graph
-    // would see most of its updates overwritten): at least ~256 items per wavefront
-    const uint64_t want_blocks = (n_items + 1023) / 1024;
-    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want_blocks, (uint64_t)prop.multiProcessorCount * 8));
+    // concurrency.  workers == 1: ONE wavefront walks the corpus in sentence order (deterministic: the run gensim's
+    // workers=1 corresponds to; compared with oracle/sgns_ref.c).  workers == 0: as many wavefronts as keep hogwild
+    // collisions rare -- far more wavefronts than vocabulary rows in flight would overwrite most updates of a small
+    // graph: at least ~256 items per wavefront.  workers > 1: that many wavefronts.
+    unsigned blocks, threads = 256;
+    if (workers == 1) { blocks = 1; threads = 64; }
+    else if (workers > 1) blocks = (workers + 3) / 4;
+    else {
+        const uint64_t want_blocks = (n_items + 1023) / 1024;
+        blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want_blocks, (uint64_t)prop.multiProcessorCount * 8));
+    }
     for (uint32_t ep = 0; ep < epochs; ep++) {
         a.item_base = n_items * ep;
-        hipLaunchKernelGGL(pw::sgns_kernel, dim3(blocks), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL(pw::sgns_kernel, dim3(blocks), dim3(threads), 0, 0, a);
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -1,13 +1,17 @@
 // sgns.hip.h -- skip-gram with negative sampling over a walk matrix (gfx950): the stage that follows the walks in
 // the reference's pipeline (Base.embed / cli.learn_embeddings: gensim Word2Vec(walks, sg=1, negative=5, window, epochs),
-// src/pecanpy/pecanpy.py:276-290, cli.py:307-325).  SURVEY.md section 8(f) rank 4.  Not a parity target -- gensim's result
-// depends on its thread interleaving and its own random stream -- but the same model and update rule (word2vec.c):
-//   for every centre position of every walk, a window shrunk by a random amount, and for every context word c in it
-//   (frequent words dropped with word2vec's subsampling probability): input vector syn0[c], targets = the centre
-//   (label 1) and `negative` words drawn from the unigram^0.75 table (label 0), g = (label - sigmoid(v.u)) * lr,
-//   u += g v, v += sum g u.  Hogwild (unsynchronised) updates, learning rate decaying linearly over the run.
-// One wavefront per (walk, position): the `dim` components of a vector are spread over the 64 lanes, dot products are
-// wave reductions, the walk row is read once per item.
+// src/pecanpy/pecanpy.py:276-290, cli.py:307-325).  SURVEY.md section 8(f) rank 4.  The model and update rule are
+// word2vec.c's (gensim's sg / negative path):
+//   a walk is thinned by word2vec's frequent-word subsampling, windows are taken over what is left; for every centre
+//   position a window shrunk by a random amount, and for every context word c in it: input vector syn0[c], targets =
+//   the centre (label 1) and `negative` words drawn from the unigram^0.75 table (label 0),
+//   g = (label - sigmoid(v.u)) * lr, u += g v, v += sum g u; learning rate decaying linearly over the run.
+// Every random choice is a hash of (seed, epoch, walk, position[, context, draw]) -- no generator state -- so the set
+// of updates is a function of the seed alone; what the hardware adds is their ORDER: one wavefront per (walk,
+// position), hogwild (unsynchronised) like gensim's worker threads.  With ONE wavefront (pw_sgns_train: workers = 1)
+// the updates run in sentence order and the result is compared with the sequential CPU restatement
+// (oracle/sgns_ref.c, tests/test_gpu_sgns.py) within float tolerance.
+// The `dim` components of a vector are spread over the 64 lanes, dot products are wave reductions.
 #pragma once
 #include "wave.h"
 
@@ -52,18 +56,24 @@ sgns_kernel(SgnsArgs a) {
         const uint32_t *row = a.walks + wk * W;
         const uint32_t len = row[a.L + 1];
         if (pos >= len) continue;
+        // occurrence (walk, p) of this epoch survives the subsampling?  (every wavefront that meets it agrees)
+        const uint64_t occ0 = a.item_base + wk * (uint64_t)(a.L + 1);
+#define occ(p) sgns_mix(a.seed ^ (occ0 + (p)) * 0x9E3779B97F4A7C15ull)
+#define kept(p) (!a.keep || (float)(occ(p) >> 40) * (1.0f / 16777216.0f) < a.keep[row[p]])
+        if (!kept(pos)) continue;
         const uint32_t centre = row[pos];
-        uint64_t rs = sgns_mix(a.seed ^ (a.item_base + item) * 0x9E3779B97F4A7C15ull);
-        if (a.keep && (float)(rs >> 40) * (1.0f / 16777216.0f) >= a.keep[centre]) continue;   // centre subsampled away
-        rs = sgns_mix(rs);
+        uint64_t rs = sgns_mix(occ(pos));
         const uint32_t eff = a.window - (uint32_t)(rs % a.window);                              // shrunk window, 1 .. window
         const float lr = fmaxf(a.min_alpha, a.alpha - (a.alpha - a.min_alpha) * (float)((double)(a.item_base + item) / (double)a.item_total));
-        const uint32_t lo = pos > eff ? pos - eff : 0u, hi = pos + eff + 1u < len ? pos + eff + 1u : len;
-        for (uint32_t c = lo; c < hi; c++) {
-            if (c == pos) continue;
+        // the window over the thinned walk: up to eff surviving positions on either side
+        uint32_t lo = pos, hi = pos, got = 0;
+        for (uint32_t c = pos; c-- > 0 && got < eff;) if (kept(c)) { lo = c; got++; }
+        got = 0;
+        for (uint32_t c = pos + 1; c < len && got < eff; c++) if (kept(c)) { hi = c; got++; }
+        for (uint32_t c = lo; c <= hi; c++) {
+            if (c == pos || !kept(c)) continue;
             const uint32_t ctx = row[c];
             rs = sgns_mix(rs + c);
-            if (a.keep && (float)(rs >> 40) * (1.0f / 16777216.0f) >= a.keep[ctx]) continue;
             float *v = a.syn0 + (uint64_t)ctx * a.dim;
             float vin[SGNS_MAX_PER_LANE], acc[SGNS_MAX_PER_LANE];
 #pragma unroll
@@ -105,18 +115,27 @@ sgns_kernel(SgnsArgs a) {
                 if (t < (int)per && k < a.dim) v[k] = vin[t] + acc[t];
             }
         }
+#undef occ
+#undef kept
     }
 }
 
-// word counts of a walk matrix (vocabulary statistics for the sampling table and the subsampling probabilities)
+// word counts of a walk matrix (vocabulary statistics for the sampling table and the subsampling probabilities);
+// bad[0] = first walk whose length cell exceeds L + 1 or that names a node >= n_nodes (atomicMin, ~0: none)
 __global__ void __launch_bounds__(256)
-sgns_count_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L, unsigned long long *counts) {
+sgns_count_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L, uint32_t n_nodes, unsigned long long *counts,
+                  unsigned long long *bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t wk = i / (L + 1);
     if (wk >= n_walks) return;
     const uint32_t pos = (uint32_t)(i - wk * (L + 1));
     const uint32_t *row = walks + wk * ((uint64_t)L + 2);
-    if (pos < row[L + 1]) atomicAdd(&counts[row[pos]], 1ull);
+    const uint32_t len = row[L + 1];
+    if (len > L + 1) { atomicMin(bad, (unsigned long long)wk); return; }
+    if (pos < len) {
+        if (row[pos] >= n_nodes) { atomicMin(bad, (unsigned long long)wk); return; }
+        atomicAdd(&counts[row[pos]], 1ull);
+    }
 }
 
 }  // namespace pw

@@ -4,7 +4,8 @@
 ``train_sgns`` runs word2vec's skip-gram-with-negative-sampling update as a HIP kernel (``pw_sgns_train``,
 csrc/sgns.hip.h) directly on the ``uint32[n_jobs, L+2]`` matrix the walk engine produces -- no ``List[List[str]]`` corpus
 in between.  Same model and defaults as gensim's (negative=5, ns_exponent=0.75, sample=1e-3, alpha 0.025 -> 1e-4,
-shrunk windows); results are not bit-comparable with gensim's, whose output depends on its thread interleaving.
+shrunk windows over the subsampled walk); not bit-comparable with gensim's own random streams -- the deterministic
+single-wavefront mode is checked against a sequential CPU restatement of the algorithm instead (tests/test_gpu_sgns.py).
 """
 import ctypes as C
 
@@ -16,8 +17,11 @@ __all__ = ["train_sgns", "save_word2vec_format"]
 
 
 def train_sgns(walk_matrix, num_nodes, dim=128, window=10, epochs=1, negative=5, alpha=0.025, min_alpha=1e-4,
-               sample=1e-3, seed=None, device=0):
-    """float32[num_nodes, dim] input vectors (``wv``) after ``epochs`` passes over the walks."""
+               sample=1e-3, seed=None, device=0, workers=0):
+    """float32[num_nodes, dim] input vectors (``wv``) after ``epochs`` passes over the walks.
+
+    ``workers=0`` (default): hogwild, as many wavefronts as the corpus feeds; ``workers=1``: one wavefront in sentence
+    order -- deterministic under ``seed`` (the counterpart of gensim's ``workers=1``), slow."""
     lib = _lib.load()
     mat = np.ascontiguousarray(walk_matrix, dtype=np.uint32)
     if mat.ndim != 2 or mat.shape[1] < 3:
@@ -27,7 +31,7 @@ def train_sgns(walk_matrix, num_nodes, dim=128, window=10, epochs=1, negative=5,
     out = np.zeros((int(num_nodes), int(dim)), dtype=np.float32)
     _lib.check(lib.pw_sgns_train(int(device), mat.ctypes.data, mat.shape[0], mat.shape[1] - 2, int(num_nodes), int(dim),
                                  int(window), int(negative), int(epochs), float(alpha), float(min_alpha), float(sample),
-                                 int(seed) & 0xFFFFFFFF, out.ctypes.data))
+                                 int(seed) & 0xFFFFFFFF, int(workers), out.ctypes.data))
     return out
 
 
