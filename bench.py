@@ -211,9 +211,9 @@ def main():
     n_jobs = starts.size
     t_prep = time.time() - t0
 
-    lo, hi = shard_bounds(n_jobs, world)[rank]
+    all_bounds = shard_bounds(n_jobs, world)
+    lo, hi = all_bounds[rank]
     d_starts = torch.from_numpy(starts[lo:hi].view(np.int32)).to(dev)
-    d_out = torch.empty((hi - lo, L + 2), dtype=torch.int32, device=dev)
     # stream address of this shard (undirected graph: nominal counts are exact)
     skip = int(has_nbr[starts[:lo]].sum()) * L
     do_gather = world > 1 and not args.no_gather
@@ -223,14 +223,26 @@ def main():
     chunk_bounds = shard_bounds(hi - lo, n_chunks)
     csum = np.concatenate([[0], np.cumsum(has_nbr[starts[lo:hi]], dtype=np.int64)])
     chunk_skip = [skip + int(csum[a]) * L for a, _ in chunk_bounds]
-    pads, parts = [], []
+    # The gather (N > 1): ONE preallocated [n_jobs, L + 2] matrix on rank 0; every chunk of every other rank's shard is
+    # sent point to point (RCCL send/recv) straight into its row slice -- no padded staging buffers, no concatenation --
+    # rank 0 walks its own shard in place, and the rows of starts without neighbours ([start, 0, ..., 0, 1]: 52 % of an
+    # R-MAT job array) are not sent at all: rank 0 writes them itself.
+    gather = None
+    job_has_nbr = has_nbr[starts]
     if do_gather:
-        widest = max(b[1] - b[0] for b in shard_bounds(n_jobs, world))
-        for c in range(n_chunks):
-            rows = max(b[1] - b[0] for b in shard_bounds(widest, n_chunks))
-            pad = torch.zeros((rows, L + 2), dtype=torch.int32, device=cdev)
-            pads.append(pad)
-            parts.append([torch.empty_like(pad) for _ in range(world)] if rank == 0 else None)
+        from pecanpy_amd.sharding import RowGather, isolated_row_filler
+
+        fill = isolated_row_filler(starts, L, cdev)
+
+        def new_gather():
+            return RowGather(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
+
+        gather = new_gather()          # (allocates the matrix on rank 0: outside the timed region, like d_out)
+    if do_gather and rank == 0 and cdev == dev:
+        d_out = gather.own_rows()
+    else:
+        d_out = torch.empty((hi - lo, L + 2), dtype=torch.int32, device=dev)
+    chunk_of = [shard_bounds(b[1] - b[0], n_chunks) for b in all_bounds]
 
     acc = {k: [] for k in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "total_steps", "list_entries_read",
                            "ambiguous_steps", "wave_chain_steps", "redo_walks", "overflow_reads")}
@@ -246,18 +258,24 @@ def main():
         seed = args.seed + pass_no[0]
         pass_no[0] += 1
         tot = {k: 0 for k in acc}
-        works = []
+        if do_gather and rank == 0:
+            gather.prefill()   # the rows rank 0 writes itself (isolated starts of the other shards): part of every pass
         for c, (a, b) in enumerate(chunk_bounds):
             eng.simulate_device(mode, p, q, extend, d_starts[a:b], L, seed=seed,
                                 stream_skip=chunk_skip[c], out=d_out[a:b])
             for k in tot:
                 tot[k] += eng.last_stats[k]
             param_index_ms[0] += eng.last_stats["param_index_ms"]
-            if do_gather:  # gather of this chunk over RCCL/xGMI while the next chunk is walked
-                pads[c][: b - a] = d_out[a:b].to(cdev)
-                works.append(dist.gather(pads[c], parts[c], dst=0, async_op=True))
-        for w in works:
-            w.wait()
+            if do_gather:  # this chunk travels over RCCL/xGMI while the next chunk is walked
+                if rank == 0:
+                    if cdev != dev:
+                        gather.full[lo + a: lo + b] = d_out[a:b].to(cdev)
+                    gather.expect([(all_bounds[r][0] + chunk_of[r][c][0], all_bounds[r][0] + chunk_of[r][c][1], r)
+                                   for r in range(1, world)])
+                else:
+                    gather.post(lo + a, lo + b, d_out[a:b])
+        if do_gather:
+            gather.finish()                     # rank 0: the contiguous [n_jobs, L + 2] matrix is complete
         for k in tot:
             acc[k].append(tot[k])
 
@@ -301,13 +319,8 @@ def main():
         return
 
     if os.environ.get("PECANPY_BENCH_VERIFY") and do_gather:
-        # dry-run check of the sharded + chunked addressing: the gathered matrix equals one whole-array run
-        b_all = shard_bounds(n_jobs, world)
-        rows_of = []
-        for r in range(world):
-            cb = shard_bounds(b_all[r][1] - b_all[r][0], n_chunks)
-            rows_of.append(torch.cat([parts[c][r][: cb[c][1] - cb[c][0]] for c in range(n_chunks)], dim=0))
-        gathered = torch.cat(rows_of, dim=0).to(dev)
+        # dry-run check of the sharded + chunked addressing: the assembled matrix equals one whole-array run
+        gathered = gather.full.to(dev)
         whole = eng.simulate_device(mode, p, q, extend, torch.from_numpy(starts.view(np.int32)).to(dev), L,
                                     seed=args.seed + pass_no[0] - 1)
         assert torch.equal(gathered, whole), "gathered shards differ from the single-stream matrix"

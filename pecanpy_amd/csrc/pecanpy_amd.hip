@@ -950,7 +950,7 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 
 // One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
 // walked again by the wave-per-walk kernel.  *n_redo receives their number.
-static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
+static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *n_redo, uint64_t *n_handed) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
     pw::LanesArgs la;
@@ -1016,7 +1016,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         la.ver = g->ver.p;
         la.ver_cap = cap;
     }
-    unsigned long long nr = 0, parked = 0;
+    unsigned long long nr = 0, parked = 0, handed = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
         const bool queue_out = use_queue && todo > tail && round < 64;
@@ -1073,12 +1073,33 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
                 }
             }
         }
+        unsigned long long redo_now = 0;
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
+        if (queue_out) HIP_TRY(hipMemcpyAsync(&redo_now, g->counters.p + 6, sizeof(redo_now), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         if (parked) {   // settle the queue just filled
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
+        }
+        if (redo_now && !getenv("PECANPY_AMD_NO_HAND_BACK")) {
+            // Walks this round could not step (mirrored overflow read, row outside the exact range, tie budget):
+            // walk_kernel takes the step(s) until the walk has sampled a real CSR entry again and hands it back as
+            // one more record of this round's queue -- the next round resumes it with the parked walks.  (Round 2
+            // let walk_kernel finish such walks: 16 k walks kept two wavefronts per CU busy for 15 ms after the
+            // rounds -- they love hubs, where walk_kernel runs whole-row chains.)
+            pw::WalkArgs wr = wa;
+            wr.job_list = g->redo.p;
+            wr.n_list = redo_now;
+            wr.resume = 2u;
+            wr.hand_back = (uint4 *)g->susp[round & 1].p;
+            wr.hand_count = g->counters.p + 32;
+            int rcw = launch_wave_walks(g, wr, extend);
+            if (rcw) return rcw;
+            HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+            HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            handed += redo_now;
         }
         HIP_TRY(hipEventRecord(g->ev[5], g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1124,13 +1145,16 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     }
 #endif
     *n_redo = nr;
+    if (n_handed) *n_handed = handed;
     return 0;
 }
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    int rc = launch_lane_walks(g, wa, &n_redo);
+    uint64_t n_handed = 0;
+    int rc = launch_lane_walks(g, wa, extend, &n_redo, &n_handed);
+    if (redo_total) *redo_total += n_handed;
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range) go to walk_kernel, which resumes
     // them at that step.  (Handing them BACK once they are on a CSR entry again was tried: such walks overflow again
     // and again, and the extra rounds on a nearly empty GPU cost more than walk_kernel's whole-row chains -- 198 vs 189 ms.)
@@ -1271,6 +1295,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.tot_e = nullptr;
     wa.tot_v = nullptr;
     wa.resume = 0;
+    wa.hand_back = nullptr;
+    wa.hand_count = nullptr;
     {
         // unit-weight biases exactly as the kernels form them: fl32(f64(1.0f) / q) (sparse_rw.py:59-62)
         wa.w_out = (float)(1.0 / q);

@@ -207,9 +207,31 @@ __device__ unsigned long long g_lprof[16];
                     for (uint32_t z_ = A.j; z_ <= L; z_++) row_[z_] = 0;                        \
                 }                                                                               \
                 A.flags = 0;                                                                    \
-            } else r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */   \
+            } else PW_LANE_DRAW();                   /* the next step's draw, asked for now */   \
         }                                                                                       \
     } while (0)
+
+// The draws of a walk are consecutive doubles: two are fetched per access (one 16-byte load, 8-byte aligned) and the
+// second waits in a register -- half as many touches of the draw stream's sectors, and every other step starts
+// without that round trip.  (-DPW_LANES_DRAW_PAIRS=0: one 8-byte load per step.)
+#ifndef PW_LANES_DRAW_PAIRS
+#define PW_LANES_DRAW_PAIRS 1
+#endif
+struct __attribute__((packed, aligned(8))) DrawPair {
+    double x, y;
+};
+#if PW_LANES_DRAW_PAIRS
+#define PW_LANE_DRAW()                                                                          \
+    do {                                                                                        \
+        if (have2) { r = r2; have2 = 0u; }                                                      \
+        else if (A.j < L) {      /* (the second draw belongs to this walk's next step) */       \
+            const DrawPair dp_ = *(const DrawPair *)(a.rng + (A.soff + (A.j - 1)));             \
+            r = dp_.x; r2 = dp_.y; have2 = 1u;                                                  \
+        } else r = a.rng[A.soff + (A.j - 1)];                                                   \
+    } while (0)
+#else
+#define PW_LANE_DRAW() do { r = a.rng[A.soff + (A.j - 1)]; } while (0)
+#endif
 
 struct __attribute__((packed, aligned(4))) OutCells {   // four staged output cells: one 16-byte store, 4-byte aligned
     uint32_t v[4];
@@ -255,6 +277,10 @@ walk_lanes_kernel(LanesArgs a) {
     uint32_t n_dead = 0, n_probes = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
+#if PW_LANES_DRAW_PAIRS
+    double r2 = 0.0;                    // the draw after r, when have2
+    uint32_t have2 = 0;
+#endif
     OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
@@ -304,6 +330,9 @@ walk_lanes_kernel(LanesArgs a) {
                         if (slot >= 2u) ob.v[1] = cell[1];
                         if (slot >= 3u) ob.v[2] = cell[2];
                         A.flags = F_ACTIVE | F_PRE;
+#if PW_LANES_DRAW_PAIRS
+                        have2 = 0u;
+#endif
                     }
                 } else {
                     A.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
@@ -318,7 +347,10 @@ walk_lanes_kernel(LanesArgs a) {
                     } else {
                         A.soff = a.stream_off[A.job] - a.rng_base;
                         A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
-                        r = a.rng[A.soff];
+#if PW_LANES_DRAW_PAIRS
+                        have2 = 0u;
+#endif
+                        PW_LANE_DRAW();
                         A.flags = F_ACTIVE;
                     }
                 }
@@ -440,6 +472,7 @@ walk_lanes_kernel(LanesArgs a) {
         LPROF_T(3);
     }
 #undef PW_LANE_APPLY
+#undef PW_LANE_DRAW
     if (a.susp)
         for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES
@@ -469,7 +502,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     if (i < n) {
         const uint4 *qp = (const uint4 *)(q + i);
         const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-        if (q0.x != NOT_FOUND) {
+        if (q0.x != NOT_FOUND && q2.x != 0u) {   // (void slot / a step walk_kernel handed back already settled)
         const float tot = __uint_as_float(q3.x), wo = __uint_as_float(q3.y);
         const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
         const float x_in = 1.0f / tot;

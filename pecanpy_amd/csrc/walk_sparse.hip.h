@@ -124,8 +124,12 @@ struct WalkArgs {
     const float *__restrict__ tot_e;
     const float *__restrict__ tot_v;
     // walks handed over by the lane kernel in mid-walk: the row holds cells 0 .. len - 1 and len (>= 1) in its length
-    // cell; the walk goes on from there instead of being walked again from its start
+    // cell; the walk goes on from there instead of being walked again from its start (1: to its end; 2: only until it
+    // has sampled a real CSR entry again -- that step is not applied but handed BACK to the lane kernel as a record
+    // of its resume queue, hand_back[4 * slot .. + 4) = walk_lanes.hip.h's SuspRec with the choice settled)
     uint32_t resume;
+    uint4 *hand_back;
+    unsigned long long *hand_count;
 };
 #define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
 
@@ -166,6 +170,9 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.lazy_ok = PW_KARG(uint32_t, lazy_ok);
     a.tot_e = (const float *)PW_KARG(uint64_t, tot_e);
     a.tot_v = (const float *)PW_KARG(uint64_t, tot_v);
+    a.resume = 0;
+    a.hand_back = nullptr;
+    a.hand_count = nullptr;
     return a;
 }
 
@@ -1375,6 +1382,7 @@ walk_kernel(WalkArgs a) {
             }
         }
         const uint32_t j_first = j;
+        bool handed = false;
         for (; j <= L; j++) {
             const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
             if (d == 0) {
@@ -1414,6 +1422,19 @@ walk_kernel(WalkArgs a) {
             choice = uni(choice);
             bool clamped = false;
             const bool real_edge = choice < d;
+            if (UNIT && !DENSE && real_edge && PW_KARG(uint32_t, resume) == 2u) {
+                // back on a CSR entry: the lane kernel takes the walk over again and applies this step itself
+                if (lane == 0) {
+                    const unsigned long long slot = atomicAdd((unsigned long long *)PW_KARG(uint64_t, hand_count), 1ull);
+                    uint4 *rec = (uint4 *)PW_KARG(uint64_t, hand_back) + 4ull * slot;
+                    rec[0] = make_uint4((uint32_t)job, j, s0, d);
+                    rec[1] = make_uint4(0u, NOT_FOUND, 0u, 0u);
+                    rec[2] = make_uint4(0u, choice, (uint32_t)soff, (uint32_t)(soff >> 32));   // (kmax 0: settled, no chain to run)
+                    rec[3] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                handed = true;
+                break;
+            }
             if (!real_edge) {
                 if (lane == 0) stat[1]++;
                 if (DENSE) { choice = d - 1; clamped = true; }  // reference reads past a temporary: clamp
@@ -1453,12 +1474,14 @@ walk_kernel(WalkArgs a) {
         }
         // header, tail zeros and length cell (cells j..L stay 0 after an early stop)
         gptr_mut<uint32_t> row = (gptr_mut<uint32_t>)PW_KARG(uint64_t, out) + job * W;
-        if (lane == 0) {
-            row[0] = start;
-            row[L + 1] = len_out;
-            stat[0] += j - j_first;   // transitions sampled here
+        if (lane == 0) stat[0] += j - j_first;   // transitions sampled here
+        if (!handed) {
+            if (lane == 0) {
+                row[0] = start;
+                row[L + 1] = len_out;
+            }
+            for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
         }
-        for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
     }
     wave_lds_fence();
 #ifdef PW_PROF

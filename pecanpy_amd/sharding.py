@@ -11,13 +11,124 @@ import numpy as np
 
 from .engine import shard_bounds
 
-__all__ = ["sharded_walk_matrix", "shard_bounds"]
+__all__ = ["sharded_walk_matrix", "shard_bounds", "RowGather", "isolated_row_filler"]
 
 
 def _dist():
     import torch.distributed as dist
 
     return dist
+
+
+class RowGather:
+    """Assembles the contiguous ``[n_rows, width]`` walk matrix on rank ``dst`` from row shards with point-to-point
+    transfers (RCCL send/recv over xGMI when the backend is ``nccl``) straight INTO row slices of the preallocated
+    matrix: no padded staging tensors, no concatenation afterwards.
+
+    ``bounds[r]`` = rows [lo, hi) rank r produces; every rank may hand its rows over in several pieces
+    (``post(lo, hi, rows)`` on the sender, ``expect([(lo, hi, src), ...])`` on the receiver: consecutive sub-ranges of
+    a shard, in the same order on both sides -- the transfer of one piece overlaps the walk kernel of the next).  ``known`` (optional bool array over all rows): rows whose content the receiver can
+    write itself and which are therefore NOT sent -- walks from starts without neighbours are ``[start, 0, ..., 0, 1]``
+    (reference src/pecanpy/pecanpy.py:190-193), half of an R-MAT job array; ``fill_known(full, idx)`` writes them.
+    ``dst``'s own rows are expected to be produced in place (``own_rows()`` is a view of the matrix).
+    """
+
+    def __init__(self, n_rows, width, bounds, dtype, device, dst=0, group=None, known=None, fill_known=None):
+        import torch
+
+        self.dist = _dist()
+        self.torch = torch
+        self.group, self.dst = group, dst
+        self.rank = self.dist.get_rank(group)
+        self.bounds = bounds
+        self.known = None if known is None else np.asarray(known, dtype=bool)
+        self.device = device
+        self.full = torch.empty((n_rows, width), dtype=dtype, device=device) if self.rank == dst else None
+        self._works, self._scatters, self._sent = [], [], []
+        self._sel_cache = {}
+        self._known_idx, self._fill_known = None, fill_known
+        if self.rank == dst and self.known is not None and fill_known is not None:
+            lo, hi = bounds[dst]
+            other = self.known.copy()
+            other[lo:hi] = False                      # (own rows: written by the walk kernel itself)
+            self._known_idx = torch.from_numpy(np.flatnonzero(other)).to(device)
+        self.prefill()
+
+    def prefill(self):
+        """Receiver: writes the rows nobody sends (once per assembled matrix; a benchmark calls it every pass)."""
+        if self._known_idx is not None and self._known_idx.numel():
+            self._fill_known(self.full, self._known_idx)
+
+    def own_rows(self):
+        lo, hi = self.bounds[self.dst]
+        return self.full[lo:hi]
+
+    def _sel(self, lo, hi, device, offset=0):
+        """index tensor (relative to lo, plus offset) of the rows of [lo, hi) that travel; None: all of them.  Cached:
+        a benchmark posts the same pieces every pass."""
+        if self.known is None:
+            return None
+        key = (lo, hi, str(device), offset)
+        if key not in self._sel_cache:
+            k = self.known[lo:hi]
+            self._sel_cache[key] = None if not k.any() else self.torch.from_numpy(np.flatnonzero(~k) + offset).to(device)
+        return self._sel_cache[key]
+
+    def post(self, lo, hi, rows):
+        """Sender: starts the transfer of ``rows`` = its rows [lo, hi) (minus the known ones)."""
+        torch = self.torch
+        if hi <= lo or self.rank == self.dst:
+            return
+        sel = self._sel(lo, hi, rows.device)
+        buf = rows if sel is None else rows.index_select(0, sel)
+        if buf.shape[0] == 0:
+            return
+        buf = buf.contiguous().to(self.device)
+        self._sent.append(buf)                        # (kept alive until the transfer is over)
+        self._works += self.dist.batch_isend_irecv([self.dist.P2POp(self.dist.isend, buf, self.dst, self.group)])
+
+    def expect(self, pieces):
+        """Receiver: starts the receives matching one ``post`` of every sender -- ``pieces`` = [(lo, hi, src), ...] --
+        as ONE group, so that the transfers of different peers run side by side (one xGMI link each)."""
+        torch = self.torch
+        if self.rank != self.dst:
+            return
+        ops = []
+        for lo, hi, src in pieces:
+            if hi <= lo:
+                continue
+            sel = self._sel(lo, hi, self.device, lo)
+            if sel is None:
+                ops.append(self.dist.P2POp(self.dist.irecv, self.full[lo:hi], src, self.group))
+            elif sel.numel():
+                stage = torch.empty((sel.numel(), self.full.shape[1]), dtype=self.full.dtype, device=self.device)
+                ops.append(self.dist.P2POp(self.dist.irecv, stage, src, self.group))
+                self._scatters.append((sel, stage))
+        if ops:
+            self._works += self.dist.batch_isend_irecv(ops)
+
+    def finish(self):
+        """Waits for every transfer; the receiver then holds the complete matrix (returned; others get None)."""
+        for w in self._works:
+            w.wait()
+        for idx, stage in self._scatters:
+            self.full.index_copy_(0, idx, stage)
+        self._works, self._scatters, self._sent = [], [], []
+        return self.full
+
+
+def isolated_row_filler(starts, walk_length, device):
+    """``fill_known`` for RowGather: rows of walks whose start has no neighbour are ``[start, 0, ..., 0, 1]``."""
+    import torch
+
+    st = torch.from_numpy(np.ascontiguousarray(starts).view(np.int32)).to(device)
+
+    def fill(full, idx):
+        full.index_fill_(0, idx, 0)
+        full[idx, 0] = st[idx]
+        full[idx, walk_length + 1] = 1
+
+    return fill
 
 
 def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None, dst=None,
@@ -75,19 +186,22 @@ def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None,
 
     if not gather:
         return walks, (lo, hi)
-    # one gather of the shards (row counts differ by at most one: pad to the widest)
     width = walk_length + 2
+    if dst is not None:
+        # the shards go straight into their rows of ONE preallocated matrix on rank dst (no pads, no cat)
+        rg = RowGather(n_jobs, width, bounds, walks.dtype, walks.device, dst=dst, group=group)
+        if rank == dst:
+            rg.own_rows().copy_(walks)
+            rg.expect([(bounds[r][0], bounds[r][1], r) for r in range(world) if r != dst])
+        else:
+            rg.post(lo, hi, walks)
+        return rg.finish()
+    # every rank wants the whole matrix: one all-gather of the shards (row counts differ by at most one: pad to the widest)
     rows = max(b[1] - b[0] for b in bounds)
     padded = torch.zeros((rows, width), dtype=walks.dtype, device=walks.device)
     padded[: hi - lo] = walks
-    if dst is None:
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(parts, padded, group=group)
-    else:
-        parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-        dist.gather(padded, parts, dst=dst, group=group)
-        if rank != dst:
-            return None
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
     return torch.cat([parts[r][: bounds[r][1] - bounds[r][0]] for r in range(world)], dim=0)
 
 

@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import pyoracle as orc
-from pecanpy_amd.sharding import shard_bounds, sharded_walk_matrix, to_uint32_numpy
+from pecanpy_amd.sharding import RowGather, isolated_row_filler, shard_bounds, sharded_walk_matrix, to_uint32_numpy
 from pecanpy_amd.synth import rmat_csr
 
 
@@ -124,3 +124,47 @@ def test_unseeded_ranks_shuffle_the_same_job_array():
         assert np.array_equal(ret["starts0"], ret["starts1"])
         n = ret["starts0"].size // 3
         assert np.array_equal(np.bincount(ret["starts0"], minlength=n), np.full(n, 3))
+
+
+def _gather_worker(rank, world, port, ret):
+    """bench.py's data path: every shard walked in chunks, each chunk's rows posted while the next is walked; rows of
+    isolated starts are not sent (rank 0 writes them itself); rank 0 walks its own shard in place."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    indptr, indices, data = rmat_csr(9, seed=5)
+    L, seed, n_chunks = 12, 3, 3
+    starts = orc.shuffled_starts(indptr.size - 1, 3, seed)
+    has = (indptr[1:] != indptr[:-1])[starts]
+    n_jobs = starts.size
+    bounds = shard_bounds(n_jobs, world)
+    dev = torch.device("cpu")
+    rg = RowGather(n_jobs, L + 2, bounds, torch.int32, dev, dst=0, known=~has, fill_known=isolated_row_filler(starts, L, dev))
+    lo, hi = bounds[rank]
+    chunks = [(lo + a, lo + b) for a, b in shard_bounds(hi - lo, n_chunks)]
+    for c in range(n_chunks):
+        a, b = chunks[c]
+        skip = int(has[:a].sum()) * L
+        mat = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts[a:b], L, seed, stream_skip=skip)
+        rows = torch.from_numpy(mat.view(np.int32).copy())
+        if rank == 0:
+            rg.full[a:b] = rows                  # (the walk kernel writes rank 0's rows in place)
+            rg.expect([(bounds[r][0] + shard_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][0],
+                        bounds[r][0] + shard_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][1], r) for r in range(1, world)])
+        else:
+            rg.post(a, b, rows)
+    full = rg.finish()
+    if rank == 0:
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, L, seed)
+        ret["ok"] = bool(np.array_equal(to_uint32_numpy(full), want))
+        ret["isolated"] = int((~has).sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunked_gather_into_row_slices_skipping_isolated_rows(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["ok"] and ret["isolated"] > 0
