@@ -109,6 +109,8 @@ struct pw_graph {
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: work that overlaps the main stream's (zero-fill of the walk matrix under the
+    hipEvent_t ev_side = nullptr;    // stream expansion; walk_kernel over the first round's redo list under the later rounds)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *stage[2] = {nullptr, nullptr};   // pinned staging buffers of pw_simulate's copy out
     double lane_ms = 0;              // lane kernel time of the current call
@@ -249,6 +251,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
         if (b) (void)hipHostFree(b);
     for (auto &e : g->ev)
         if (e) (void)hipEventDestroy(e);
+    if (g->ev_side) (void)hipEventDestroy(g->ev_side);
+    if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -263,6 +267,8 @@ static int graph_common_init(pw_graph *g, int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     g->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming));
     for (auto &e : g->ev) HIP_TRY(hipEventCreate(&e));
     return 0;
 }
@@ -479,7 +485,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
-    if (g->unit && nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {
+    if (nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {   // (weighted graphs too: membership does not depend on the weights)
         // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel); skipped for
         // graphs with self loops, where "common neighbour" and the reference's prev handling differ
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
@@ -718,6 +724,8 @@ static pw::CsrDev csr_dev(const pw_graph *g) {
     c.tab_off = g->d_tab_off;
     c.slots = g->d_slots;
     c.tri = (const uint4 *)g->d_lines;   // (stride: one 64-byte line per CSR entry)
+    c.clist = g->d_clist;
+    c.step_edge = 0xffffffffu;
     c.vrec = g->d_vrec;
     c.words_per_row = g->words_per_row;
     c.n_nodes = g->n_nodes;
@@ -925,7 +933,8 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     return 0;
 }
 
-static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
+// (side: on the handle's second stream with a job counter of its own, next to work of the main stream)
+static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, bool side = false) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
     if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa);
@@ -938,8 +947,10 @@ static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
-    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+    hipStream_t st = side ? g->stream2 : g->stream;
+    if (side) wa.job_counter = g->counters.p + 12;
+    HIP_TRY(hipMemsetAsync(wa.job_counter, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, st, wa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -950,7 +961,8 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 
 // One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
 // walked again by the wave-per-walk kernel.  *n_redo receives their number.
-static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *n_redo, uint64_t *n_handed) {
+// *n_redo: walks handed to walk_kernel; *n_early: the first of them, already being walked on the side stream.
+static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *n_redo, uint64_t *n_early) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
     pw::LanesArgs la;
@@ -1016,7 +1028,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
         la.ver = g->ver.p;
         la.ver_cap = cap;
     }
-    unsigned long long nr = 0, parked = 0, handed = 0;
+    unsigned long long nr = 0, parked = 0, early = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
         const bool queue_out = use_queue && todo > tail && round < 64;
@@ -1075,31 +1087,25 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
         }
         unsigned long long redo_now = 0;
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
-        if (queue_out) HIP_TRY(hipMemcpyAsync(&redo_now, g->counters.p + 6, sizeof(redo_now), hipMemcpyDeviceToHost, g->stream));
+        if (round == 0) HIP_TRY(hipMemcpyAsync(&redo_now, g->counters.p + 6, sizeof(redo_now), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
+        if (round == 0 && parked && redo_now && !getenv("PECANPY_AMD_NO_EARLY_REDO")) {
+            // Most walks the lane kernel cannot step (mirrored overflow reads: 16 k of 21 M at RMAT-22) drop out in the
+            // first round.  walk_kernel finishes them on the side stream WHILE the later rounds run (a few thousand
+            // wavefronts of whole-row chains on hub rows: 15 ms that used to follow the last round).  Rows, redo
+            // entries and job counter are disjoint from what the rounds touch; the statistics are atomic adds.
+            pw::WalkArgs wr = wa;
+            wr.job_list = g->redo.p;
+            wr.n_list = redo_now;
+            wr.resume = 1u;
+            int rcw = launch_wave_walks(g, wr, extend, true);
+            if (rcw) return rcw;
+            early = redo_now;
+        }
         if (parked) {   // settle the queue just filled
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
-        }
-        if (redo_now && !getenv("PECANPY_AMD_NO_HAND_BACK")) {
-            // Walks this round could not step (mirrored overflow read, row outside the exact range, tie budget):
-            // walk_kernel takes the step(s) until the walk has sampled a real CSR entry again and hands it back as
-            // one more record of this round's queue -- the next round resumes it with the parked walks.  (Round 2
-            // let walk_kernel finish such walks: 16 k walks kept two wavefronts per CU busy for 15 ms after the
-            // rounds -- they love hubs, where walk_kernel runs whole-row chains.)
-            pw::WalkArgs wr = wa;
-            wr.job_list = g->redo.p;
-            wr.n_list = redo_now;
-            wr.resume = 2u;
-            wr.hand_back = (uint4 *)g->susp[round & 1].p;
-            wr.hand_count = g->counters.p + 32;
-            int rcw = launch_wave_walks(g, wr, extend);
-            if (rcw) return rcw;
-            HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
-            HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
-            HIP_TRY(hipStreamSynchronize(g->stream));
-            handed += redo_now;
         }
         HIP_TRY(hipEventRecord(g->ev[5], g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1144,25 +1150,32 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
                 hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[5] ? (double)hp[4] / (double)hp[5] : 0.0);
     }
 #endif
+    if (early) {   // the main stream goes on when the side stream's walks are done
+        HIP_TRY(hipEventRecord(g->ev_side, g->stream2));
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_side, 0));
+    }
     *n_redo = nr;
-    if (n_handed) *n_handed = handed;
+    *n_early = early;
     return 0;
 }
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    uint64_t n_handed = 0;
-    int rc = launch_lane_walks(g, wa, extend, &n_redo, &n_handed);
-    if (redo_total) *redo_total += n_handed;
-    // Walks the lane kernel cannot step (overflow reads, rows outside the exact range) go to walk_kernel, which resumes
-    // them at that step.  (Handing them BACK once they are on a CSR entry again was tried: such walks overflow again
-    // and again, and the extra rounds on a nearly empty GPU cost more than walk_kernel's whole-row chains -- 198 vs 189 ms.)
+    uint64_t n_early = 0;
+    int rc = launch_lane_walks(g, wa, extend, &n_redo, &n_early);
+    // Walks the lane kernel cannot step (overflow reads, rows outside the exact range, tie budget) go to walk_kernel,
+    // which resumes them at that step and finishes them.  Measured and rejected: handing them BACK to the lane kernel
+    // once they are on a CSR entry again -- as extra cycles after the rounds (198 vs 189 ms per RMAT-22 pass, round 2)
+    // or after ONE eager step, every round followed by a walk_kernel launch over its redo list (200 vs 181 ms, round
+    // 3): such walks overflow again and again, an eager step on a 97 k-entry hub row takes milliseconds, and each
+    // launch waits for the slowest of them.
     if (rc || !n_redo) return rc;
     if (redo_total) *redo_total += n_redo;
+    if (n_redo == n_early) return 0;
     pw::WalkArgs wr = wa;
-    wr.job_list = g->redo.p;
-    wr.n_list = n_redo;
+    wr.job_list = g->redo.p + n_early;
+    wr.n_list = n_redo - n_early;
     wr.resume = 1u;   // from the step the lane kernel stopped at (its rows hold the walks so far)
     return launch_wave_walks(g, wr, extend);
 }
@@ -1200,6 +1213,11 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     int rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, false, &total, nullptr);
     if (rc) return rc;
 
+    const bool lanes_pre = g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && mode == PW_MODE_SPARSE_OTF;
+    if (lanes_pre) {   // (zero-fill of the walk matrix for the lane kernel: overlapped with the stream expansion)
+        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream2));
+        HIP_TRY(hipEventRecord(g->ev_side, g->stream2));
+    }
     // 2. MT19937 doubles covering [stream_skip, stream_skip + total): n_gen generators, each
     //    expanding `per_gen` (a power of two) consecutive blocks; generator states come from the
     //    seed state by polynomial jump-ahead on the device (binary tree of x^(624*2^m) jumps).
@@ -1209,7 +1227,9 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
     uint64_t per_gen = 1;
     int per_gen_log = 0;
-    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }
+    const char *gens_env = getenv("PECANPY_AMD_MT_GENS");
+    const uint64_t max_gen = gens_env ? (uint64_t)strtoull(gens_env, nullptr, 10) : 1024;
+    while (per_gen * max_gen < n_blocks) { per_gen <<= 1; per_gen_log++; }
     const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
     if (!g->jump_table_ready) {
         const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
@@ -1295,8 +1315,6 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.tot_e = nullptr;
     wa.tot_v = nullptr;
     wa.resume = 0;
-    wa.hand_back = nullptr;
-    wa.hand_count = nullptr;
     {
         // unit-weight biases exactly as the kernels form them: fl32(f64(1.0f) / q) (sparse_rw.py:59-62)
         wa.w_out = (float)(1.0 / q);
@@ -1316,8 +1334,9 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     g->lane_rounds = 0;
     g->ver_checked = g->ver_mismatch = g->ver_dropped = g->ver_ties = 0;
     HIP_TRY(hipEventRecord(g->ev[2], g->stream));
-    // the lane kernel only writes the cells a walk fills: the matrix starts zeroed (pecanpy.py:182-187)
-    if (lanes) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
+    // the lane kernel only writes the cells a walk fills: the matrix starts zeroed (pecanpy.py:182-187) -- by the side
+    // stream, under the stream expansion above
+    if (lanes_pre) HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_side, 0));
     rc = launch_walks(g, wa, extend != 0, &redo_total);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->ev[3], g->stream));

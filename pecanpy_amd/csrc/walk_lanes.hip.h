@@ -36,20 +36,6 @@
 
 namespace pw {
 
-// Edge line of CSR entry e = (u -> v): one 64-byte aligned record -- everything a step needs about the edge it
-// arrives by and, for the short lists that most steps meet, the list itself: ONE sector per step for both.
-struct ELine {
-    uint32_t nxt;       // v
-    uint32_t n_in;      // |N(u) & N(v)|
-    uint32_t rev_pos;   // position of u in row v, NOT_FOUND when (v -> u) is not an edge
-    uint32_t deg;       // degree(v)       (these four words: the record walk_kernel's lazy step reads)
-    uint32_t s0;        // indptr[v]
-    uint32_t coff;      // list in the overflow array: offset in 16-byte units (n_in > EL_INLINE or degree(v) > 65536)
-    uint16_t inl[20];   // the list itself when n_in <= EL_INLINE and degree(v) <= 65536: uint16 positions in row v
-};
-static_assert(sizeof(ELine) == 64, "edge line is one 64-byte sector");
-constexpr uint32_t EL_INLINE = 20;
-
 // A walk parked at a step that only the float32 chain can settle: everything the step and the rest of the walk
 // need.  The lane kernel appends these to a queue instead of running the chain with a handful of its 64 lanes enabled;
 // lanes_chain_kernel settles a whole queue at full width (choice), and the next lane launch resumes the walks.
@@ -70,14 +56,6 @@ struct VerRec {
     double r;
 };
 static_assert(sizeof(VerRec) == 48, "verification record is three 16-byte stores");
-
-// the list of common-neighbour positions of the edge a walk arrived by (n_in == 0: never dereferenced)
-__device__ __forceinline__ ListView edge_list(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t d, uint32_t n_in,
-                                              uint32_t coff) {
-    const bool narrow = d <= 65536u;
-    const uint8_t *p = (narrow && n_in <= EL_INLINE) ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
-    return ListView{p, narrow ? 0u : 1u};
-}
 
 struct LanesArgs {
     const ELine *__restrict__ lines;
@@ -207,31 +185,9 @@ __device__ unsigned long long g_lprof[16];
                     for (uint32_t z_ = A.j; z_ <= L; z_++) row_[z_] = 0;                        \
                 }                                                                               \
                 A.flags = 0;                                                                    \
-            } else PW_LANE_DRAW();                   /* the next step's draw, asked for now */   \
+            } else r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */   \
         }                                                                                       \
     } while (0)
-
-// The draws of a walk are consecutive doubles: two are fetched per access (one 16-byte load, 8-byte aligned) and the
-// second waits in a register -- half as many touches of the draw stream's sectors, and every other step starts
-// without that round trip.  (-DPW_LANES_DRAW_PAIRS=0: one 8-byte load per step.)
-#ifndef PW_LANES_DRAW_PAIRS
-#define PW_LANES_DRAW_PAIRS 1
-#endif
-struct __attribute__((packed, aligned(8))) DrawPair {
-    double x, y;
-};
-#if PW_LANES_DRAW_PAIRS
-#define PW_LANE_DRAW()                                                                          \
-    do {                                                                                        \
-        if (have2) { r = r2; have2 = 0u; }                                                      \
-        else if (A.j < L) {      /* (the second draw belongs to this walk's next step) */       \
-            const DrawPair dp_ = *(const DrawPair *)(a.rng + (A.soff + (A.j - 1)));             \
-            r = dp_.x; r2 = dp_.y; have2 = 1u;                                                  \
-        } else r = a.rng[A.soff + (A.j - 1)];                                                   \
-    } while (0)
-#else
-#define PW_LANE_DRAW() do { r = a.rng[A.soff + (A.j - 1)]; } while (0)
-#endif
 
 struct __attribute__((packed, aligned(4))) OutCells {   // four staged output cells: one 16-byte store, 4-byte aligned
     uint32_t v[4];
@@ -277,10 +233,6 @@ walk_lanes_kernel(LanesArgs a) {
     uint32_t n_dead = 0, n_probes = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
-#if PW_LANES_DRAW_PAIRS
-    double r2 = 0.0;                    // the draw after r, when have2
-    uint32_t have2 = 0;
-#endif
     OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
@@ -330,9 +282,6 @@ walk_lanes_kernel(LanesArgs a) {
                         if (slot >= 2u) ob.v[1] = cell[1];
                         if (slot >= 3u) ob.v[2] = cell[2];
                         A.flags = F_ACTIVE | F_PRE;
-#if PW_LANES_DRAW_PAIRS
-                        have2 = 0u;
-#endif
                     }
                 } else {
                     A.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
@@ -347,10 +296,7 @@ walk_lanes_kernel(LanesArgs a) {
                     } else {
                         A.soff = a.stream_off[A.job] - a.rng_base;
                         A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
-#if PW_LANES_DRAW_PAIRS
-                        have2 = 0u;
-#endif
-                        PW_LANE_DRAW();
+                        r = a.rng[A.soff];
                         A.flags = F_ACTIVE;
                     }
                 }
@@ -472,7 +418,6 @@ walk_lanes_kernel(LanesArgs a) {
         LPROF_T(3);
     }
 #undef PW_LANE_APPLY
-#undef PW_LANE_DRAW
     if (a.susp)
         for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES
@@ -502,7 +447,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     if (i < n) {
         const uint4 *qp = (const uint4 *)(q + i);
         const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-        if (q0.x != NOT_FOUND && q2.x != 0u) {   // (void slot / a step walk_kernel handed back already settled)
+        if (q0.x != NOT_FOUND) {
         const float tot = __uint_as_float(q3.x), wo = __uint_as_float(q3.y);
         const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
         const float x_in = 1.0f / tot;

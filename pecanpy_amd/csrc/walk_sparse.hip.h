@@ -35,6 +35,30 @@
 
 namespace pw {
 
+constexpr uint32_t NOT_FOUND = 0xffffffffu;
+
+// Edge line of CSR entry e = (u -> v): one 64-byte aligned record -- everything a step needs about the edge it
+// arrives by and, for the short lists that most steps meet, the list itself: ONE sector per step for both.
+struct ELine {
+    uint32_t nxt;       // v
+    uint32_t n_in;      // |N(u) & N(v)|
+    uint32_t rev_pos;   // position of u in row v, NOT_FOUND when (v -> u) is not an edge
+    uint32_t deg;       // degree(v)       (these four words: the record walk_kernel's lazy step reads)
+    uint32_t s0;        // indptr[v]
+    uint32_t coff;      // list in the overflow array: offset in 16-byte units (n_in > EL_INLINE or degree(v) > 65536)
+    uint16_t inl[20];   // the list itself when n_in <= EL_INLINE and degree(v) <= 65536: uint16 positions in row v
+};
+static_assert(sizeof(ELine) == 64, "edge line is one 64-byte sector");
+constexpr uint32_t EL_INLINE = 20;
+
+// the list of common-neighbour positions of the edge a walk arrived by (n_in == 0: never dereferenced)
+__device__ __forceinline__ ListView edge_list(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t d, uint32_t n_in,
+                                              uint32_t coff) {
+    const bool narrow = d <= 65536u;
+    const uint8_t *p = (narrow && n_in <= EL_INLINE) ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+    return ListView{p, narrow ? 0u : 1u};
+}
+
 struct CsrDev {
     const uint32_t *__restrict__ indptr;
     const uint32_t *__restrict__ indices;
@@ -78,6 +102,11 @@ struct CsrDev {
     // names the next vertex and tells which of the two rows will supply the keys.  nullptr: not built
     // (graphs with self loops).
     const uint4 *__restrict__ tri;
+    const uint8_t *__restrict__ clist;   // ... and the lists too long for their edge line
+    // the CSR entry (prev -> cur) the step being sampled arrived by, or NOT_FOUND (first step, mirrored overflow
+    // read, resumed walk): set in the per-step copy of the arguments; with it the membership mask of the step is
+    // scattered from the entry's list instead of being searched (build_mask_list)
+    uint32_t step_edge;
     uint32_t n_nodes;
     uint32_t nnz;
 };
@@ -124,12 +153,8 @@ struct WalkArgs {
     const float *__restrict__ tot_e;
     const float *__restrict__ tot_v;
     // walks handed over by the lane kernel in mid-walk: the row holds cells 0 .. len - 1 and len (>= 1) in its length
-    // cell; the walk goes on from there instead of being walked again from its start (1: to its end; 2: only until it
-    // has sampled a real CSR entry again -- that step is not applied but handed BACK to the lane kernel as a record
-    // of its resume queue, hand_back[4 * slot .. + 4) = walk_lanes.hip.h's SuspRec with the choice settled)
+    // cell; the walk goes on from there instead of being walked again from its start
     uint32_t resume;
-    uint4 *hand_back;
-    unsigned long long *hand_count;
 };
 #define PW_KARG(T, field) kernarg<T>(offsetof(WalkArgs, field))
 
@@ -150,6 +175,8 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.g.slots = (const uint64_t *)PW_KARG(uint64_t, g.slots);
     a.g.vrec = (const uint4 *)PW_KARG(uint64_t, g.vrec);
     a.g.tri = (const uint4 *)PW_KARG(uint64_t, g.tri);
+    a.g.clist = (const uint8_t *)PW_KARG(uint64_t, g.clist);
+    a.g.step_edge = NOT_FOUND;
     a.g.n_nodes = PW_KARG(uint32_t, g.n_nodes);
     a.g.nnz = PW_KARG(uint32_t, g.nnz);
     a.p = PW_KARG(double, p);
@@ -171,8 +198,6 @@ __device__ __forceinline__ WalkArgs reload_walk_args() {
     a.tot_e = (const float *)PW_KARG(uint64_t, tot_e);
     a.tot_v = (const float *)PW_KARG(uint64_t, tot_v);
     a.resume = 0;
-    a.hand_back = nullptr;
-    a.hand_count = nullptr;
     return a;
 }
 
@@ -271,8 +296,6 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MASK_WORDS = PW_MASK_WORDS;        // per wave: 32*MASK_WORDS neighbours per segment
 constexpr uint32_t SEG = MASK_WORDS * 32;
 constexpr int EPL = 4;                           // elements per lane per generic scan pass
-constexpr uint32_t NOT_FOUND = 0xffffffffu;
-
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
 __device__ __forceinline__ double uni(double v) {
     return __longlong_as_double((long long)readfirst_u64((uint64_t)__double_as_longlong(v)));
@@ -833,13 +856,67 @@ template <typename T> __device__ __forceinline__ bool is_pow2_fp(T x) {
     return (FloatTraits<T>::bits(x) & (((U)1 << FloatTraits<T>::MANT) - 1)) == 0;
 }
 
-// Membership mask of one segment: search-based (sparse) or bit-test based (dense adjacency bits).
+// Membership mask of one segment from the lane index (walk_lanes.hip.h): the walker arrived by CSR entry e = (prev ->
+// cur), whose list holds the positions in cur's row of the common neighbours of prev and cur -- the mask is those
+// positions, scattered; no key stream, no filter, no index probe.  node2vec+ (in_mask): the i-th entry of the REVERSE
+// entry's list (cur -> prev: same common neighbours, same order, positions in prev's row) locates w(prev, x).
+// r0 = the entry's record { cur, n_in, position of prev in cur's row, degree(cur) }.
+template <typename T>
+__device__ __forceinline__ uint32_t build_mask_list(const CsrDev &g, uint32_t *mask, uint32_t e, const uint4 r0, uint32_t s0,
+                                                    uint32_t a, uint32_t len, uint32_t t0, uint32_t dp, uint32_t *in_mask,
+                                                    const T *__restrict__ data) {
+    const int lane = lane_id();
+    const uint32_t nwords = (len + 31) >> 5;
+    for (uint32_t w = lane; w < nwords; w += WAVE) {
+        mask[w] = 0;
+        if (in_mask) in_mask[w] = 0;
+    }
+    wave_lds_fence();
+    const ELine *lines = (const ELine *)g.tri;
+    const uint32_t n_in = r0.y, rev = r0.z, d = r0.w;
+    const ListView P = edge_list(lines, g.clist, e, d, n_in, lines[e].coff);
+    // list entries whose position lies in [a, a + len) (the list is ascending; one segment: all of them)
+    uint32_t lo_i = 0, hi_i = n_in;
+    if (a != 0 || len < d) {
+        uint32_t lo = 0, hi = n_in;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P.at(mid) < a) lo = mid + 1; else hi = mid; }
+        lo_i = lo;
+        hi = n_in;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P.at(mid) < a + len) lo = mid + 1; else hi = mid; }
+        hi_i = lo;
+    }
+    ListView Q = P;
+    if (in_mask) {
+        const uint32_t e2 = s0 + rev;   // (the caller checked that the reverse entry exists)
+        Q = edge_list(lines, g.clist, e2, dp, lines[e2].n_in, lines[e2].coff);
+    }
+    for (uint32_t i = lo_i + (uint32_t)lane; i < hi_i; i += WAVE) {
+        const uint32_t pos = P.at(i), rel = pos - a;
+        atomicOr(&mask[rel >> 5], 1u << (rel & 31));
+        if (in_mask) {
+            const uint32_t x = g.indices[s0 + pos];
+            if (Arith<T>::in_edge(data[t0 + Q.at(i)], g.thr[x])) atomicOr(&in_mask[rel >> 5], 1u << (rel & 31));
+        }
+    }
+    wave_lds_fence();
+    return (rev != NOT_FOUND && rev >= a && rev < a + len) ? rev : NOT_FOUND;
+}
+
+// Membership mask of one segment: from the arriving entry's list (sparse, lane index present), search-based (sparse)
+// or bit-test based (dense adjacency bits).
 template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t segment_mask(const CsrDev &g, uint32_t *mask, uint32_t *in_mask,
                                                  uint32_t *queue, uint32_t cur, uint32_t s0, uint32_t sa,
                                                  uint32_t len, uint32_t t0, uint32_t dp, uint32_t prev) {
     const T *__restrict__ data = (const T *)g.data;
     if (DENSE) return build_mask_bits<T>(g, mask, s0, sa, len, t0, dp, prev, in_mask, data);
+    if (g.tri && g.step_edge != NOT_FOUND) {
+        const uint32_t e = uni(g.step_edge);
+        const uint4 r0 = g.tri[4ull * e];
+        const uint4 u0 = make_uint4(uni(r0.x), uni(r0.y), uni(r0.z), uni(r0.w));
+        // (node2vec+ on a directed graph without the reverse entry: the weight w(prev, x) has to be searched)
+        if (u0.x == cur && (!in_mask || u0.z != NOT_FOUND)) return build_mask_list<T>(g, mask, e, u0, s0, sa, len, t0, dp, in_mask, data);
+    }
     return build_mask<T>(g, mask, queue, cur, prev, s0, sa, len, t0, dp, in_mask, data);
 }
 
@@ -1382,7 +1459,6 @@ walk_kernel(WalkArgs a) {
             }
         }
         const uint32_t j_first = j;
-        bool handed = false;
         for (; j <= L; j++) {
             const uint32_t s0 = vc.s0, d = vc.d, t0 = vp.s0, dp = vp.d;
             if (d == 0) {
@@ -1400,14 +1476,16 @@ walk_kernel(WalkArgs a) {
 #endif
                 if (choice == LAZY_FALLBACK) {
                     PROF_TICK(pf, 1);
-                    const WalkArgs la = reload_walk_args();
+                    WalkArgs la = reload_walk_args();
+                    la.g.step_edge = j >= 2 ? prev_edge : NOT_FOUND;
                     choice = sample_step_unit<T, DENSE>(la, mask, rank, queue, cur, j >= 2, prev, t0, dp, r, s0, d);
                     PROF_TICK(pf, 6);
                     PROF_COUNT(pf, 10, 1);
                 }
             }
             else {
-                const WalkArgs la = reload_walk_args();   // arguments are not kept live across the loop
+                WalkArgs la = reload_walk_args();   // arguments are not kept live across the loop
+                la.g.step_edge = j >= 2 ? prev_edge : NOT_FOUND;
                 // normaliser of this transition from the per-edge table (float32 CSR graphs), when the walker
                 // arrived by a real CSR entry
                 T ktot = (T)0;
@@ -1422,19 +1500,6 @@ walk_kernel(WalkArgs a) {
             choice = uni(choice);
             bool clamped = false;
             const bool real_edge = choice < d;
-            if (UNIT && !DENSE && real_edge && PW_KARG(uint32_t, resume) == 2u) {
-                // back on a CSR entry: the lane kernel takes the walk over again and applies this step itself
-                if (lane == 0) {
-                    const unsigned long long slot = atomicAdd((unsigned long long *)PW_KARG(uint64_t, hand_count), 1ull);
-                    uint4 *rec = (uint4 *)PW_KARG(uint64_t, hand_back) + 4ull * slot;
-                    rec[0] = make_uint4((uint32_t)job, j, s0, d);
-                    rec[1] = make_uint4(0u, NOT_FOUND, 0u, 0u);
-                    rec[2] = make_uint4(0u, choice, (uint32_t)soff, (uint32_t)(soff >> 32));   // (kmax 0: settled, no chain to run)
-                    rec[3] = make_uint4(0u, 0u, 0u, 0u);
-                }
-                handed = true;
-                break;
-            }
             if (!real_edge) {
                 if (lane == 0) stat[1]++;
                 if (DENSE) { choice = d - 1; clamped = true; }  // reference reads past a temporary: clamp
@@ -1474,14 +1539,12 @@ walk_kernel(WalkArgs a) {
         }
         // header, tail zeros and length cell (cells j..L stay 0 after an early stop)
         gptr_mut<uint32_t> row = (gptr_mut<uint32_t>)PW_KARG(uint64_t, out) + job * W;
-        if (lane == 0) stat[0] += j - j_first;   // transitions sampled here
-        if (!handed) {
-            if (lane == 0) {
-                row[0] = start;
-                row[L + 1] = len_out;
-            }
-            for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
+        if (lane == 0) {
+            row[0] = start;
+            row[L + 1] = len_out;
+            stat[0] += j - j_first;   // transitions sampled here
         }
+        for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
     }
     wave_lds_fence();
 #ifdef PW_PROF
@@ -1522,7 +1585,8 @@ tot_build_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused
     const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
     float tot = 0.0f;
     if (d) {
-        const WalkArgs la = reload_walk_args();
+        WalkArgs la = reload_walk_args();
+        la.g.step_edge = is_edge ? (uint32_t)item : NOT_FOUND;
         (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur,
                                                  is_edge, prev, t0, dp, 0.0, s0, d, nullptr, &tot);
     }
@@ -1554,11 +1618,15 @@ step_probe_kernel(WalkArgs a_unused, const ProbeArgs *pa_unused) {
     const int lane = lane_id();
     constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
     const ProbeArgs pa = *(const ProbeArgs *)kernarg<uint64_t>(XARG);
-    const WalkArgs la = reload_walk_args();
+    WalkArgs la = reload_walk_args();
     const uint32_t cur = uni(pa.cur), prev = uni(pa.prev);
     const bool has_prev = uni(pa.has_prev) != 0u;
     const uint32_t s0 = uni(la.g.indptr[cur]), d = uni(la.g.indptr[cur + 1]) - s0;
     const uint32_t t0 = has_prev ? uni(la.g.indptr[prev]) : 0u, dp = has_prev ? uni(la.g.indptr[prev + 1]) - t0 : 0u;
+    if (!DENSE && has_prev && dp) {   // the CSR entry (prev -> cur), when there is one: its list gives the membership mask
+        const uint32_t pe = uni(lower_bound_u32(la.g.indices + t0, dp, cur));
+        if (pe < dp && uni(la.g.indices[t0 + pe]) == cur) la.g.step_edge = t0 + pe;
+    }
     if (lane == 0) pa.out[2] = d;
     if (d == 0) return;
     uint32_t choice;

@@ -56,7 +56,7 @@ def test_lane_kernel_not_used_outside_its_regime():
     _, _, wdata = rmat_csr(10, seed=3, weighted=True)
     weng = WalkEngine.from_csr(indptr, indices, wdata)
     weng.simulate("SparseOTF", 0.5, 2, False, starts, 20, seed=1)
-    assert weng.last_stats["lane_kernel"] == 0 and weng.index_info()["lane_list_entries"] == 0
+    assert weng.last_stats["lane_kernel"] == 0 and weng.index_info()["lane_list_entries"] > 0   # (lists: yes -- the wave kernel scatters its masks from them)
 
 
 def test_lane_kernel_hub_rows_beyond_the_lds_window(monkeypatch):
