@@ -109,8 +109,8 @@ struct pw_graph {
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // side stream: work that overlaps the main stream's (zero-fill of the walk matrix under the
-    hipEvent_t ev_side = nullptr;    // stream expansion; walk_kernel over the first round's redo list under the later rounds)
+    hipStream_t stream2 = nullptr;   // side stream: the zero-fill of the walk matrix runs under the stream expansion
+    hipEvent_t ev_side = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *stage[2] = {nullptr, nullptr};   // pinned staging buffers of pw_simulate's copy out
     double lane_ms = 0;              // lane kernel time of the current call
@@ -933,8 +933,7 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     return 0;
 }
 
-// (side: on the handle's second stream with a job counter of its own, next to work of the main stream)
-static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, bool side = false) {
+static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
     if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa);
@@ -947,10 +946,8 @@ static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, bool si
     uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
-    hipStream_t st = side ? g->stream2 : g->stream;
-    if (side) wa.job_counter = g->counters.p + 12;
-    HIP_TRY(hipMemsetAsync(wa.job_counter, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, st, wa);
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -961,8 +958,7 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 
 // One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
 // walked again by the wave-per-walk kernel.  *n_redo receives their number.
-// *n_redo: walks handed to walk_kernel; *n_early: the first of them, already being walked on the side stream.
-static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *n_redo, uint64_t *n_early) {
+static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
     pw::LanesArgs la;
@@ -1028,7 +1024,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
         la.ver = g->ver.p;
         la.ver_cap = cap;
     }
-    unsigned long long nr = 0, parked = 0, early = 0;
+    unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
         const bool queue_out = use_queue && todo > tail && round < 64;
@@ -1085,23 +1081,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
                 }
             }
         }
-        unsigned long long redo_now = 0;
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
-        if (round == 0) HIP_TRY(hipMemcpyAsync(&redo_now, g->counters.p + 6, sizeof(redo_now), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
-        if (round == 0 && parked && redo_now && !getenv("PECANPY_AMD_NO_EARLY_REDO")) {
-            // Most walks the lane kernel cannot step (mirrored overflow reads: 16 k of 21 M at RMAT-22) drop out in the
-            // first round.  walk_kernel finishes them on the side stream WHILE the later rounds run (a few thousand
-            // wavefronts of whole-row chains on hub rows: 15 ms that used to follow the last round).  Rows, redo
-            // entries and job counter are disjoint from what the rounds touch; the statistics are atomic adds.
-            pw::WalkArgs wr = wa;
-            wr.job_list = g->redo.p;
-            wr.n_list = redo_now;
-            wr.resume = 1u;
-            int rcw = launch_wave_walks(g, wr, extend, true);
-            if (rcw) return rcw;
-            early = redo_now;
-        }
         if (parked) {   // settle the queue just filled
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
@@ -1150,32 +1131,27 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
                 hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[5] ? (double)hp[4] / (double)hp[5] : 0.0);
     }
 #endif
-    if (early) {   // the main stream goes on when the side stream's walks are done
-        HIP_TRY(hipEventRecord(g->ev_side, g->stream2));
-        HIP_TRY(hipStreamWaitEvent(g->stream, g->ev_side, 0));
-    }
     *n_redo = nr;
-    *n_early = early;
     return 0;
 }
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    uint64_t n_early = 0;
-    int rc = launch_lane_walks(g, wa, extend, &n_redo, &n_early);
+    int rc = launch_lane_walks(g, wa, &n_redo);
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range, tie budget) go to walk_kernel,
     // which resumes them at that step and finishes them.  Measured and rejected: handing them BACK to the lane kernel
     // once they are on a CSR entry again -- as extra cycles after the rounds (198 vs 189 ms per RMAT-22 pass, round 2)
     // or after ONE eager step, every round followed by a walk_kernel launch over its redo list (200 vs 181 ms, round
     // 3): such walks overflow again and again, an eager step on a 97 k-entry hub row takes milliseconds, and each
-    // launch waits for the slowest of them.
+    // launch waits for the slowest of them.  Also measured: finishing the first round's redo walks on a second stream
+    // BESIDE the later rounds (179.5 vs 178.0 ms): six 80-register wavefronts of the lane kernel fill the SIMDs' register
+    // files, walk_kernel's wavefronts only get in as lane wavefronts retire -- nothing overlaps.
     if (rc || !n_redo) return rc;
     if (redo_total) *redo_total += n_redo;
-    if (n_redo == n_early) return 0;
     pw::WalkArgs wr = wa;
-    wr.job_list = g->redo.p + n_early;
-    wr.n_list = n_redo - n_early;
+    wr.job_list = g->redo.p;
+    wr.n_list = n_redo;
     wr.resume = 1u;   // from the step the lane kernel stopped at (its rows hold the walks so far)
     return launch_wave_walks(g, wr, extend);
 }
@@ -1227,9 +1203,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
     uint64_t per_gen = 1;
     int per_gen_log = 0;
-    const char *gens_env = getenv("PECANPY_AMD_MT_GENS");
-    const uint64_t max_gen = gens_env ? (uint64_t)strtoull(gens_env, nullptr, 10) : 1024;
-    while (per_gen * max_gen < n_blocks) { per_gen <<= 1; per_gen_log++; }
+    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }   // (2048 generators: 7.4 vs 8.0 ms, 4096: 9.2)
     const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
     if (!g->jump_table_ready) {
         const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;

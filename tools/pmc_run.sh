@@ -19,7 +19,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   rm -rf /tmp/pmc_$i
   timeout 400 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline > $OUT/pass$i.log 2>&1
   python $R/tools/prof_summary.py /tmp/pmc_$i/p_results.db $OUT/pass$i.txt > /dev/null 2>&1
-  tail -1 $OUT/pass$i.log | cut -c1-300 > $OUT/pass$i.bench.txt
+  grep -m1 '^{"metric"' $OUT/pass$i.log | cut -c1-1500 > $OUT/pass$i.bench.txt
   rm -f $OUT/pass$i.log
 done
 cat $OUT/pass*.txt

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r02_traffic.json, the file
+"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r03_traffic.json, the file
 bench.py reads the HBM-side traffic and the issue counters of a workload from.
 usage: pmc_to_json.py <dir with pass*.txt> <workload key> <kernel substring[+substring...]> <steps per pass> [note]"""
 import glob
@@ -44,11 +44,12 @@ def main(d, key, kernel, steps, note=""):
             "wave_cycles_waiting_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
             "clock_assumed_ghz": 2.4,
         },
+        "sectors_per_step": round((c.get("TCC_MISS_sum") or 0.0) / steps, 3),
         "note": note or ("FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch (tools/pmc_run.sh); "
                          "scattered <= 64-byte accesses: FETCH_SIZE is exact at one 64-byte sector per access "
                          "(profiles/r02_fetch_calibration.txt)"),
     }
-    path = os.path.join(REPO, "profiles", "r02_traffic.json")
+    path = os.path.join(REPO, "profiles", "r03_traffic.json")
     try:
         doc = json.load(open(path))
     except (OSError, ValueError):
