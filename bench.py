@@ -346,7 +346,8 @@ def main():
         chain_steps = int(acc["wave_chain_steps"][-1])
         declared = (steps0 * (64 + 8 + 4) + entries * 2 + chain_steps * 128 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
                     (hi - lo - walks0) * 8)
-        kernel = "walk_lanes_kernel (every round of a pass) + lanes_chain_kernel"
+        kernel = ("walk_lanes_kernel (every round of a pass) + lanes_chain_kernel" if int(st["lane_kernel"]) == 1 else
+                  "walk_lanes_kernel<FLOATS> (1/p or 1/q not a power of two: two float32 chains per step, per lane)")
         fmt = ("64 B edge line (record + inline list) + 8 B draw + 4 B output per step, 2 B per common-neighbour list entry "
                "read (in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
     elif cfg["graph"] == "er":

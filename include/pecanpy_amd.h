@@ -66,7 +66,7 @@ typedef struct {
     uint32_t stream_addressing; /* 0: the reference's exact draw assignment; 1: nominal per-walk slots
                                    (fallback on sink-heavy directed graphs) */
     /* lane kernel (one walk per lane, csrc/walk_lanes.hip.h): unit-weight CSR graphs, 1/p and 1/q powers of two */
-    uint32_t lane_kernel;       /* 1 when the call ran on the lane kernel */
+    uint32_t lane_kernel;       /* 1: the call ran on the lane kernel; 2: on its float-chain form (1/p or 1/q not a power of two) */
     uint32_t lane_rounds;       /* lane kernel launches of the call: walks whose step needs the float32 chain are parked,
                                    the chains of a whole queue run in one launch, the next round resumes the walks */
     uint64_t redo_walks;        /* walks the lane kernel handed to the wave-per-walk kernel (overflow reads, ...) */
@@ -268,6 +268,13 @@ int pw_selftest_exact_decision(const uint8_t *cls, uint32_t n, float w_out, floa
  * routines.  Rows of more than 65536 entries use uint32 positions, shorter ones uint16 (the lane index's formats). */
 int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                      uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *tight, uint32_t *chain_lane);
+/* The step of the lane kernel's FLOATS form (unit weights, 1/p or 1/q NOT a power of two: w_out, w_prev arbitrary
+ * positive float32): chain[i] = the reference's position (sequential float32 w.sum(), w / tot, cumsum, searchsorted),
+ * lane[i] = the same from two closed-form chains of one thread (lane_chain with r = +inf for the total, then the
+ * search; 0xfffffffb never reached, 0xfffffffa rounding-tie budget), tots[2 i] / tots[2 i + 1] = the sequential row
+ * total / the thread's.  on_device: one GPU thread per target. */
+int pw_selftest_lane_floats(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev,
+                            const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots);
 /* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);

@@ -1135,10 +1135,74 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     return 0;
 }
 
+// Unit-weight graphs whose 1/p or 1/q is not a power of two: the lane kernel in its FLOATS form -- every step is the
+// reference's two float32 chains, evaluated per lane (walk_lanes.hip.h); one launch, nothing is parked.
+static bool lanes_float_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
+    return g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && !wa.lazy_ok && !getenv("PECANPY_AMD_NO_LANES");
+}
+
+static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
+    const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
+    if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
+    pw::LanesArgs la;
+    memset(&la, 0, sizeof(la));
+    la.lines = g->d_lines;
+    la.clist = g->d_clist;
+    la.vrec = g->d_vrec;
+    la.nnz = g->nnz;
+    la.L = wa.L;
+    la.n_jobs = wa.n_jobs;
+    la.starts = wa.starts;
+    la.stream_off = wa.stream_off;
+    la.job_list = wa.job_list;
+    la.n_list = wa.n_list;
+    la.rng = wa.rng;
+    la.rng_base = wa.rng_base;
+    la.out = wa.out;
+    la.job_counter = g->counters.p;
+    la.stats = g->counters.p + 1;
+    la.redo_list = g->redo.p;
+    la.redo_count = g->counters.p + 6;
+    la.w_out = wa.w_out;
+    la.w_prev = wa.w_prev;
+    la.susp_count = g->counters.p + 32;
+    la.ver_count = g->counters.p + 40;
+    la.susp_chunk = 1;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<true, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ < 1) occ = 1;
+    uint64_t want = (n_work + pw::WAVES_PER_BLOCK * pw::WAVE - 1) / (pw::WAVES_PER_BLOCK * pw::WAVE);
+    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
+    if (grid > want) grid = want;
+    if (grid < 1) grid = 1;
+    {   // (job chunks as in launch_lane_walks; smaller: a lane's step is ~10x longer here and the tail matters more)
+        const uint64_t share = n_work / (grid * pw::WAVES_PER_BLOCK * 8);
+        uint32_t c = 64;
+        while (c * 2 <= 256 && (uint64_t)c * 2 <= share) c *= 2;
+        la.job_chunk = c;
+    }
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+    hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, true>), dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+    unsigned long long nr = 0;
+    HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[4], g->ev[5]));
+    g->lane_ms += ms;
+    g->lane_rounds++;
+    *n_redo = nr;
+    return 0;
+}
+
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
-    if (!lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
+    const bool floats = lanes_float_eligible(g, wa);
+    if (!floats && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
     uint64_t n_redo = 0;
-    int rc = launch_lane_walks(g, wa, &n_redo);
+    int rc = floats ? launch_lane_float_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range, tie budget) go to walk_kernel,
     // which resumes them at that step and finishes them.  Measured and rejected: handing them BACK to the lane kernel
     // once they are on a CSR entry again -- as extra cycles after the rounds (198 vs 189 ms per RMAT-22 pass, round 2)
@@ -1303,7 +1367,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     rc = ensure_tot_table(g, wa, extend != 0);   // (before the timed walk region: a per-(p, q) index, reported apart)
     if (rc) return rc;
     uint64_t redo_total = 0;
-    const bool lanes = lanes_eligible(g, wa);
+    const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa);
     g->lane_ms = 0;
     g->lane_rounds = 0;
     g->ver_checked = g->ver_mismatch = g->ver_dropped = g->ver_ties = 0;
@@ -1392,7 +1456,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.overflow_reads = h[2];
     st.clamped_reads = h[3];
     st.dead_end_walks = dead;
-    st.lane_kernel = lanes ? 1u : 0u;
+    st.lane_kernel = lanes ? (lanes_float_eligible(g, wa) ? 2u : 1u) : 0u;
     st.redo_walks = redo_total;
     st.list_entries_read = h[7];
     st.ambiguous_steps = h[8];
@@ -1761,9 +1825,10 @@ struct LaneRow {
     pw::ListView view() const { return pw::ListView{wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide}; }
 };
 
-int lane_row_setup(const uint8_t *cls, uint32_t n, float w_out, float w_prev, LaneRow &row) {
+int lane_row_setup(const uint8_t *cls, uint32_t n, float w_out, float w_prev, LaneRow &row, bool need_pow2 = true) {
     auto pow2 = [](float w) { int e = 0; return std::frexp(w, &e) == 0.5f; };
-    if (!pow2(w_out) || !pow2(w_prev)) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    if (need_pow2 && (!pow2(w_out) || !pow2(w_prev))) return fail(PW_ERR_UNSUPPORTED, "biases must be powers of two");
+    if (!(w_out > 0.0f) || !(w_prev > 0.0f)) return fail(PW_ERR_INVALID, "biases must be positive");
     uint32_t cnt[3] = {0, 0, 0};
     row.wide = n > 65536u ? 1u : 0u;   // positions of rows up to 65536 entries are uint16 (walk_lanes.hip.h)
     for (uint32_t k = 0; k < n; k++) {
@@ -1824,6 +1889,114 @@ lane_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wi
     out4[4 * i] = o[0]; out4[4 * i + 1] = o[1]; out4[4 * i + 2] = o[2]; out4[4 * i + 3] = o[3];
 }
 }  // namespace pw
+
+namespace pw {
+// the FLOATS form of the lane kernel for one target: row total by lane_chain(r = +inf), then the search over w / tot
+PW_HD void lane_floats_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint32_t pp, float w_out, float w_prev, double r,
+                           uint32_t *choice, float *tot) {
+    uint32_t reads = 0;
+    float rowsum = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+#else
+    const double inf = INFINITY;
+#endif
+    uint32_t res = lane_chain(n, n_cl, pp, inf, 1.0f, w_out, w_prev, cl, reads, &rowsum);
+    *tot = rowsum;
+    if (res != LANE_CHAIN_END) { *choice = res; return; }   // (LANE_TIE)
+    *choice = lane_chain(n, n_cl, pp, r, 1.0f / rowsum, w_out / rowsum, w_prev / rowsum, cl, reads);
+}
+
+__global__ void __launch_bounds__(256)
+lane_floats_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t n_cl, uint32_t pp, float w_out,
+                            float w_prev, const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_r) return;
+    float tot = 0.0f;   // the reference: sequential float32 w.sum(), w / tot, cumsum, searchsorted -- by this thread
+    for (uint32_t k = 0; k < n; k++) tot = tot + (cls[k] == 1 ? 1.0f : (cls[k] == 0 ? w_out : w_prev));
+    const float x_in = 1.0f / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    float c = 0.0f;
+    uint32_t kc = n;
+    for (uint32_t k = 0; k < n; k++) {
+        c = c + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev));
+        if ((double)c >= r[i]) { kc = k; break; }
+    }
+    chain[i] = kc;
+    float tl = 0.0f;
+    uint32_t ch = 0;
+    lane_floats_one(n, ListView{cl, wide}, n_cl, pp, w_out, w_prev, r[i], &ch, &tl);
+    lane[i] = ch;
+    tots[2 * i] = tot;
+    tots[2 * i + 1] = tl;
+}
+}  // namespace pw
+
+// The FLOATS form of a lane-kernel step (1/p or 1/q not a power of two: arbitrary float32 row values): chain[i] = the
+// reference's position for draw r[i] (sequential float32 w.sum(), w / tot, cumsum, searchsorted), lane[i] = the same by
+// two closed-form chains of one thread (0xfffffffb: never reached, 0xfffffffa: tie budget), tots[2 i], tots[2 i + 1] =
+// the sequential row total and the thread's.  on_device: one GPU thread per target.
+PW_EXPORT int pw_selftest_lane_floats(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev,
+                                      const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots) {
+    if (!cls || !r || !chain || !lane || !tots || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    LaneRow row;
+    int rc = lane_row_setup(cls, n, w_out, w_prev, row, false);
+    if (rc) return rc;
+    if (!on_device) {
+        float tot = 0.0f;
+        for (uint32_t k = 0; k < n; k++) tot = tot + (cls[k] == 1 ? 1.0f : (cls[k] == 0 ? w_out : w_prev));
+        const float x_in = 1.0f / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+        std::vector<float> c(n);
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < n; k++) { acc = acc + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev)); c[k] = acc; }
+        for (uint32_t i = 0; i < n_r; i++) {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+            chain[i] = lo;
+            float tl = 0.0f;
+            pw::lane_floats_one(n, row.view(), row.n_cl, row.pp, w_out, w_prev, r[i], &lane[i], &tl);
+            tots[2 * (size_t)i] = tot;
+            tots[2 * (size_t)i + 1] = tl;
+        }
+        return PW_OK;
+    }
+    int ndev = pw_device_count();
+    if (ndev <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(PW_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_cls = nullptr;
+    void *d_cl = nullptr;
+    double *d_r = nullptr;
+    uint32_t *d_chain = nullptr, *d_lane = nullptr;
+    float *d_tots = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)d_cls, d_cl, (void *)d_r, (void *)d_chain, (void *)d_lane, (void *)d_tots})
+            if (q) (void)hipFree(q);
+    };
+    const size_t cl_bytes = row.wide ? row.cl32.size() * sizeof(uint32_t) : row.cl16.size() * sizeof(uint16_t);
+    const void *cl_host = row.wide ? (const void *)row.cl32.data() : (const void *)row.cl16.data();
+    const size_t nr = n_r ? n_r : 1;
+    hipError_t e = hipMalloc((void **)&d_cls, n);
+    if (e == hipSuccess) e = hipMalloc(&d_cl, cl_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_r, sizeof(double) * nr);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_chain, sizeof(uint32_t) * nr);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lane, sizeof(uint32_t) * nr);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tots, sizeof(float) * 2 * nr);
+    if (e == hipSuccess) e = hipMemcpy(d_cls, cls, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cl, cl_host, cl_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_r) e = hipMemcpy(d_r, r, sizeof(double) * (size_t)n_r, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_r) {
+        hipLaunchKernelGGL(pw::lane_floats_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.n_cl,
+                           row.pp, w_out, w_prev, d_r, n_r, d_chain, d_lane, d_tots);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(chain, d_chain, sizeof(uint32_t) * (size_t)n_r, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(lane, d_lane, sizeof(uint32_t) * (size_t)n_r, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(tots, d_tots, sizeof(float) * 2 * (size_t)n_r, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("pw_selftest_lane_floats: ") + hipGetErrorString(e));
+    return PW_OK;
+}
 
 PW_EXPORT int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r,
                                uint32_t n_r, uint32_t *chain, uint32_t *lane, uint32_t *kmax, uint32_t *tight,

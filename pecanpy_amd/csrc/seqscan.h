@@ -418,8 +418,10 @@ struct ChainEval {   // partial sum (in ulps of the current binade) after common
     }
 };
 
+// c_end (optional): receives the float32 sum of the kend elements when no partial sum reaches r (LANE_CHAIN_END) -- with
+// r = +infinity the routine is the reference's sequential row total, w.sum() (src/pecanpy/rw/sparse_rw.py:89).
 PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
-                          const ListView &cl, uint32_t &reads) {
+                          const ListView &cl, uint32_t &reads, float *c_end = nullptr) {
     using B = Binade<float>;
     float c = 0.0f;
     uint32_t k = 0;    // next element to add
@@ -538,8 +540,8 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
             }
             PW_LANE_STAT(g_lane_seq_elems++);
             if (!leave) {   // [k_start, lim) stays inside the binade and below the target
-                if (lim == kend) return LANE_CHAIN_END;
                 c = B::make((uint32_t)Cc, eb);
+                if (lim == kend) { if (c_end) *c_end = c; return LANE_CHAIN_END; }
                 continue;   // k == lim == pp: prev is added next
             }
             if (Cc < (uint64_t)B::TOP) return kf;   // target reached inside the binade
@@ -570,8 +572,8 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         if (j >= run_end) {
             if (p_f == 0xffffffffu) {
                 // [k, lim) stays below the target and inside the binade: its exact closed-form sum
-                if (lim == kend) return LANE_CHAIN_END;
                 c = B::make((uint32_t)(base + (uint64_t)(lim - s_run) * io), eb);
+                if (lim == kend) { if (c_end) *c_end = c; return LANE_CHAIN_END; }
                 k = lim;
                 i0 = lo;
                 PW_LANE_CURSOR();
@@ -591,6 +593,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         i0 = lo + (kf == p_f ? 1u : 0u);
         PW_LANE_CURSOR();
     }
+    if (c_end) *c_end = c;
     return LANE_CHAIN_END;
 #undef PW_LANE_SEQ
 #undef PW_LANE_CURSOR

@@ -197,7 +197,12 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // form used when no queue is given (a.susp == nullptr: short job lists, the last round).  !INPLACE: such walks are
 // always parked (a.susp != nullptr); without the chain code the kernel needs fewer registers.
 // VERIFY: steps settled by lane_tight are recorded for lanes_verify_kernel (test mode, PECANPY_AMD_VERIFY_TIGHT=1).
-template <bool INPLACE, bool VERIFY>
+// FLOATS (with INPLACE): 1/p or 1/q is not a power of two -- the row values are arbitrary float32 numbers, no exact
+// integer decision exists, and EVERY step is the reference's two float32 chains, each evaluated by the lane in closed
+// form per binade (lane_chain): the row total w.sum() (sparse_rw.py:89), then cumsum / searchsorted over w / tot
+// (pecanpy.py:556-557).  ~6x fewer wave instructions per step than walk_kernel's eager step, which gives every walk a
+// whole wavefront.
+template <bool INPLACE, bool VERIFY, bool FLOATS = false>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : PW_LANES_MIN_WAVES_Q)
 walk_lanes_kernel(LanesArgs a) {
     const int lane = lane_id();
@@ -312,6 +317,29 @@ walk_lanes_kernel(LanesArgs a) {
         // their chains together once a few have gathered or nothing else can run.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
+        if (FLOATS) {
+            if (runnable) {
+                wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
+                const ListView cl = edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff);
+                float xi = 1.0f, xo = wo, xp = w_prev, rowsum = 0.0f;
+                double target = __longlong_as_double(0x7ff0000000000000ll);   // +inf: the chain runs to the end of the row
+                uint32_t res = LANE_CHAIN_END;
+                for (int phase = 0; phase < 2 && res == LANE_CHAIN_END; phase++) {   // (one inlined copy of the chain)
+                    uint32_t reads = 0;
+                    res = lane_chain(A.d, A.n_in, A.pp, target, xi, xo, xp, cl, reads, &rowsum);
+                    n_probes += reads;
+                    if (phase == 0 && res == LANE_CHAIN_END) {   // tot known: the normalised values, float32 / float32
+                        xi = 1.0f / rowsum; xo = wo / rowsum; xp = w_prev / rowsum;
+                        target = r;
+                        continue;
+                    }
+                    break;
+                }
+                // LANE_CHAIN_END after the search: the CDF never reached r (mirrored overflow read); LANE_TIE: a tie binade
+                // beyond the budget -- both: walk_kernel takes the walk over at this step
+                choice = res < A.d ? res : A.d;
+            }
+        } else {
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
         if (runnable) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
@@ -407,6 +435,7 @@ walk_lanes_kernel(LanesArgs a) {
                 }
                 LPROF_T(4);
             }
+        }
         }
         n_steps += (unsigned long long)__popcll(ballot(A.flags == F_ACTIVE && choice < A.d));   // (LANE_* codes are >= any degree)
         if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {

@@ -296,3 +296,61 @@ def test_interval_decision_power_of_two_totals(device):
         run = LaneRun(cls, 1.0, 2.0, r, device)
         ok = run.tight != LANE_AMBIGUOUS
         assert np.array_equal(run.tight[ok], run.chain[ok])
+
+
+# ---- the FLOATS form of a lane-kernel step: 1/p or 1/q not a power of two (arbitrary float32 row values) ----------
+FLOAT_BIASES = [(1 / 1.7, 1 / 0.3), (1 / 0.37, 1 / 3.0), (0.9, 1.1), (1 / 3.0, 1.0), (7.3, 0.01), (1 / 1.3, 1 / 0.4)]
+
+
+def float_chain_reference(cls, w_out, w_prev):
+    """float32 row total and partial sums of w / tot, sequential (Numba's arr.sum() and np.cumsum)."""
+    w = np.where(cls == 1, np.float32(1.0), np.where(cls == 0, np.float32(w_out), np.float32(w_prev))).astype(np.float32)
+    tot = np.float32(0)
+    for v in w:
+        tot = np.float32(tot + v)
+    x = (w / tot).astype(np.float32)
+    c = np.zeros(cls.size, dtype=np.float32)
+    acc = np.float32(0)
+    for k, v in enumerate(x):
+        acc = np.float32(acc + v)
+        c[k] = acc
+    return tot, c
+
+
+@pytest.mark.parametrize("device", BACKENDS)
+@pytest.mark.parametrize("w_out,w_prev", FLOAT_BIASES)
+def test_float_chain_step_for_non_dyadic_biases(w_out, w_prev, device):
+    """Two closed-form chains of one thread (row total, then the search over w / tot) equal the sequential float32
+    loops for arbitrary positive float32 biases -- uniform draws and draws on / one ulp around every partial sum."""
+    lib = _lib.load()
+    w_out, w_prev = float(np.float32(w_out)), float(np.float32(w_prev))
+    rng = np.random.default_rng(int(w_out * 977 + w_prev * 131) + 5)
+    declined = total = 0
+    rows = []
+    for n in (1, 2, 5, 33, 64, 65, 400, 3000, 20000, 70000):
+        for p_common in (0.0, 0.03, 0.4, 1.0):
+            for with_prev in (False, True):
+                rows.append(random_row(rng, n, p_common, with_prev))
+    rows += lattice_rows(4096) + structured_rows(rng, 1500)
+    for cls in rows:
+        n = cls.size
+        tot, c32 = float_chain_reference(cls, w_out, w_prev)
+        cd = c32.astype(np.float64)
+        sub = slice(None, None, max(1, n // 400))
+        r = np.clip(np.concatenate([rng.random(400), cd[sub], np.nextafter(cd[sub], 0.0), np.nextafter(cd[sub], 2.0),
+                                    np.array([0.0, 1e-300, 1 - 2.0 ** -53])]), 0.0, np.nextafter(1.0, 0.0))
+        chain, lane = (np.empty(r.size, dtype=np.uint32) for _ in range(2))
+        tots = np.empty(2 * r.size, dtype=np.float32)
+        _lib.check(lib.pw_selftest_lane_floats(int(device), 0, np.ascontiguousarray(cls).ctypes.data_as(C.c_void_p), n, w_out, w_prev,
+                                               r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
+                                               lane.ctypes.data_as(C.c_void_p), tots.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(chain, np.searchsorted(cd, r, side="left").astype(np.uint32))       # the hook's own reference
+        assert (tots[0::2] == tot).all()
+        tie = lane == LANE_TIE
+        assert (tots[1::2][~tie] == tot).all(), (n, w_out, w_prev)                                  # row total, bit for bit
+        end = lane == LANE_CHAIN_END
+        assert np.array_equal(lane[~tie & ~end], chain[~tie & ~end]), (n, w_out, w_prev)
+        assert (chain[end] == n).all()
+        declined += int(tie.sum())
+        total += r.size
+    assert declined / total < 0.05

@@ -50,13 +50,35 @@ def test_lane_kernel_runs_and_equals_oracle_and_wave_kernel(scale, p, q, monkeyp
 def test_lane_kernel_not_used_outside_its_regime():
     indptr, indices, data = rmat_csr(10, seed=3)
     starts = orc.shuffled_starts(indptr.size - 1, 2, 1)
-    eng = WalkEngine.from_csr(indptr, indices, data)
-    eng.simulate("SparseOTF", 0.3, 1.7, False, starts, 20, seed=1)          # non-dyadic biases: float chain only
-    assert eng.last_stats["lane_kernel"] == 0
     _, _, wdata = rmat_csr(10, seed=3, weighted=True)
     weng = WalkEngine.from_csr(indptr, indices, wdata)
     weng.simulate("SparseOTF", 0.5, 2, False, starts, 20, seed=1)
     assert weng.last_stats["lane_kernel"] == 0 and weng.index_info()["lane_list_entries"] > 0   # (lists: yes -- the wave kernel scatters its masks from them)
+
+
+@pytest.mark.parametrize("p,q", [(0.3, 1.7), (3.0, 0.37), (1.0, 1.3), (0.7, 1.0)])
+def test_float_chain_lane_kernel_for_non_dyadic_p_q(p, q, monkeypatch):
+    """1/p or 1/q not a power of two: no exact integer decision exists; the lane kernel's FLOATS form evaluates the
+    reference's two float32 chains (row total, CDF search) per lane, every step.  Oracle, wave kernel and lane kernel
+    agree on R-MAT graphs and on the hub graph (40 000-entry row, thousands of common neighbours per list)."""
+    for graph in ("rmat12", "rmat13", "hub"):
+        if graph == "hub":
+            indptr, indices, data = _hub_graph(np.random.default_rng(21))
+            n = indptr.size - 1
+            starts = np.concatenate([np.zeros(100, dtype=np.uint32), np.random.default_rng(2).integers(0, n, 3000).astype(np.uint32)])
+        else:
+            indptr, indices, data = rmat_csr(int(graph[4:]), seed=31)
+            starts = orc.shuffled_starts(indptr.size - 1, 3, 5)
+        want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 30, 5, return_stats=True)
+        eng = WalkEngine.from_csr(indptr, indices, data)
+        got = eng.simulate("SparseOTF", p, q, False, starts, 30, seed=5)
+        st = dict(eng.last_stats)
+        assert st["lane_kernel"] == 2, graph
+        assert np.array_equal(got, want), graph
+        assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
+        wave = _wave_engine(indptr, indices, data, monkeypatch)
+        assert np.array_equal(wave.simulate("SparseOTF", p, q, False, starts, 30, seed=5), want)
+        assert wave.last_stats["lane_kernel"] == 0
 
 
 def test_lane_kernel_hub_rows_beyond_the_lds_window(monkeypatch):
