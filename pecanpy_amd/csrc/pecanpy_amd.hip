@@ -870,9 +870,17 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
     da.out = wa.out;
     da.job_counter = wa.job_counter;
     da.stats = wa.stats;
+    // rows of up to 131 072 columns: the row of `cur` is kept in registers for the next step (WPL words per lane)
+    typedef void (*dense_fn)(pw::DenseArgs);
+    dense_fn fn = pw::walk_dense_bits_kernel<0>;
+    if (!getenv("PECANPY_AMD_DENSE_NO_KEEP")) {
+        if (da.wpr <= 64 * 8) fn = pw::walk_dense_bits_kernel<8>;
+        else if (da.wpr <= 64 * 16) fn = pw::walk_dense_bits_kernel<16>;
+        else if (da.wpr <= 64 * 25) fn = pw::walk_dense_bits_kernel<25>;
+        else if (da.wpr <= 64 * 32) fn = pw::walk_dense_bits_kernel<32>;
+    }
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_dense_bits_kernel,
-                                                         pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     uint64_t want = (n_work + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
@@ -880,7 +888,7 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(pw::walk_dense_bits_kernel, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, da);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, da);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -204,6 +204,11 @@ __device__ __forceinline__ void prepare_dense_segment(const uint64_t *__restrict
     build_rank(mo, ro, DW);
 }
 
+// WPL > 0 (rows of at most 64 * WPL words): the row of `cur` stays in REGISTERS (WPL 64-bit words per lane) and is the
+// row of `prev` one step later -- the count pass then reads ONE row from HBM per step instead of two (round 3; the
+// kernel is HBM bound: FETCH_SIZE 1.13 TB per ER-100k pass under PMC, a wide coalesced stream that the counter
+// under-counts by 2, i.e. ~5 TB/s).  WPL == 0: both rows from memory (rows beyond 131 072 columns).
+template <int WPL>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
 walk_dense_bits_kernel(DenseArgs a) {
     __shared__ uint32_t s_mi[WAVES_PER_BLOCK][DW], s_mo[WAVES_PER_BLOCK][DW];
@@ -233,6 +238,7 @@ walk_dense_bits_kernel(DenseArgs a) {
         uint32_t cur = start, prev = 0;
         uint32_t len_out = L + 1;
         double rbuf = 0.0;
+        uint64_t keep[WPL > 0 ? WPL : 1];   // row of the vertex the walk was at one step ago (word i * 64 + lane)
         uint32_t j = 1;
         for (; j <= L; j++) {
             const uint32_t d = uni(a.deg[cur]);
@@ -251,8 +257,46 @@ walk_dense_bits_kernel(DenseArgs a) {
             uint32_t n_in = 0, n_pv = 0;
             // per-segment class counts (in / all neighbours, prev excluded) for the exact-arithmetic search
             const bool seg_counts = has_prev && n_seg <= MAX_SEG_COUNTS;
+            if (WPL > 0 && !has_prev) {   // first step of a walk: its row is the next step's prev row
+#pragma unroll
+                for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) {
+                    const uint32_t w = (uint32_t)i * WAVE + lane;
+                    keep[i] = w < wpr ? crow[w] : 0ull;
+                }
+            }
             if (has_prev) {
                 uint32_t acc = 0, acc_in_seg = 0, acc_all_seg = 0;
+                if (WPL > 0) {
+                    uint64_t cws[WPL > 0 ? WPL : 1];
+#pragma unroll
+                    for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) {   // every load of the row in flight at once
+                        const uint32_t w = (uint32_t)i * WAVE + lane;
+                        cws[i] = w < wpr ? crow[w] : 0ull;
+                    }
+#pragma unroll
+                    for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) {
+                        const uint32_t w = (uint32_t)i * WAVE + lane;
+                        uint64_t cw = cws[i];
+                        const uint64_t pw = keep[i];
+                        keep[i] = cw;
+                        if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));
+                        const uint32_t ci = (uint32_t)__popcll(cw & pw);
+                        acc += ci;
+                        acc_in_seg += ci;
+                        acc_all_seg += (uint32_t)__popcll(cw);
+                        // a segment = DQW 64-bit words = DQW / WAVE words per lane
+                        if (seg_counts && ((i + 1) % (DQW / WAVE) == 0 || (uint32_t)(i + 1) * WAVE >= wpr)) {
+                            uint32_t si = acc_in_seg, sa = acc_all_seg;
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) {
+                                si += (uint32_t)__shfl_xor((int)si, off, WAVE);
+                                sa += (uint32_t)__shfl_xor((int)sa, off, WAVE);
+                            }
+                            if (lane == 0 && (uint32_t)i * WAVE < wpr) { seg_in[i / (DQW / WAVE)] = si; seg_all[i / (DQW / WAVE)] = sa; }
+                            acc_in_seg = acc_all_seg = 0;
+                        }
+                    }
+                } else {
                 uint32_t it = 0;
                 for (uint32_t w0 = 0; w0 < wpr; w0 += WAVE, it++) {
                     const uint32_t w = w0 + lane;
@@ -275,6 +319,7 @@ walk_dense_bits_kernel(DenseArgs a) {
                         if (lane == 0) { seg_in[it / (DQW / WAVE)] = si; seg_all[it / (DQW / WAVE)] = sa; }
                         acc_in_seg = acc_all_seg = 0;
                     }
+                }
                 }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) acc += (uint32_t)__shfl_xor((int)acc, off, WAVE);
