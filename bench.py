@@ -352,9 +352,14 @@ def main():
                "read (in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
     elif cfg["graph"] == "er":
         wpr = (n_nodes + 63) // 64
-        declared = steps0 * (3 * wpr * 8 + 12)
+        if wpr <= 2048:
+            # rows of up to 131 072 columns: the row of cur stays in registers and serves as prev's row one step later
+            declared = steps0 * (wpr * 8 + 12)
+            fmt = "packed adjacency: ONE row per step (the row of cur is kept in registers for the next step) + draw + output"
+        else:
+            declared = steps0 * (3 * wpr * 8 + 12)
+            fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
         kernel = "walk_dense_bits_kernel"
-        fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
     else:
         # the wave-per-walk kernel streams rows (keys of the shorter row, weights of cur's row): SURVEY 8(d)'s
         # figure in the reference's element sizes is its declared format

@@ -204,6 +204,36 @@ __device__ __forceinline__ void prepare_dense_segment(const uint64_t *__restrict
     build_rank(mo, ro, DW);
 }
 
+// prepare_dense_segment with the segment's words of both rows already in registers (c4[j], p4[j] = word
+// seg * DQW + j * 64 + lane of cur's / prev's row; has_prev)
+__device__ __forceinline__ void prepare_dense_segment_regs(const uint64_t (&c4)[4], const uint64_t (&p4)[4], uint32_t wpr, uint32_t n,
+                                                           uint32_t seg, uint32_t prev, uint32_t *mi, uint32_t *mo, uint16_t *ri,
+                                                           uint16_t *ro) {
+    const int lane = lane_id();
+    const uint32_t w0 = seg * DQW;
+#pragma unroll
+    for (int j = 0; j < DQW / WAVE; j++) {
+        const uint32_t wl = (uint32_t)j * WAVE + lane;
+        const uint32_t w = w0 + wl;
+        uint64_t cw = 0, pw = 0;
+        if (w < wpr) {
+            cw = c4[j];
+            pw = p4[j];
+            const uint64_t col0 = (uint64_t)w * 64;
+            if (col0 + 64 > n) cw &= (n > col0) ? ((1ull << (n - col0)) - 1ull) : 0ull;   // columns >= n
+            if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));                            // prev forms its own class
+        }
+        const uint64_t in = cw & pw, out = cw & ~pw;
+        mi[2 * wl] = (uint32_t)in;
+        mi[2 * wl + 1] = (uint32_t)(in >> 32);
+        mo[2 * wl] = (uint32_t)out;
+        mo[2 * wl + 1] = (uint32_t)(out >> 32);
+    }
+    wave_lds_fence();
+    build_rank(mi, ri, DW);
+    build_rank(mo, ro, DW);
+}
+
 // WPL > 0 (rows of at most 64 * WPL words): the row of `cur` stays in REGISTERS (WPL 64-bit words per lane) and is the
 // row of `prev` one step later -- the count pass then reads ONE row from HBM per step instead of two (round 3; the
 // kernel is HBM bound: FETCH_SIZE 1.13 TB per ER-100k pass under PMC, a wide coalesced stream that the counter
@@ -239,6 +269,7 @@ walk_dense_bits_kernel(DenseArgs a) {
         uint32_t len_out = L + 1;
         double rbuf = 0.0;
         uint64_t keep[WPL > 0 ? WPL : 1];   // row of the vertex the walk was at one step ago (word i * 64 + lane)
+        uint64_t cws[WPL > 0 ? WPL : 1];    // row of cur, this step
         uint32_t j = 1;
         for (; j <= L; j++) {
             const uint32_t d = uni(a.deg[cur]);
@@ -261,13 +292,12 @@ walk_dense_bits_kernel(DenseArgs a) {
 #pragma unroll
                 for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) {
                     const uint32_t w = (uint32_t)i * WAVE + lane;
-                    keep[i] = w < wpr ? crow[w] : 0ull;
+                    cws[i] = w < wpr ? crow[w] : 0ull;
                 }
             }
             if (has_prev) {
                 uint32_t acc = 0, acc_in_seg = 0, acc_all_seg = 0;
                 if (WPL > 0) {
-                    uint64_t cws[WPL > 0 ? WPL : 1];
 #pragma unroll
                     for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) {   // every load of the row in flight at once
                         const uint32_t w = (uint32_t)i * WAVE + lane;
@@ -278,7 +308,6 @@ walk_dense_bits_kernel(DenseArgs a) {
                         const uint32_t w = (uint32_t)i * WAVE + lane;
                         uint64_t cw = cws[i];
                         const uint64_t pw = keep[i];
-                        keep[i] = cw;
                         if ((prev >> 6) == w) cw &= ~(1ull << (prev & 63));
                         const uint32_t ci = (uint32_t)__popcll(cw & pw);
                         acc += ci;
@@ -395,6 +424,22 @@ walk_dense_bits_kernel(DenseArgs a) {
                             e0 = e1;
                         }
                         if (sx != NOT_FOUND) {
+                            if (WPL > 0) {
+                                // both rows of the segment are in registers (words 4 sx .. 4 sx + 3 of every lane): no
+                                // second trip to memory between the count pass and the search
+                                uint64_t c4[4] = {0, 0, 0, 0}, p4[4] = {0, 0, 0, 0};
+#define PW_DSEG(S)                                                                                        \
+    case S:                                                                                                \
+        _Pragma("unroll") for (int jj = 0; jj < 4; jj++) {                                                 \
+            c4[jj] = cws[(4 * S + jj) < (WPL > 0 ? WPL : 1) ? (4 * S + jj) : 0];                           \
+            p4[jj] = keep[(4 * S + jj) < (WPL > 0 ? WPL : 1) ? (4 * S + jj) : 0];                          \
+            if ((4 * S + jj) >= (WPL > 0 ? WPL : 1)) c4[jj] = p4[jj] = 0;                                  \
+        }                                                                                                  \
+        break;
+                                switch (sx) { PW_DSEG(0) PW_DSEG(1) PW_DSEG(2) PW_DSEG(3) PW_DSEG(4) PW_DSEG(5) PW_DSEG(6) PW_DSEG(7) default: break; }
+#undef PW_DSEG
+                                prepare_dense_segment_regs(c4, p4, wpr, n, sx, prev, mi, mo, ri, ro);
+                            } else
                             prepare_dense_segment(crow, prow, has_prev, wpr, n, sx, prev, mi, mo, ri, ro);
                             const uint32_t lo = sx * DSEG, len = n - lo < DSEG ? n - lo : DSEG;
                             const ColRow cr{mi, mo, ri, ro, lo, len, prev_col};
@@ -445,6 +490,10 @@ walk_dense_bits_kernel(DenseArgs a) {
                 nxt = uni(best);
             }
             if (lane == 0) row[j] = nxt;
+            if (WPL > 0) {
+#pragma unroll
+                for (int i = 0; i < (WPL > 0 ? WPL : 1); i++) keep[i] = cws[i];
+            }
             prev = cur;
             cur = nxt;
             st_steps++;
