@@ -57,9 +57,12 @@ struct VerRec {
 };
 static_assert(sizeof(VerRec) == 48, "verification record is three 16-byte stores");
 
+constexpr uint32_t LANE_NEEDS_WAVE = 0xfffffff9u;   // a step only walk_kernel can decide (tie budget, row outside the exact range)
+
 struct LanesArgs {
-    const ELine *__restrict__ lines;
+    const ELine *__restrict__ lines;          // [nnz] edge lines, then [n_nodes] OVERFLOW lines (when vlines != 0)
     const uint8_t *__restrict__ clist;
+    uint32_t vlines;                          // lines[nnz + v] = the line of the mirrored overflow read at vertex v
     const uint4 *__restrict__ vrec;           // { indptr[v], degree(v), .. } (walk_sparse.hip.h)
     uint32_t nnz;
     uint32_t L;
@@ -144,7 +147,15 @@ __device__ unsigned long long g_lprof[16];
 // otherwise one 32-byte record names the next vertex and everything the next step needs.
 #define PW_LANE_APPLY()                                                                         \
     do {                                                                                        \
-        if (choice >= A.d) {   /* walk_kernel takes the walk over AT THIS STEP (WalkArgs::resume) */ \
+        uint32_t oe_ = NOT_FOUND;                                                               \
+        if (choice == A.d && a.vlines) {                                                        \
+            /* The CDF never reached r: the reference reads indices[indptr[cur] + degree], the first neighbour of the  \
+               next non-empty row (App. D quirk 1) -- a vertex that only depends on cur.  Its edge line (next vertex,   \
+               common neighbours of cur and that vertex, ...) was built with the index: lines[nnz + cur]. */            \
+            const uint32_t vtx_ = A.j == 1u ? a.starts[A.job] : a.lines[A.e].nxt;                \
+            if (a.lines[(uint64_t)a.nnz + vtx_].nxt != NOT_FOUND) oe_ = a.nnz + vtx_;           \
+        }                                                                                       \
+        if (choice >= A.d && oe_ == NOT_FOUND) {   /* walk_kernel takes the walk over AT THIS STEP (WalkArgs::resume) */ \
             const unsigned long long slot_ = atomicAdd(a.redo_count, 1ull);                     \
             a.redo_list[slot_] = A.job;                                                         \
             const uint32_t st_ = (A.j - 1u) & 3u;   /* staged cells out, length cell = A.j */     \
@@ -155,7 +166,8 @@ __device__ unsigned long long g_lprof[16];
             row_[L + 1] = A.j;                                                                  \
             A.flags = 0;                                                                        \
         } else {                                                                                \
-            A.e = A.s0 + choice;                                                                \
+            A.e = oe_ != NOT_FOUND ? oe_ : A.s0 + choice;                                       \
+            if (oe_ != NOT_FOUND) n_over++;                                                     \
             const uint4 *rp_ = (const uint4 *)(a.lines + A.e);                                  \
             const uint4 r0_ = rp_[0];                                                           \
             const uint2 r1_ = *(const uint2 *)(rp_ + 1);                                        \
@@ -235,7 +247,7 @@ walk_lanes_kernel(LanesArgs a) {
     // statistics: wave-uniform sums of ballots where a count of lanes is all that is needed (scalar registers), 32-bit
     // per-lane counters for the rest
     unsigned long long n_steps = 0, n_amb = 0, n_wave = 0;
-    uint32_t n_dead = 0, n_probes = 0;
+    uint32_t n_dead = 0, n_probes = 0, n_over = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
     OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
@@ -337,7 +349,7 @@ walk_lanes_kernel(LanesArgs a) {
                 }
                 // LANE_CHAIN_END after the search: the CDF never reached r (mirrored overflow read); LANE_TIE: a tie binade
                 // beyond the budget -- both: walk_kernel takes the walk over at this step
-                choice = res < A.d ? res : A.d;
+                choice = res < A.d ? res : (res == LANE_CHAIN_END ? A.d : LANE_NEEDS_WAVE);
             }
         } else {
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -429,8 +441,8 @@ walk_lanes_kernel(LanesArgs a) {
                                                     edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), reads);
                     n_probes += reads;
                     choice = res;
-                    if (res == LANE_CHAIN_END) choice = A.d;                // never reached: mirrored overflow read -> redo
-                    if (res == LANE_TIE) choice = A.d;                      // tie binade too long for one lane -> redo
+                    if (res == LANE_CHAIN_END) choice = A.d;                // never reached: the mirrored overflow read
+                    if (res == LANE_TIE) choice = LANE_NEEDS_WAVE;          // tie binade too long for one lane -> redo
                     A.flags = F_ACTIVE;
                 }
                 LPROF_T(4);
@@ -453,12 +465,14 @@ walk_lanes_kernel(LanesArgs a) {
     if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
 #endif
     // wave totals
-    unsigned long long dead_w = n_dead, probes_w = n_probes;
+    unsigned long long dead_w = n_dead, probes_w = n_probes, over_w = n_over;
     for (int off = 32; off > 0; off >>= 1) {
         dead_w += (unsigned long long)__shfl_down((long long)dead_w, (unsigned)off, WAVE);
         probes_w += (unsigned long long)__shfl_down((long long)probes_w, (unsigned)off, WAVE);
+        over_w += (unsigned long long)__shfl_down((long long)over_w, (unsigned)off, WAVE);
     }
     if (lane == 0) {
+        if (over_w) { atomicAdd(a.stats + 1, over_w); atomicAdd(a.stats + 0, over_w); }   // (an overflow read is a sampled transition too)
         if (n_steps) atomicAdd(a.stats + 0, n_steps);
         if (dead_w) atomicAdd(a.stats + 3, dead_w);
         if (probes_w) atomicAdd(a.stats + 6, probes_w);
@@ -484,7 +498,8 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
         const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev,
                                         edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w), reads);
         uint32_t choice = res;
-        if (res == LANE_CHAIN_END || res == LANE_TIE) choice = q0.w;   // overflow read / tie budget: the wave kernel redoes the walk
+        if (res == LANE_CHAIN_END) choice = q0.w;          // never reached: the mirrored overflow read (choice == degree)
+        if (res == LANE_TIE) choice = LANE_NEEDS_WAVE;     // tie budget: the wave kernel redoes the walk
         q[i].choice = choice;
         reads_l = reads;
         done = 1;
@@ -560,6 +575,12 @@ struct LaneBuildArgs {
     ELine *lines;
     uint8_t *clist;                 // FILL only
     uint32_t *segcnt;               // per-(neighbour, segment) counts of the rows longer than LB_SEG
+    // OVERFLOW lines (VIRT passes): vertex v's mirrored overflow read lands on x0(v) = indices[indptr[v + 1]]; the walk
+    // then stands on x0 having come from v -- by a pair that need not be an edge.  lines[nnz + v] is that pair's line;
+    // its list (positions in row x0 of N(v) & N(x0)) is built like a reverse list: x0's row in LDS, v's row streamed.
+    // vlist = the vertices v grouped by x0 (item.vb = start of x0's group), nnz = first overflow line.
+    const uint32_t *__restrict__ vlist;
+    uint32_t nnz;
 };
 
 // ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
@@ -579,6 +600,33 @@ eline_init_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, ELine *lines)
     uint4 *lp = (uint4 *)(lines + e);
     lp[0] = make_uint4(v, 0u, rev, vr.y);
     *(uint2 *)(lp + 1) = make_uint2(vr.x, 0u);
+}
+
+// lines[nnz + v] = { x0, 0, position of v in row x0, degree(x0), indptr[x0], 0 } with x0 = indices[indptr[v + 1]], the vertex
+// the reference's "choice == degree" read of row v lands on (first neighbour of the next non-empty row);
+// nxt = NOT_FOUND when v has no neighbours or that read would leave the index array (the walk kernel clamps: redo path)
+__global__ void __launch_bounds__(256)
+vline_init_kernel(CsrDev g, ELine *lines) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_nodes) return;
+    const uint32_t s0 = g.indptr[v], s1 = g.indptr[v + 1];
+    uint4 l0 = make_uint4(NOT_FOUND, 0u, NOT_FOUND, 0u);
+    uint2 l1 = make_uint2(0u, 0u);
+    if (s1 > s0 && s1 < g.nnz) {
+        const uint32_t x0 = g.indices[s1];
+        const uint4 vr = g.vrec[x0];
+        uint32_t rev = NOT_FOUND;
+        if (vr.y) {
+            const uint64_t tb = g.tab_off[x0];
+            const uint32_t tmask = (uint32_t)(g.tab_off[x0 + 1] - tb) - 1u;
+            rev = adj_lookup(g.slots + tb, tmask, v, true);
+        }
+        l0 = make_uint4(x0, 0u, rev, vr.y);
+        l1 = make_uint2(vr.x, 0u);
+    }
+    uint4 *lp = (uint4 *)(lines + (uint64_t)g.nnz + v);
+    lp[0] = l0;
+    *(uint2 *)(lp + 1) = l1;
 }
 
 __device__ __forceinline__ bool list_is_narrow(uint32_t deg) { return deg <= 65536u; }
@@ -603,9 +651,10 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *keys, uint32
 struct LaneBuildItem {
     uint32_t h, seg, nseg, m0;
     uint32_t j0, j1;   // neighbours (positions of row h) this workgroup takes: the longest rows are split further
+    uint32_t vb, pad;  // VIRT passes: j indexes vlist[vb + j] instead of row h
 };
 
-template <int THREADS, int CAP, bool FILL>
+template <int THREADS, int CAP, bool FILL, bool VIRT = false>
 __global__ void __launch_bounds__(THREADS)
 lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
     constexpr int NW = THREADS / WAVE;
@@ -632,10 +681,20 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
         const uint32_t j = base + (uint32_t)tid;
         if (j < it.j1) {
             const uint32_t e2 = s_h + j;
-            const uint4 r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
-            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
+            uint4 r0;
+            uint2 r1;
+            if (VIRT) {   // neighbour = a vertex whose overflow read lands on h; only ITS line gets a list ("reverse" list)
+                const uint32_t v = a.vlist[it.vb + j];
+                r0 = make_uint4(v, 0u, v, a.indptr[v + 1] - a.indptr[v]);   // (.z = v: e1 below = nnz + v)
+                r1 = make_uint2(a.indptr[v], 0u);
+            } else {
+                r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
+                r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
+            }
             const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
-            const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
+            const bool mine = VIRT || rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
+            // e1: the entry whose list holds positions in row h (the reverse entry; VIRT: k's overflow line)
+            const uint32_t e1 = VIRT ? a.nnz + k : (rev != NOT_FOUND ? s_k + rev : NOT_FOUND);
             if (mine && d_k) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
@@ -651,9 +710,8 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                         if (FILL) {
                             if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) cnt += a.segcnt[it.m0 + j * nseg + sg];
                             k_narrow = list_is_narrow(d_k);
-                            p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
-                            if (rev != NOT_FOUND) {
-                                const uint32_t e1 = s_k + rev;
+                            if (!VIRT) p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                            if (e1 != NOT_FOUND) {
                                 const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
                                 p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                             }
@@ -663,7 +721,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                             const uint32_t idx = lds_lower_bound(keys, P, w);
                             if (keys[idx] == w) {
                                 if (FILL) {
-                                    if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
+                                    if (p2) { if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i; }
                                     if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
                                 }
                                 cnt++;
@@ -673,12 +731,12 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                             if (nseg > 1) {
                                 a.segcnt[it.m0 + j * nseg + it.seg] = cnt;
                                 if (cnt) {
-                                    atomicAdd(&a.lines[e2].n_in, cnt);
-                                    if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, cnt);
+                                    if (!VIRT) atomicAdd(&a.lines[e2].n_in, cnt);
+                                    if (e1 != NOT_FOUND) atomicAdd(&a.lines[e1].n_in, cnt);
                                 }
                             } else {
-                                a.lines[e2].n_in = cnt;
-                                if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = cnt;
+                                if (!VIRT) a.lines[e2].n_in = cnt;
+                                if (e1 != NOT_FOUND) a.lines[e1].n_in = cnt;
                             }
                         }
                     } else {
@@ -694,18 +752,26 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
         for (uint32_t qi = (uint32_t)wv; qi < nq; qi += NW) {
             const uint32_t jq = qj[qi], lo_i = qlo[qi], hi_i = qhi[qi];
             const uint32_t e2 = s_h + jq;
-            const uint4 r0 = *(const uint4 *)(a.lines + e2);
-            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);
+            uint4 r0;
+            uint2 r1;
+            if (VIRT) {
+                const uint32_t v = a.vlist[it.vb + jq];
+                r0 = make_uint4(v, 0u, v, a.indptr[v + 1] - a.indptr[v]);
+                r1 = make_uint2(a.indptr[v], 0u);
+            } else {
+                r0 = *(const uint4 *)(a.lines + e2);
+                r1 = *((const uint2 *)(a.lines + e2) + 2);
+            }
             const uint32_t rev = r0.z, d_k = r0.w, s_k = r1.x;
+            const uint32_t e1 = VIRT ? a.nnz + r0.x : (rev != NOT_FOUND ? s_k + rev : NOT_FOUND);
             uint32_t run = 0;
             uint8_t *p2 = nullptr, *p1 = nullptr;
             bool k_narrow = true;
             if (FILL) {
                 if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) run += a.segcnt[it.m0 + jq * nseg + sg];
                 k_narrow = list_is_narrow(d_k);
-                p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
-                if (rev != NOT_FOUND) {
-                    const uint32_t e1 = s_k + rev;
+                if (!VIRT) p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                if (e1 != NOT_FOUND) {
                     const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
                     p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                 }
@@ -719,7 +785,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 const uint64_t m = ballot(hit);
                 if (FILL && hit) {
                     const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
-                    if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
+                    if (p2) { if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i; }
                     if (p1) { if (h_narrow) ((uint16_t *)p1)[rk] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[rk] = a0 + idx; }
                 }
                 run += (uint32_t)__popcll(m);
@@ -728,12 +794,12 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 if (nseg > 1) {
                     a.segcnt[it.m0 + jq * nseg + it.seg] = run;
                     if (run) {
-                        atomicAdd(&a.lines[e2].n_in, run);
-                        if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, run);
+                        if (!VIRT) atomicAdd(&a.lines[e2].n_in, run);
+                        if (e1 != NOT_FOUND) atomicAdd(&a.lines[e1].n_in, run);
                     }
                 } else {
-                    a.lines[e2].n_in = run;
-                    if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = run;
+                    if (!VIRT) a.lines[e2].n_in = run;
+                    if (e1 != NOT_FOUND) a.lines[e1].n_in = run;
                 }
             }
         }
@@ -754,12 +820,12 @@ constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;
 
 // tile_sums[b] = 16-byte units of tile b; entry_sums[b] = list entries of tile b
 __global__ void __launch_bounds__(CL_BLOCK)
-clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint64_t *tile_sums, uint64_t *entry_sums) {
+clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint32_t nnz_real, uint64_t *tile_sums, uint64_t *entry_sums) {
     __shared__ uint64_t sh[CL_BLOCK], sh2[CL_BLOCK];
     const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)threadIdx.x * CL_ITEMS;
     uint64_t s = 0, s2 = 0;
     for (int k = 0; k < CL_ITEMS; k++)
-        if (base + k < nnz) { s += list_units(lines, base + k); s2 += lines[base + k].n_in; }
+        if (base + k < nnz) { s += list_units(lines, base + k); if (base + k < nnz_real) s2 += lines[base + k].n_in; }
     sh[threadIdx.x] = s;
     sh2[threadIdx.x] = s2;
     __syncthreads();

@@ -40,7 +40,7 @@ def test_lane_kernel_runs_and_equals_oracle_and_wave_kernel(scale, p, q, monkeyp
     assert st["lane_kernel"] == 1
     assert np.array_equal(got, want)
     assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
-    assert st["redo_walks"] >= st["overflow_reads"] > 0 or st["overflow_reads"] == 0
+    # (mirrored overflow reads are stepped by the lane kernel itself, through the vertex's overflow line: no redo needed)
     wave = _wave_engine(indptr, indices, data, monkeypatch)
     got_w = wave.simulate("SparseOTF", p, q, False, starts, 40, seed=5)
     assert wave.last_stats["lane_kernel"] == 0
@@ -305,3 +305,30 @@ def test_graph_handle_releases_its_device_memory(monkeypatch):
         eng.close()
         free.append(torch.cuda.mem_get_info()[0])
     assert free[0] - free[-1] < (32 << 20), free
+
+
+def test_overflow_reads_step_through_the_vertex_overflow_line(monkeypatch):
+    """choice == degree (the float32 CDF falls short of r): the reference reads the first neighbour of the next non-empty
+    row (App. D quirk 1) -- a vertex that depends on cur only, so the pair (cur, that vertex) has a line of its own in the
+    lane index (lines[nnz + cur]) and the lane kernel steps through the read itself.  Same walks as the oracle and as a
+    handle without those lines (PECANPY_AMD_NO_VLINES: the wave kernel finishes such walks); overflow reads on hub rows,
+    on first steps, and the clamped read at the end of the index array (always the wave kernel's)."""
+    rng = np.random.default_rng(5)
+    indptr, indices, data = _hub_graph(rng, n=70000, hub_deg=60000)
+    n = indptr.size - 1
+    starts = np.concatenate([np.zeros(4000, dtype=np.uint32), rng.integers(0, n, 20000).astype(np.uint32)])
+    for p, q in ((0.5, 2.0), (1.0, 0.25)):
+        want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 60, 7, return_stats=True)
+        assert ost.overflow_reads > 20                      # (a 60 000-entry row: ~1e-4 of the draws fall beyond its CDF)
+        eng = WalkEngine.from_csr(indptr, indices, data)
+        got = eng.simulate("SparseOTF", p, q, False, starts, 60, seed=7)
+        st = dict(eng.last_stats)
+        assert np.array_equal(got, want)
+        assert st["overflow_reads"] == ost.overflow_reads and st["total_steps"] == ost.total_steps
+        assert st["redo_walks"] < st["overflow_reads"]      # stepped in the lane kernel, not handed to the wave kernel
+        monkeypatch.setenv("PECANPY_AMD_NO_VLINES", "1")
+        plain = WalkEngine.from_csr(indptr, indices, data)
+        monkeypatch.delenv("PECANPY_AMD_NO_VLINES")
+        got2 = plain.simulate("SparseOTF", p, q, False, starts, 60, seed=7)
+        assert np.array_equal(got2, want)
+        assert plain.last_stats["redo_walks"] >= plain.last_stats["overflow_reads"] == ost.overflow_reads

@@ -184,3 +184,41 @@ def test_read_npz_memory_maps_uncompressed_members(tmp_path):
     c.read_npz(p, True)
     assert c.indptr.dtype == np.uint32 and c.data.dtype == np.float32
     assert np.array_equal(c.indptr, ip) and np.array_equal(c.indices, ix) and np.array_equal(c.data, dt)
+
+
+# ---- synthetic graph families of the exactness evidence (pecanpy_amd/synth.py) --------------------------------------
+def _check_undirected_csr(indptr, indices, data):
+    n = indptr.size - 1
+    ip = indptr.astype(np.int64)
+    assert ip[0] == 0 and ip[-1] == indices.size and (np.diff(ip) >= 0).all() and (data == 1.0).all()
+    rows = np.repeat(np.arange(n), np.diff(ip))
+    assert (rows != indices).all()                                    # no self loops
+    inner = np.ones(indices.size, dtype=bool)
+    inner[ip[:-1][np.diff(ip) > 0]] = False
+    assert (np.diff(indices.astype(np.int64))[inner[1:]] > 0).all()   # rows strictly ascending
+    key = rows * n + indices.astype(np.int64)
+    assert np.array_equal(np.sort(key), np.sort(indices.astype(np.int64) * n + rows))   # symmetric
+    return np.diff(ip)
+
+
+def test_ring_lattice_is_regular_and_triangle_rich():
+    from pecanpy_amd.synth import ring_lattice_csr
+
+    indptr, indices, data = ring_lattice_csr(400, 12)
+    deg = _check_undirected_csr(indptr, indices, data)
+    assert (deg == 24).all()
+    # neighbours at ring distance t share 2k - t - 1 neighbours
+    row0, row5 = set(indices[indptr[0]:indptr[1]]), set(indices[indptr[5]:indptr[6]])
+    assert len(row0 & row5) == 2 * 12 - 5 - 1
+
+
+def test_holme_kim_bipartite_hubs_and_gnm_are_well_formed():
+    from pecanpy_amd.synth import bipartite_hubs_csr, gnm_csr, holme_kim_csr
+
+    deg = _check_undirected_csr(*holme_kim_csr(3000, 6, 0.8, seed=1))
+    assert deg.min() >= 6 and deg.max() > 60                          # grown by preferential attachment: a heavy tail
+    indptr, indices, data = bipartite_hubs_csr(5, 2000, 700, seed=3)
+    deg = _check_undirected_csr(indptr, indices, data)
+    assert (deg[:5] == 700).all() and (indices[indptr[0]:indptr[5]] >= 5).all()   # hubs only see leaves: no triangles
+    deg = _check_undirected_csr(*gnm_csr(5000, 20000, seed=2))
+    assert abs(deg.mean() - 8.0) < 0.2
