@@ -281,51 +281,26 @@ static pw::CsrDev csr_dev(const pw_graph *g);
 // adjacent pair, row of the larger endpoint in LDS (lane_lists_kernel: count pass, offsets, fill pass).  Skipped (the
 // wave-per-walk kernel then serves every call, eager step) when lines + lists would take more than half of the free
 // device memory.  `indptr` = the caller's host array.
-static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t *indices, const uint32_t *d_edge_row) {
+static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t *d_edge_row) {
     if (!g->nnz) return 0;
     const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
     // work items: one per (vertex, segment of its row, chunk of its neighbours)
-    std::vector<pw::LaneBuildItem> small, large, vsmall, vlarge;
+    std::vector<pw::LaneBuildItem> small, large;
     uint64_t segcnt_total = 0;
     const uint32_t JCHUNK = 16384;
     for (uint32_t h = 0; h < n_nodes; h++) {
         const uint32_t d = indptr[h + 1] - indptr[h];
         if (d < 2) continue;   // one neighbour k: N(h) & N(k) = {k} & N(k) is empty without self loops
-        if (d <= (uint32_t)pw::LB_SMALL) { small.push_back({h, 0u, 1u, 0u, 0u, d, 0u, 0u}); continue; }
+        if (d <= (uint32_t)pw::LB_SMALL) { small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
         const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
         uint32_t m0 = 0;
         if (nseg > 1) { m0 = (uint32_t)segcnt_total; segcnt_total += (uint64_t)d * nseg; }
         for (uint32_t sg = 0; sg < nseg; sg++)
-            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d, 0u, 0u});
-    }
-    // OVERFLOW lines (walk_lanes.hip.h: vline_init_kernel): vertex v's "choice == degree" read lands on x0(v) =
-    // indices[indptr[v + 1]]; the vertices are grouped by x0 (counting sort) and every x0 gets work items like a row's
-    const bool vlines = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
-    std::vector<uint32_t> vlist;
-    if (vlines) {
-        std::vector<uint32_t> vcount((size_t)n_nodes + 1, 0);
-        for (uint32_t v = 0; v < n_nodes; v++)
-            if (indptr[v + 1] > indptr[v] && indptr[v + 1] < nnz) vcount[indices[indptr[v + 1]] + 1]++;
-        for (uint32_t h = 0; h < n_nodes; h++) vcount[h + 1] += vcount[h];   // vcount[h] = start of h's group
-        vlist.resize(vcount[n_nodes] ? vcount[n_nodes] : 1);
-        std::vector<uint32_t> cursor(vcount.begin(), vcount.end() - 1);
-        for (uint32_t v = 0; v < n_nodes; v++)
-            if (indptr[v + 1] > indptr[v] && indptr[v + 1] < nnz) vlist[cursor[indices[indptr[v + 1]]]++] = v;
-        for (uint32_t h = 0; h < n_nodes; h++) {
-            const uint32_t nv = vcount[h + 1] - vcount[h], d = indptr[h + 1] - indptr[h];
-            if (!nv || !d) continue;
-            if (d <= (uint32_t)pw::LB_SMALL) {
-                for (uint32_t j0 = 0; j0 < nv; j0 += JCHUNK) vsmall.push_back({h, 0u, 1u, 0u, j0, j0 + JCHUNK < nv ? j0 + JCHUNK : nv, vcount[h], 0u});
-                continue;
-            }
-            const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
-            uint32_t m0 = 0;
-            if (nseg > 1) { m0 = (uint32_t)segcnt_total; segcnt_total += (uint64_t)nv * nseg; }
-            for (uint32_t sg = 0; sg < nseg; sg++)
-                for (uint32_t j0 = 0; j0 < nv; j0 += JCHUNK) vlarge.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < nv ? j0 + JCHUNK : nv, vcount[h], 0u});
-        }
+            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
     }
     if (segcnt_total >= 0xffffffffull) return 0;   // (rows this long and this many: no lane index)
+    // + one OVERFLOW line per vertex (walk_lanes.hip.h: vline_init_kernel): the pair of its mirrored choice == degree read
+    const bool vlines = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
     const uint32_t n_lines = vlines ? nnz + n_nodes : nnz;
     // the longest rows first (their workgroups run longest)
     std::stable_sort(large.begin(), large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
@@ -335,13 +310,12 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t line_bytes = (uint64_t)n_lines * sizeof(pw::ELine) + 64;
     if (line_bytes > free_b / 2) return 0;
-    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr, *d_vsmall = nullptr, *d_vlarge = nullptr;
-    uint32_t *d_segcnt = nullptr, *d_vlist = nullptr;
+    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
+    uint32_t *d_segcnt = nullptr;
     uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
     const uint64_t n_tiles = ((uint64_t)n_lines + pw::CL_TILE - 1) / pw::CL_TILE;
     auto cleanup = [&]() {
-        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_vsmall, (void *)d_vlarge, (void *)d_segcnt, (void *)d_vlist,
-                        (void *)d_tiles, (void *)d_etiles})
+        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles})
             if (q) (void)hipFree(q);
     };
     auto drop = [&](int rc) {   // no lane index
@@ -363,16 +337,6 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
         e = hipMemcpyAsync(d_small, small.data(), sizeof(pw::LaneBuildItem) * small.size(), hipMemcpyHostToDevice, g->stream);
     if (e == hipSuccess && !large.empty())
         e = hipMemcpyAsync(d_large, large.data(), sizeof(pw::LaneBuildItem) * large.size(), hipMemcpyHostToDevice, g->stream);
-    if (e == hipSuccess && vlines) {
-        e = hipMalloc((void **)&d_vsmall, sizeof(pw::LaneBuildItem) * (vsmall.size() + 1));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_vlarge, sizeof(pw::LaneBuildItem) * (vlarge.size() + 1));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_vlist, sizeof(uint32_t) * vlist.size());
-        if (e == hipSuccess && !vsmall.empty())
-            e = hipMemcpyAsync(d_vsmall, vsmall.data(), sizeof(pw::LaneBuildItem) * vsmall.size(), hipMemcpyHostToDevice, g->stream);
-        if (e == hipSuccess && !vlarge.empty())
-            e = hipMemcpyAsync(d_vlarge, vlarge.data(), sizeof(pw::LaneBuildItem) * vlarge.size(), hipMemcpyHostToDevice, g->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_vlist, vlist.data(), sizeof(uint32_t) * vlist.size(), hipMemcpyHostToDevice, g->stream);
-    }
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index: ") + hipGetErrorString(e)));
     pw::CsrDev c = csr_dev(g);
     pw::LaneBuildArgs ba;
@@ -381,10 +345,9 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     ba.lines = g->d_lines;
     ba.clist = nullptr;
     ba.segcnt = d_segcnt;
-    ba.vlist = d_vlist;
-    ba.nnz = nnz;
     hipLaunchKernelGGL(pw::eline_init_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c, d_edge_row, g->d_lines);
     if (vlines) hipLaunchKernelGGL(pw::vline_init_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, g->stream, c, g->d_lines);
+    const unsigned vgrid = (unsigned)(((uint64_t)n_nodes * pw::WAVE + 255) / 256);
     auto lists = [&](bool fill) {
         if (!large.empty()) {
             if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
@@ -394,13 +357,9 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
             if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, true>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
             else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
         }
-        if (!vlarge.empty()) {
-            if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true, true>), dim3((unsigned)vlarge.size()), dim3(256), 0, g->stream, ba, d_vlarge);
-            else hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false, true>), dim3((unsigned)vlarge.size()), dim3(256), 0, g->stream, ba, d_vlarge);
-        }
-        if (!vsmall.empty()) {
-            if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, true, true>), dim3((unsigned)vsmall.size()), dim3(64), 0, g->stream, ba, d_vsmall);
-            else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false, true>), dim3((unsigned)vsmall.size()), dim3(64), 0, g->stream, ba, d_vsmall);
+        if (vlines) {
+            if (fill) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
+            else hipLaunchKernelGGL(pw::vline_lists_kernel<false>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, (uint8_t *)nullptr);
         }
     };
     lists(false);
@@ -541,7 +500,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel); skipped for
         // graphs with self loops, where "common neighbour" and the reference's prev handling differ
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
-        rc = build_lane_index(g, indptr, indices, d_edge_row);
+        rc = build_lane_index(g, indptr, d_edge_row);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
     (void)hipEventRecord(g->ev[1], g->stream);

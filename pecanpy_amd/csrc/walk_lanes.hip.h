@@ -575,12 +575,6 @@ struct LaneBuildArgs {
     ELine *lines;
     uint8_t *clist;                 // FILL only
     uint32_t *segcnt;               // per-(neighbour, segment) counts of the rows longer than LB_SEG
-    // OVERFLOW lines (VIRT passes): vertex v's mirrored overflow read lands on x0(v) = indices[indptr[v + 1]]; the walk
-    // then stands on x0 having come from v -- by a pair that need not be an edge.  lines[nnz + v] is that pair's line;
-    // its list (positions in row x0 of N(v) & N(x0)) is built like a reverse list: x0's row in LDS, v's row streamed.
-    // vlist = the vertices v grouped by x0 (item.vb = start of x0's group), nnz = first overflow line.
-    const uint32_t *__restrict__ vlist;
-    uint32_t nnz;
 };
 
 // ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
@@ -602,9 +596,11 @@ eline_init_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, ELine *lines)
     *(uint2 *)(lp + 1) = make_uint2(vr.x, 0u);
 }
 
-// lines[nnz + v] = { x0, 0, position of v in row x0, degree(x0), indptr[x0], 0 } with x0 = indices[indptr[v + 1]], the vertex
-// the reference's "choice == degree" read of row v lands on (first neighbour of the next non-empty row);
-// nxt = NOT_FOUND when v has no neighbours or that read would leave the index array (the walk kernel clamps: redo path)
+// OVERFLOW lines.  Vertex v's "choice == degree" read lands on x0(v) = indices[indptr[v + 1]] (first neighbour of the
+// next non-empty row); the walk then stands on x0 having come from v -- a pair that need not be an edge, so no CSR entry
+// carries its record.  lines[nnz + v] = { x0, |N(v) & N(x0)|, position of v in row x0, degree(x0), indptr[x0], list offset }
+// + the list (positions in row x0 of the common neighbours), like any edge line; nxt = NOT_FOUND when v has no
+// neighbours or the read would leave the index array (the walk kernel clamps it: redo path).
 __global__ void __launch_bounds__(256)
 vline_init_kernel(CsrDev g, ELine *lines) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,6 +625,43 @@ vline_init_kernel(CsrDev g, ELine *lines) {
     *(uint2 *)(lp + 1) = l1;
 }
 
+// The lists of the overflow lines: one wavefront per vertex v streams row v and looks every neighbour up in x0's
+// adjacency index (one probe; x0 is a hub more often than not -- the smallest neighbour of the next vertex -- and its
+// table stays in L2): the hits, in row order, ARE the ascending positions in row x0.  FILL = false: the count.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
+    const uint32_t v = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+    if (v >= g.n_nodes) return;
+    const int lane = lane_id();
+    const uint32_t e = g.nnz + v;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    const uint32_t x0 = r0.x, d0 = r0.w;
+    if (x0 == NOT_FOUND || d0 == 0) return;
+    const uint32_t s_v = g.indptr[v], d_v = g.indptr[v + 1] - s_v;
+    const uint64_t tb = g.tab_off[x0];
+    const uint32_t tmask = (uint32_t)(g.tab_off[x0 + 1] - tb) - 1u;
+    const bool narrow = d0 <= 65536u;
+    uint8_t *p = nullptr;
+    if (FILL) p = (uint8_t *)((narrow && r0.y <= EL_INLINE) ? (uint8_t *)(lines + e) + 24 : clist + (uint64_t)lines[e].coff * 16u);
+    const uint64_t lane_lt = (1ull << lane) - 1ull;
+    uint32_t run = 0;
+    for (uint32_t c0 = 0; c0 < d_v; c0 += WAVE) {
+        const uint32_t i = c0 + (uint32_t)lane;
+        const bool valid = i < d_v;
+        const uint32_t w = valid ? g.indices[s_v + i] : 0u;
+        const uint32_t gpos = adj_lookup(g.slots + tb, tmask, w, valid);
+        const bool hit = valid && gpos != NOT_FOUND;
+        const uint64_t m = ballot(hit);
+        if (FILL && hit) {
+            const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
+            if (narrow) ((uint16_t *)p)[rk] = (uint16_t)gpos; else ((uint32_t *)p)[rk] = gpos;
+        }
+        run += (uint32_t)__popcll(m);
+    }
+    if (!FILL && lane == 0) lines[e].n_in = run;
+}
+
 __device__ __forceinline__ bool list_is_narrow(uint32_t deg) { return deg <= 65536u; }
 __device__ __forceinline__ bool list_is_inline(uint32_t deg, uint32_t n_in) { return list_is_narrow(deg) && n_in <= EL_INLINE; }
 __device__ __forceinline__ const uint8_t *list_base(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t deg,
@@ -651,10 +684,9 @@ __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *keys, uint32
 struct LaneBuildItem {
     uint32_t h, seg, nseg, m0;
     uint32_t j0, j1;   // neighbours (positions of row h) this workgroup takes: the longest rows are split further
-    uint32_t vb, pad;  // VIRT passes: j indexes vlist[vb + j] instead of row h
 };
 
-template <int THREADS, int CAP, bool FILL, bool VIRT = false>
+template <int THREADS, int CAP, bool FILL>
 __global__ void __launch_bounds__(THREADS)
 lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
     constexpr int NW = THREADS / WAVE;
@@ -681,20 +713,10 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
         const uint32_t j = base + (uint32_t)tid;
         if (j < it.j1) {
             const uint32_t e2 = s_h + j;
-            uint4 r0;
-            uint2 r1;
-            if (VIRT) {   // neighbour = a vertex whose overflow read lands on h; only ITS line gets a list ("reverse" list)
-                const uint32_t v = a.vlist[it.vb + j];
-                r0 = make_uint4(v, 0u, v, a.indptr[v + 1] - a.indptr[v]);   // (.z = v: e1 below = nnz + v)
-                r1 = make_uint2(a.indptr[v], 0u);
-            } else {
-                r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
-                r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
-            }
+            const uint4 r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
+            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
             const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
-            const bool mine = VIRT || rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
-            // e1: the entry whose list holds positions in row h (the reverse entry; VIRT: k's overflow line)
-            const uint32_t e1 = VIRT ? a.nnz + k : (rev != NOT_FOUND ? s_k + rev : NOT_FOUND);
+            const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
             if (mine && d_k) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
@@ -710,8 +732,9 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                         if (FILL) {
                             if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) cnt += a.segcnt[it.m0 + j * nseg + sg];
                             k_narrow = list_is_narrow(d_k);
-                            if (!VIRT) p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
-                            if (e1 != NOT_FOUND) {
+                            p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                            if (rev != NOT_FOUND) {
+                                const uint32_t e1 = s_k + rev;
                                 const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
                                 p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                             }
@@ -721,7 +744,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                             const uint32_t idx = lds_lower_bound(keys, P, w);
                             if (keys[idx] == w) {
                                 if (FILL) {
-                                    if (p2) { if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i; }
+                                    if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
                                     if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
                                 }
                                 cnt++;
@@ -731,12 +754,12 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                             if (nseg > 1) {
                                 a.segcnt[it.m0 + j * nseg + it.seg] = cnt;
                                 if (cnt) {
-                                    if (!VIRT) atomicAdd(&a.lines[e2].n_in, cnt);
-                                    if (e1 != NOT_FOUND) atomicAdd(&a.lines[e1].n_in, cnt);
+                                    atomicAdd(&a.lines[e2].n_in, cnt);
+                                    if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, cnt);
                                 }
                             } else {
-                                if (!VIRT) a.lines[e2].n_in = cnt;
-                                if (e1 != NOT_FOUND) a.lines[e1].n_in = cnt;
+                                a.lines[e2].n_in = cnt;
+                                if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = cnt;
                             }
                         }
                     } else {
@@ -752,26 +775,18 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
         for (uint32_t qi = (uint32_t)wv; qi < nq; qi += NW) {
             const uint32_t jq = qj[qi], lo_i = qlo[qi], hi_i = qhi[qi];
             const uint32_t e2 = s_h + jq;
-            uint4 r0;
-            uint2 r1;
-            if (VIRT) {
-                const uint32_t v = a.vlist[it.vb + jq];
-                r0 = make_uint4(v, 0u, v, a.indptr[v + 1] - a.indptr[v]);
-                r1 = make_uint2(a.indptr[v], 0u);
-            } else {
-                r0 = *(const uint4 *)(a.lines + e2);
-                r1 = *((const uint2 *)(a.lines + e2) + 2);
-            }
+            const uint4 r0 = *(const uint4 *)(a.lines + e2);
+            const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);
             const uint32_t rev = r0.z, d_k = r0.w, s_k = r1.x;
-            const uint32_t e1 = VIRT ? a.nnz + r0.x : (rev != NOT_FOUND ? s_k + rev : NOT_FOUND);
             uint32_t run = 0;
             uint8_t *p2 = nullptr, *p1 = nullptr;
             bool k_narrow = true;
             if (FILL) {
                 if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) run += a.segcnt[it.m0 + jq * nseg + sg];
                 k_narrow = list_is_narrow(d_k);
-                if (!VIRT) p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
-                if (e1 != NOT_FOUND) {
+                p2 = (uint8_t *)list_base(a.lines, a.clist, e2, d_k, r0.y, r1.y);
+                if (rev != NOT_FOUND) {
+                    const uint32_t e1 = s_k + rev;
                     const uint32_t n1 = a.lines[e1].n_in, c1 = a.lines[e1].coff;
                     p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                 }
@@ -785,7 +800,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 const uint64_t m = ballot(hit);
                 if (FILL && hit) {
                     const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
-                    if (p2) { if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i; }
+                    if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
                     if (p1) { if (h_narrow) ((uint16_t *)p1)[rk] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[rk] = a0 + idx; }
                 }
                 run += (uint32_t)__popcll(m);
@@ -794,12 +809,12 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 if (nseg > 1) {
                     a.segcnt[it.m0 + jq * nseg + it.seg] = run;
                     if (run) {
-                        if (!VIRT) atomicAdd(&a.lines[e2].n_in, run);
-                        if (e1 != NOT_FOUND) atomicAdd(&a.lines[e1].n_in, run);
+                        atomicAdd(&a.lines[e2].n_in, run);
+                        if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, run);
                     }
                 } else {
-                    if (!VIRT) a.lines[e2].n_in = run;
-                    if (e1 != NOT_FOUND) a.lines[e1].n_in = run;
+                    a.lines[e2].n_in = run;
+                    if (rev != NOT_FOUND) a.lines[s_k + rev].n_in = run;
                 }
             }
         }
