@@ -1013,7 +1013,11 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     // separate launch runs all queued chains at full width, and the next round of the lane kernel resumes the walks.
     // Rounds go on while a queue is worth a launch; the last one runs its chains in place.
     const char *tail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
-    uint64_t tail = tail_env ? (uint64_t)strtoull(tail_env, nullptr, 10) : lanes_resident / 2;
+    // (RMAT-22, 21 M walks with neighbours: tail = lanes_resident / 2 -> 6 rounds, 158.7 ms per pass; 4 x -> 4 rounds, 155.2;
+    //  16 x -> 160.8: the chains of the last round run at a few lanes per wavefront)
+    uint64_t tail = lanes_resident / 2;
+    if (n_work / 16 > tail) tail = n_work / 16 < 4 * lanes_resident ? n_work / 16 : 4 * lanes_resident;
+    if (tail_env) tail = (uint64_t)strtoull(tail_env, nullptr, 10);
     bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
     const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;

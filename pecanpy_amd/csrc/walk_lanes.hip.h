@@ -167,7 +167,9 @@ __device__ unsigned long long g_lprof[16];
             A.flags = 0;                                                                        \
         } else {                                                                                \
             A.e = oe_ != NOT_FOUND ? oe_ : A.s0 + choice;                                       \
-            if (oe_ != NOT_FOUND) n_over++;                                                     \
+            if (oe_ != NOT_FOUND) {   /* (~1e-5 of the steps: counted where it happens; a sampled transition too) */ \
+                atomicAdd(a.stats + 1, 1ull); atomicAdd(a.stats + 0, 1ull);                     \
+            }                                                                                   \
             const uint4 *rp_ = (const uint4 *)(a.lines + A.e);                                  \
             const uint4 r0_ = rp_[0];                                                           \
             const uint2 r1_ = *(const uint2 *)(rp_ + 1);                                        \
@@ -242,12 +244,21 @@ walk_lanes_kernel(LanesArgs a) {
     Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
     bool exhausted = false;
     uint64_t pool_lo = 0, pool_hi = 0;   // wavefront-uniform: job indices reserved from the shared counter
+    // JOB WINDOW: what a new walk needs before its first step -- job, start vertex, its row, its stream position, its
+    // first draw: a chain of three dependent scattered loads -- is fetched for the NEXT 64 jobs of the pool at once and
+    // parked in LDS; a refill then costs one LDS read instead of that chain (nearly every loop iteration refills a lane
+    // or two: ~40 steps per walk, 64 lanes).  Entries [win_lo, win_lo + win_n) of the job array are in the window.
+    struct JobSlot { uint32_t job, start, s0, d; uint32_t soff_lo, soff_hi, r_lo, r_hi; };
+    __shared__ JobSlot s_win[WAVES_PER_BLOCK][WAVE];
+    JobSlot *const win = s_win[readfirst_u32(threadIdx.x / WAVE)];
+    uint64_t win_lo = 0;
+    uint32_t win_n = 0;
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
     const uint64_t grid_lanes = (uint64_t)gridDim.x * (WAVES_PER_BLOCK * WAVE);
     // statistics: wave-uniform sums of ballots where a count of lanes is all that is needed (scalar registers), 32-bit
     // per-lane counters for the rest
     unsigned long long n_steps = 0, n_amb = 0, n_wave = 0;
-    uint32_t n_dead = 0, n_probes = 0, n_over = 0;
+    uint32_t n_dead = 0, n_probes = 0;
     // a step in flight, kept while the lane waits for the chains: draw, row total, prefix bound, out weight
     double r = 0.0;
     OutCells ob = {{0u, 0u, 0u, 0u}};   // staged output cells of the current walk
@@ -283,6 +294,32 @@ walk_lanes_kernel(LanesArgs a) {
             const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
             const uint64_t pool_base = pool_lo;
             pool_lo += avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+            if (!a.resume) {
+                const uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+                if (pool_base < win_lo || pool_base + take > win_lo + win_n) {   // (wave-uniform) window used up: the next 64 jobs
+                    win_lo = pool_base;
+                    win_n = avail < (uint64_t)WAVE ? (uint32_t)avail : (uint32_t)WAVE;
+                    wave_lds_fence();                                      // (earlier reads of the window are over)
+                    if ((uint32_t)lane < win_n) {
+                        const uint64_t widx = pool_base + (uint64_t)lane;
+                        JobSlot js;
+                        js.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
+                        js.start = a.starts[js.job];
+                        const uint4 vr = a.vrec[js.start];
+                        js.s0 = vr.x; js.d = vr.y;
+                        uint64_t so = 0;
+                        double r0 = 0.0;
+                        if (vr.y) { so = a.stream_off[js.job] - a.rng_base; r0 = a.rng[so]; }
+                        js.soff_lo = (uint32_t)so; js.soff_hi = (uint32_t)(so >> 32);
+                        js.r_lo = (uint32_t)__double_as_longlong(r0);
+                        js.r_hi = (uint32_t)((unsigned long long)__double_as_longlong(r0) >> 32);
+                        uint4 *wp = (uint4 *)(win + lane);
+                        wp[0] = make_uint4(js.job, js.start, js.s0, js.d);
+                        wp[1] = make_uint4(js.soff_lo, js.soff_hi, js.r_lo, js.r_hi);
+                    }
+                    wave_lds_fence();
+                }
+            }
             if (!(A.flags & F_ACTIVE) && !exhausted && rank < avail) {
                 const uint64_t widx = pool_base + rank;
                 if (a.resume) {
@@ -301,9 +338,11 @@ walk_lanes_kernel(LanesArgs a) {
                         A.flags = F_ACTIVE | F_PRE;
                     }
                 } else {
-                    A.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
-                    const uint32_t start = a.starts[A.job];
-                    const uint4 vr = a.vrec[start];
+                    const uint4 *wp = (const uint4 *)(win + (uint32_t)(widx - win_lo));
+                    const uint4 j0 = wp[0], j1 = wp[1];
+                    A.job = j0.x;
+                    const uint32_t start = j0.y;
+                    const uint4 vr = make_uint4(j0.z, j0.w, 0u, 0u);
                     uint32_t *row = a.out + (uint64_t)A.job * W;
                     row[0] = start;
                     if (vr.y == 0) {
@@ -311,9 +350,9 @@ walk_lanes_kernel(LanesArgs a) {
                         if (a.job_list)          // a repaired row may hold an older walk
                             for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                     } else {
-                        A.soff = a.stream_off[A.job] - a.rng_base;
+                        A.soff = ((uint64_t)j1.y << 32) | j1.x;
                         A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
-                        r = a.rng[A.soff];
+                        r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
                         A.flags = F_ACTIVE;
                     }
                 }
@@ -465,14 +504,12 @@ walk_lanes_kernel(LanesArgs a) {
     if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
 #endif
     // wave totals
-    unsigned long long dead_w = n_dead, probes_w = n_probes, over_w = n_over;
+    unsigned long long dead_w = n_dead, probes_w = n_probes;
     for (int off = 32; off > 0; off >>= 1) {
         dead_w += (unsigned long long)__shfl_down((long long)dead_w, (unsigned)off, WAVE);
         probes_w += (unsigned long long)__shfl_down((long long)probes_w, (unsigned)off, WAVE);
-        over_w += (unsigned long long)__shfl_down((long long)over_w, (unsigned)off, WAVE);
     }
     if (lane == 0) {
-        if (over_w) { atomicAdd(a.stats + 1, over_w); atomicAdd(a.stats + 0, over_w); }   // (an overflow read is a sampled transition too)
         if (n_steps) atomicAdd(a.stats + 0, n_steps);
         if (dead_w) atomicAdd(a.stats + 3, dead_w);
         if (probes_w) atomicAdd(a.stats + 6, probes_w);
