@@ -359,7 +359,7 @@ def main():
         else:
             declared = steps0 * (3 * wpr * 8 + 12)
             fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
-        kernel = "walk_dense_bits_kernel"
+        kernel = "walk_dense_fast_kernel"
     else:
         # the wave-per-walk kernel streams rows (keys of the shorter row, weights of cur's row): SURVEY 8(d)'s
         # figure in the reference's element sizes is its declared format

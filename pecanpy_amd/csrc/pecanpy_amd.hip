@@ -862,7 +862,12 @@ static walk_kernel_fn pick_kernel(const pw_graph *g, bool extend) {
 }
 
 // unweighted dense graphs: column-space kernel on the packed adjacency (walk_dense.hip.h)
-static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
+static bool is_pow2_double(double x) {
+    int e = 0;
+    return x > 0 && std::frexp(x, &e) == 0.5;
+}
+
+static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa, uint64_t *redo_total) {
     pw::DenseArgs da;
     da.adjbits = g->d_adjbits;
     da.deg = g->d_deg;
@@ -890,16 +895,50 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa) {
         else if (da.wpr <= 64 * 25) fn = pw::walk_dense_bits_kernel<25>;
         else if (da.wpr <= 64 * 32) fn = pw::walk_dense_bits_kernel<32>;
     }
-    int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
-    if (occ < 1) occ = 1;
     uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
-    uint64_t want = (n_work + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
-    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
-    if (grid > want) grid = want;
-    if (grid < 1) grid = 1;
+    // dyadic 1/p, 1/q: the decisive path alone, in registers (walk_dense_fast_kernel); what it leaves (a handful of
+    // walks per 10^8 steps) is walked again by the complete kernel
+    typedef void (*fast_fn)(pw::DenseArgs, uint32_t *, unsigned long long *, uint32_t);
+    fast_fn ff = nullptr;
+    if (fn != pw::walk_dense_bits_kernel<0> && is_pow2_double(1.0 / wa.p) && is_pow2_double(1.0 / wa.q) && !getenv("PECANPY_AMD_DENSE_NO_FAST")) {
+        if (da.wpr <= 64 * 8) ff = pw::walk_dense_fast_kernel<8>;
+        else if (da.wpr <= 64 * 16) ff = pw::walk_dense_fast_kernel<16>;
+        else if (da.wpr <= 64 * 25) ff = pw::walk_dense_fast_kernel<25>;
+        else ff = pw::walk_dense_fast_kernel<32>;
+    }
+    auto grid_for = [&](const void *f, uint64_t work, unsigned *out) -> int {
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, f, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+        if (occ < 1) occ = 1;
+        const uint64_t want = (work + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
+        uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
+        if (grid > want) grid = want;
+        if (grid < 1) grid = 1;
+        *out = (unsigned)grid;
+        return 0;
+    };
+    unsigned grid = 1;
+    if (ff && n_work) {
+        if (g->redo.ensure(n_work)) return PW_ERR_NOMEM;
+        if (grid_for((const void *)ff, n_work, &grid)) return PW_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+        HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+        const char *rt = getenv("PECANPY_AMD_DENSE_REDO_TEST");   // tests: every k-th walk is handed over at its third step
+        hipLaunchKernelGGL(ff, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, da, g->redo.p, g->counters.p + 6,
+                           rt ? (uint32_t)strtoul(rt, nullptr, 10) : 0u);
+        HIP_TRY(hipGetLastError());
+        unsigned long long nr = 0;
+        HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (!nr) return 0;
+        if (redo_total) *redo_total += nr;
+        da.job_list = g->redo.p;
+        da.n_list = nr;
+        n_work = nr;
+    }
+    if (grid_for((const void *)fn, n_work, &grid)) return PW_ERR_HIP;
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, da);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, da);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -952,10 +991,10 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     return 0;
 }
 
-static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend) {
+static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total = nullptr) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
-    if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa);
+    if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa, redo_total);
     int occ = 0;
     walk_kernel_fn fn = pick_kernel(g, extend);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
@@ -1225,7 +1264,7 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     const bool floats = lanes_float_eligible(g, wa);
-    if (!floats && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend);
+    if (!floats && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend, redo_total);
     uint64_t n_redo = 0;
     int rc = floats ? launch_lane_float_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range, tie budget) go to walk_kernel,

@@ -509,6 +509,221 @@ walk_dense_bits_kernel(DenseArgs a) {
     }
 }
 
+// ---- the FAST form ---------------------------------------------------------------------------------------------
+// walk_dense_bits_kernel carries the float64 chain (masks + rank arrays in LDS, seq_scan_binade, ...) for the steps the
+// exact-arithmetic decision cannot settle -- 2 of 80 M steps at ER-100k -- and for non-dyadic p, q; that code sets the
+// kernel's register count (254 VGPRs at WPL = 25: two wavefronts per SIMD, and the walk is a chain of dependent
+// operations: occupancy is what hides it).  This kernel is the decisive path ALONE, entirely in registers:
+//   count pass   per-lane class counts per 16384-column segment, packed in | out << 16, one interleaved wave sum each
+//   tot          from the counts (dyadic weights: exact), thresholds of the exact decision (seqscan.h)
+//   search       segment from the sums; inside it the columns are ordered (word group, lane, bit): group by four wave
+//                sums, lane by one inclusive scan, bit by a 64-way evaluation of the chosen lane's two words
+// No LDS, no masks, no rank arrays.  The first step of a walk (no prev: every neighbour weighs 1) is the same decision
+// with an empty prev row.  A walk that meets a step this kernel does not settle (not decisive, r == 0, weights beyond
+// the exact range) is put on the redo list and walked again, from its start, by walk_dense_bits_kernel.
+// (Register budget: left to the compiler -- 211 VGPRs at WPL = 25, two wavefronts per SIMD.  Forcing three (168) or four
+// (128) spills in the step loop: 77 / 57 M steps/s against 373 at ER-100k.  At 373 M steps/s x 12.5 KB per row the kernel
+// moves 4.7 TB/s, three quarters of the achievable HBM rate.)
+template <int WPL>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
+walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *redo_count, uint32_t redo_every) {
+    constexpr int NSEG = (WPL + 3) / 4;   // a segment = DQW 64-bit words = 4 words per lane
+    static_assert(DQW / WAVE == 4, "segment = four words per lane");
+    const int lane = lane_id();
+    const uint32_t L = a.L, n = a.n, wpr = a.wpr;
+    const uint64_t W = (uint64_t)L + 2;
+    const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
+    const double w_outq = 1.0 / a.q, w_prevp = 1.0 / a.p;
+    unsigned long long st_steps = 0, st_dead = 0;
+
+    for (;;) {
+        unsigned long long widx = 0;
+        if (lane == 0) widx = atomicAdd(a.job_counter, 1ull);
+        widx = readfirst_u64(widx);
+        if (widx >= n_work) break;
+        const uint64_t job = a.job_list ? (uint64_t)uni(a.job_list[widx]) : (uint64_t)widx;
+        uint32_t *row = a.out + job * W;
+        const uint32_t start = uni(a.starts[job]);
+        const uint64_t soff = readfirst_u64(a.stream_off[job]) - a.rng_base;
+        uint32_t cur = start, prev = 0;
+        uint32_t len_out = L + 1;
+        double rbuf = 0.0;
+        uint64_t keep[WPL];   // row of the vertex the walk was at one step ago (word i * 64 + lane)
+        uint64_t cws[WPL];    // row of cur
+#pragma unroll
+        for (int i = 0; i < WPL; i++) keep[i] = 0ull;
+        bool redo = false, dead = false;
+        uint32_t j = 1;
+        for (; j <= L; j++) {
+            const uint32_t d = uni(a.deg[cur]);
+            if (d == 0) { len_out = j; dead = j > 1; break; }
+            const uint32_t jr = (j - 1) & (WAVE - 1);
+            if (jr == 0) {
+                const uint32_t idx = (j - 1) + (uint32_t)lane;
+                rbuf = idx < L ? a.rng[soff + idx] : 0.0;
+            }
+            const double r = readlane_f64(rbuf, (int)jr);
+            const bool has_prev = j >= 2;
+            const uint64_t *__restrict__ crow = a.adjbits + (uint64_t)cur * wpr;
+#pragma unroll
+            for (int i = 0; i < WPL; i++) {   // every load of the row in flight at once
+                const uint32_t w = (uint32_t)i * WAVE + lane;
+                cws[i] = w < wpr ? crow[w] : 0ull;
+            }
+            uint32_t n_pv = 0;
+            if (has_prev) n_pv = (uint32_t)((uni(crow[prev >> 6]) >> (prev & 63)) & 1ull);
+            // count pass (keep == 0 at the first step: everything is "out")
+            uint32_t pks[NSEG];
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) pks[sg] = 0;
+#pragma unroll
+            for (int i = 0; i < WPL; i++) {
+                const uint32_t w = (uint32_t)i * WAVE + lane;
+                uint64_t cw = cws[i];
+                if (has_prev && (prev >> 6) == w) cw &= ~(1ull << (prev & 63));   // prev forms its own class
+                const uint32_t ci = (uint32_t)__popcll(cw & keep[i]);
+                pks[i / 4] += ci | (((uint32_t)__popcll(cw) - ci) << 16);           // (<= 256 per lane and class)
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) pks[sg] += (uint32_t)__shfl_xor((int)pks[sg], off, WAVE);
+            }
+            uint32_t n_in = 0, n_out = 0;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) {
+                pks[sg] = uni(pks[sg]);
+                n_in += pks[sg] & 0xffffu;
+                n_out += pks[sg] >> 16;
+            }
+            const uint32_t prev_col = n_pv ? prev : NOT_FOUND;
+            const double w_out = has_prev ? w_outq : 1.0;
+            // exact total and the exact-arithmetic decision (see walk_dense_bits_kernel)
+            double u = 1.0;
+            if (n_out && w_out < u) u = w_out;
+            if (n_pv && w_prevp < u) u = w_prevp;
+            const double td = (double)n_in + (double)n_out * w_out + (double)n_pv * w_prevp;
+            const double S = td / u, wi = 1.0 / u, wo = w_out / u, wp = w_prevp / u;   // exact: powers of two
+            const double wmax = fmax(wi, fmax(wo, wp)) + 2.0;
+            bool ok = (n_out == 0 || is_pow2_fp<double>(w_out)) && (n_pv == 0 || is_pow2_fp<double>(w_prevp)) &&
+                      n_in + n_out + n_pv == d && S <= 1099511627776.0 && wmax <= 1048576.0 && r > 0.0;
+            uint32_t nxt = NOT_FOUND;
+            uint64_t lo_th = 0, hi_th = 0, Wi = 0, Wo = 0, Wp = 0, e0 = 0;
+            uint32_t sx = NOT_FOUND;
+            const uint32_t pw_word = prev_col != NOT_FOUND ? (prev >> 6) : NOT_FOUND;   // word of prev's own class
+            if (ok) {
+                const ExactThresholds64 th = exact_thresholds_f64(r * S, (double)d, wmax - 2.0);
+                lo_th = th.lo; hi_th = th.hi;
+                Wi = (uint64_t)wi; Wo = (uint64_t)wo; Wp = (uint64_t)wp;
+                const uint32_t pseg = pw_word != NOT_FOUND ? pw_word / DQW : NOT_FOUND;
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) {
+                    if (sx == NOT_FOUND) {
+                        const uint64_t e1 = e0 + (uint64_t)(pks[sg] & 0xffffu) * Wi + (uint64_t)(pks[sg] >> 16) * Wo +
+                                            (pseg == (uint32_t)sg ? Wp : 0ull);
+                        if (e1 >= lo_th) sx = (uint32_t)sg; else e0 = e1;
+                    }
+                }
+            }
+            // the eight words of the target segment; then the row of cur BECOMES the prev row of the next step: from here
+            // on one copy of a row is live (the search works on the words just taken out)
+            uint64_t c4[4] = {0, 0, 0, 0}, p4[4] = {0, 0, 0, 0};
+            {
+#define PW_DSEG(SG)                                                                  \
+    case SG:                                                                         \
+        _Pragma("unroll") for (int jj = 0; jj < 4; jj++) {                           \
+            if (4 * SG + jj < WPL) { c4[jj] = cws[4 * SG + jj < WPL ? 4 * SG + jj : 0]; p4[jj] = keep[4 * SG + jj < WPL ? 4 * SG + jj : 0]; } \
+        }                                                                            \
+        break;
+                    switch (sx) { PW_DSEG(0) PW_DSEG(1) PW_DSEG(2) PW_DSEG(3) PW_DSEG(4) PW_DSEG(5) PW_DSEG(6) PW_DSEG(7) default: break; }
+#undef PW_DSEG
+            }
+#pragma unroll
+            for (int i = 0; i < WPL; i++) keep[i] = cws[i];
+            if (sx != NOT_FOUND) {
+                {
+                    uint64_t in4[4], out4[4];
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const uint32_t w = (4u * sx + (uint32_t)jj) * WAVE + (uint32_t)lane;
+                        uint64_t cw = c4[jj];
+                        if (has_prev && (prev >> 6) == w) cw &= ~(1ull << (prev & 63));
+                        in4[jj] = cw & p4[jj];
+                        out4[jj] = cw & ~p4[jj];
+                        pk[jj] = (uint32_t)__popcll(in4[jj]) | ((uint32_t)__popcll(out4[jj]) << 16);
+                    }
+                    uint32_t sm4[4] = {pk[0], pk[1], pk[2], pk[3]};   // four independent wave sums, interleaved
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) sm4[jj] += (uint32_t)__shfl_xor((int)sm4[jj], off, WAVE);
+                    }
+                    uint64_t in_s = 0, out_s = 0, eg = e0;
+                    uint32_t pk_s = 0, g_sel = NOT_FOUND;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        if (g_sel == NOT_FOUND) {   // (wave uniform)
+                            const uint32_t sm = uni(sm4[jj]);
+                            const uint32_t grp = 4u * sx + (uint32_t)jj;
+                            const uint64_t e_next = eg + (uint64_t)(sm & 0xffffu) * Wi + (uint64_t)(sm >> 16) * Wo +
+                                                    ((pw_word != NOT_FOUND && (pw_word >> 6) == grp) ? Wp : 0ull);
+                            if (e_next >= lo_th) { g_sel = grp; in_s = in4[jj]; out_s = out4[jj]; pk_s = pk[jj]; }
+                            else eg = e_next;
+                        }
+                    }
+                    if (g_sel != NOT_FOUND) {
+                        uint32_t incl = pk_s;   // inclusive scan over the lanes (the halves cannot carry: sums <= 4096)
+#pragma unroll
+                        for (int off = 1; off < WAVE; off <<= 1) {
+                            const uint32_t y = (uint32_t)__shfl_up((int)incl, (unsigned)off, WAVE);
+                            if (lane >= off) incl += y;
+                        }
+                        const bool pv_here = pw_word != NOT_FOUND && (pw_word >> 6) == g_sel;
+                        const uint32_t pv_lane = pw_word & 63u;
+                        const uint64_t G = eg + (uint64_t)(incl & 0xffffu) * Wi + (uint64_t)(incl >> 16) * Wo +
+                                           ((pv_here && pv_lane <= (uint32_t)lane) ? Wp : 0ull);
+                        const uint64_t hm = ballot(G >= lo_th);
+                        if (hm) {
+                            const int l = __builtin_ctzll(hm);
+                            const uint32_t pk_l = readlane_u32(pk_s, l);
+                            const bool pv_word = pv_here && pv_lane == (uint32_t)l;
+                            const uint64_t e2 = readlane_u64(G, l) -
+                                                ((uint64_t)(pk_l & 0xffffu) * Wi + (uint64_t)(pk_l >> 16) * Wo + (pv_word ? Wp : 0ull));
+                            const uint64_t inw = readlane_u64(in_s, l), outw = readlane_u64(out_s, l);
+                            const uint64_t mb = lane == WAVE - 1 ? ~0ull : ((2ull << lane) - 1ull);   // bits 0 .. lane
+                            const uint64_t Gb = e2 + (uint64_t)__popcll(inw & mb) * Wi + (uint64_t)__popcll(outw & mb) * Wo +
+                                                ((pv_word && (prev & 63u) <= (uint32_t)lane) ? Wp : 0ull);
+                            const uint64_t hb = ballot(Gb >= lo_th);
+                            if (hb) {
+                                const int b = __builtin_ctzll(hb);
+                                if (readlane_u64(Gb, b) >= hi_th) nxt = (g_sel * WAVE + (uint32_t)l) * 64u + (uint32_t)b;   // decisive
+                            }
+                        }
+                    }
+                }
+            }
+            if (nxt == NOT_FOUND || nxt >= n) { redo = true; break; }
+            if (redo_every && j == 3 && job % redo_every == 0) { redo = true; break; }   // (test switch: exercises the hand-over)
+            if (lane == 0) row[j] = nxt;
+            prev = cur;
+            cur = nxt;
+        }
+        if (redo) {   // walk_dense_bits_kernel walks this job again (and writes the whole row)
+            if (lane == 0) redo_list[atomicAdd(redo_count, 1ull)] = (uint32_t)job;
+            continue;
+        }
+        st_steps += (unsigned long long)(j <= L ? j - 1 : L);
+        if (dead) st_dead++;
+        if (lane == 0) { row[0] = start; row[L + 1] = len_out; }
+        for (uint32_t z = j + lane; z <= L; z += WAVE) row[z] = 0;
+    }
+    if (lane == 0) {
+        if (st_steps) atomicAdd(&a.stats[0], st_steps);
+        if (st_dead) atomicAdd(&a.stats[3], st_dead);
+    }
+}
+
 // degrees from the packed rows (one wavefront per row)
 __global__ void __launch_bounds__(256)
 dense_degree_kernel(const uint64_t *__restrict__ adjbits, uint32_t n, uint32_t wpr, uint32_t *deg) {

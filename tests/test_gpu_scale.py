@@ -267,3 +267,32 @@ def test_c4_density_oracle_prefix_on_a_20k_slice():
     want = orc.walks_dense_otf(mat, 0.5, 2, starts, 40, 5, nonzero=adj.astype(bool))
     got = eng.simulate("DenseOTF", 0.5, 2, False, starts, 40, seed=5)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,density", [(9000, 0.05), (40000, 0.02), (70000, 0.01), (110000, 0.006)])
+def test_dense_fast_kernel_equals_the_complete_kernel(n, density, monkeypatch):
+    """walk_dense_fast_kernel (dyadic 1/p, 1/q: the exact decision alone, in registers) against walk_dense_bits_kernel
+    (the same decision + the float64 chain behind it) on rows of 141 / 625 / 1094 / 1719 words -- the four register
+    widths the kernel is instantiated for -- at three (p, q); then with every 7th walk handed over to the complete
+    kernel at its third step (PECANPY_AMD_DENSE_REDO_TEST): the hand-over rewrites the whole row."""
+    import torch
+
+    bits, deg = _er_bits(n, density, seed=4)
+    eng = WalkEngine.from_dense_bits(bits, n)
+    starts = np.arange(n, dtype=np.uint32)[: 30000]
+    np.random.RandomState(2).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    for p, q in ((0.5, 2.0), (4.0, 0.25), (1.0, 1.0)):
+        fast = eng.simulate_device("DenseOTF", p, q, False, d_starts, 40, seed=3)
+        st = dict(eng.last_stats)
+        monkeypatch.setenv("PECANPY_AMD_DENSE_NO_FAST", "1")
+        full = eng.simulate_device("DenseOTF", p, q, False, d_starts, 40, seed=3)
+        assert eng.last_stats["total_steps"] == st["total_steps"]
+        monkeypatch.delenv("PECANPY_AMD_DENSE_NO_FAST")
+        assert torch.equal(fast, full), (n, p, q)
+        assert st["redo_walks"] <= 2, st                              # (the decision is decisive for all but ~1e-8 of the steps)
+    monkeypatch.setenv("PECANPY_AMD_DENSE_REDO_TEST", "7")
+    mixed = eng.simulate_device("DenseOTF", 1.0, 1.0, False, d_starts, 40, seed=3)
+    assert eng.last_stats["redo_walks"] >= starts.size // 7
+    assert eng.last_stats["total_steps"] == st["total_steps"]
+    assert torch.equal(mixed, full)
