@@ -303,6 +303,39 @@ PW_HD SearchResult list_search(const ListView &cl, uint32_t lo_min, uint32_t n, 
     return r;
 }
 
+// The same search with THREE probes per level (the range is cut into quarters): half the DEPENDENT memory round trips
+// of the bisection for 1.5x its probes.  For the float chains (lane_chain): a chain is ~17 binades x one search each,
+// every probe a scattered load the next one waits for -- latency, not bandwidth, is what a chain costs.  Same result
+// as list_search, field by field.
+template <class Eval>
+PW_HD SearchResult list_search_wide(const ListView &cl, uint32_t lo_min, uint32_t n, const Eval &ev, uint64_t target, uint32_t &reads) {
+    SearchResult r;
+    r.p_below = 0; r.v_below = 0; r.has_below = false; r.p_at = 0xffffffffu; r.v_at = 0;
+    uint32_t lo = lo_min, hi = n;   // invariants: below = entry lo - 1 (when has_below), at = entry hi (when hi < n)
+    while (hi - lo >= 3u && hi > lo) {
+        const uint32_t m2 = lo + ((hi - lo) >> 1);
+        const uint32_t m1 = lo + ((m2 - lo) >> 1);
+        const uint32_t m3 = m2 + 1u + ((hi - m2 - 1u) >> 1);
+        const uint32_t P1 = cl.at(m1), P2 = cl.at(m2), P3 = cl.at(m3);   // (independent loads: in flight together)
+        reads += 3;
+        const uint64_t v1 = ev(m1, P1), v2 = ev(m2, P2), v3 = ev(m3, P3);
+        if (v1 >= target) { hi = m1; r.p_at = P1; r.v_at = v1; }
+        else if (v2 >= target) { lo = m1 + 1u; r.p_below = P1; r.v_below = v1; r.has_below = true; hi = m2; r.p_at = P2; r.v_at = v2; }
+        else if (v3 >= target) { lo = m2 + 1u; r.p_below = P2; r.v_below = v2; r.has_below = true; hi = m3; r.p_at = P3; r.v_at = v3; }
+        else { lo = m3 + 1u; r.p_below = P3; r.v_below = v3; r.has_below = true; }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t P = cl.at(mid);
+        reads++;
+        const uint64_t v = ev(mid, P);
+        if (v >= target) { hi = mid; r.p_at = P; r.v_at = v; }
+        else { lo = mid + 1u; r.p_below = P; r.v_below = v; r.has_below = true; }
+    }
+    r.f = lo;
+    return r;
+}
+
 // ---- the exact decision evaluated by ONE thread from the positions of the common neighbours (lane kernel) ------
 // Row of d neighbours; cl[0..n_in) = ascending positions of the common neighbours of prev and cur ("in", weight
 // 1), pp = position of prev (weight w_prev; 0xffffffff: prev is not a neighbour), everything else "out" (weight
@@ -555,7 +588,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         // first common neighbour in [k, lim) whose partial sum reaches Tt; the run of "out" neighbours before it
         // starts at s_run with partial sum `base`
         const ChainEval ev{C, ii, io, k, i0, lim};
-        const SearchResult sr = list_search(cl, i0, n_in, ev, Tt, reads);
+        const SearchResult sr = list_search_wide(cl, i0, n_in, ev, Tt, reads);
         const uint32_t lo = sr.f;
         uint32_t s_run = k, p_f = 0xffffffffu;
         uint64_t base = C, g_f = 0;

@@ -522,9 +522,10 @@ walk_dense_bits_kernel(DenseArgs a) {
 // with an empty prev row.  A walk that meets a step this kernel does not settle (not decisive, r == 0, weights beyond
 // the exact range) is put on the redo list and walked again, from its start, by walk_dense_bits_kernel.
 // (Register budget: left to the compiler -- 211 VGPRs at WPL = 25, two wavefronts per SIMD.  Forcing three (168) or four
-// (128) spills in the step loop: 77 / 57 M steps/s against 373 at ER-100k.  At 373 M steps/s x 12.5 KB per row the kernel
-// moves 4.7 TB/s, three quarters of the achievable HBM rate.)
-template <int WPL>
+// (128) spills in the step loop: 199 / 57 M steps/s against 396 at ER-100k.  At 396 M steps/s x 12.5 KB per row the kernel
+// moves 5 TB/s, four fifths of the achievable HBM rate.)
+// FULL: the first FULL word groups lie inside every row this instantiation is launched for (wpr > 64 * FULL): no bounds test.
+template <int WPL, int FULL>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
 walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *redo_count, uint32_t redo_every) {
     constexpr int NSEG = (WPL + 3) / 4;   // a segment = DQW 64-bit words = 4 words per lane
@@ -568,7 +569,7 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
 #pragma unroll
             for (int i = 0; i < WPL; i++) {   // every load of the row in flight at once
                 const uint32_t w = (uint32_t)i * WAVE + lane;
-                cws[i] = w < wpr ? crow[w] : 0ull;
+                cws[i] = (i < FULL || w < wpr) ? crow[w] : 0ull;
             }
             uint32_t n_pv = 0;
             if (has_prev) n_pv = (uint32_t)((uni(crow[prev >> 6]) >> (prev & 63)) & 1ull);
