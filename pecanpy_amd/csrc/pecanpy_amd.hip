@@ -12,6 +12,7 @@
 #include <new>
 #include <random>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <string>
 #include <thread>
@@ -1549,17 +1550,23 @@ static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t byt
             HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));   // no pinned memory: plain copy
             return 0;
         }
-    auto fan_out = [](char *to, const char *from, size_t n) {
-        const int T = 4;
-        std::thread th[T];
+    // (the destination is usually fresh pageable memory: the copy is bound by first-touch page faults per thread)
+    static const int T_env = getenv("PECANPY_AMD_COPY_THREADS") ? atoi(getenv("PECANPY_AMD_COPY_THREADS")) : 0;
+    const int T_use = T_env > 0 ? (T_env > 32 ? 32 : T_env) : 8;
+    auto fan_out = [T_use](char *to, const char *from, size_t n) {
+        const int T = T_use;
+        std::thread th[32];
         const size_t part = (n / T + 4095) & ~(size_t)4095;
         for (int t = 0; t < T; t++) {
             const size_t lo = (size_t)t * part, hi = lo + part < n ? lo + part : n;
             th[t] = std::thread([=]() { if (lo < hi) memcpy(to + lo, from + lo, hi - lo); });
         }
-        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++) th[t].join();
     };
     const size_t n_ch = (bytes + CH - 1) / CH;
+    const bool dbg = getenv("PECANPY_AMD_COPY_DEBUG") != nullptr;
+    double t_wait = 0, t_copy = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t c = 0; c <= n_ch; c++) {
         if (c < n_ch) {
             const size_t off = c * CH, len = off + CH < bytes ? CH : bytes - off;
@@ -1568,10 +1575,15 @@ static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t byt
         }
         if (c > 0) {
             const size_t off = (c - 1) * CH, len = off + CH < bytes ? CH : bytes - off;
+            const double t0 = now();
             HIP_TRY(hipEventSynchronize(g->ev[(c - 1) & 1 ? 5 : 4]));
+            const double t1 = now();
             fan_out((char *)dst + off, (const char *)g->stage[(c - 1) & 1], len);
+            t_wait += t1 - t0;
+            t_copy += now() - t1;
         }
     }
+    if (dbg) fprintf(stderr, "[copy_out] %.2f GB: waiting for DMA %.1f ms, host copies %.1f ms (%d threads)\n", bytes / 1e9, t_wait * 1e3, t_copy * 1e3, T_use);
     return 0;
 }
 
@@ -1582,17 +1594,26 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     if (set_device(g)) return PW_ERR_HIP;
     uint32_t *d_starts = nullptr, *d_out = nullptr;
     size_t out_elems = (size_t)n_jobs * ((size_t)walk_length + 2);
+    const bool dbg = getenv("PECANPY_AMD_COPY_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
     hipError_t e = hipMalloc((void **)&d_out, sizeof(uint32_t) * (out_elems ? out_elems : 1));
     if (e != hipSuccess) { (void)hipFree(d_starts); return fail(PW_ERR_NOMEM, hipGetErrorString(e)); }
     int rc = 0;
+    const double t1 = now();
     e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    const double t2 = now();
     if (!rc) rc = pw_simulate_device(g, mode, p, q, extend, d_starts, n_jobs, walk_length, has_seed, seed,
                                      stream_skip, d_out, stats);
+    const double t3 = now();
     if (!rc) rc = copy_out_staged(g, out, d_out, sizeof(uint32_t) * out_elems);
+    const double t4 = now();
     (void)hipFree(d_starts);
     (void)hipFree(d_out);
+    if (dbg) fprintf(stderr, "[pw_simulate] alloc %.1f ms, starts in %.1f, walks %.1f, matrix out %.1f, free %.1f\n", (t1 - t0) * 1e3,
+                     (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
     return rc;
 }
 
