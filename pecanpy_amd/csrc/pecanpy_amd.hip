@@ -1986,10 +1986,10 @@ PW_HD void lane_floats_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint32
 #else
     const double inf = INFINITY;
 #endif
-    uint32_t res = lane_chain(n, n_cl, pp, inf, 1.0f, w_out, w_prev, cl, reads, &rowsum);
+    uint32_t res = lane_chain<true>(n, n_cl, pp, inf, 1.0f, w_out, w_prev, cl, reads, &rowsum);
     *tot = rowsum;
     if (res != LANE_CHAIN_END) { *choice = res; return; }   // (LANE_TIE)
-    *choice = lane_chain(n, n_cl, pp, r, 1.0f / rowsum, w_out / rowsum, w_prev / rowsum, cl, reads);
+    *choice = lane_chain<true>(n, n_cl, pp, r, 1.0f / rowsum, w_out / rowsum, w_prev / rowsum, cl, reads);
 }
 
 __global__ void __launch_bounds__(256)

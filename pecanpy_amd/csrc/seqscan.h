@@ -304,9 +304,9 @@ PW_HD SearchResult list_search(const ListView &cl, uint32_t lo_min, uint32_t n, 
 }
 
 // The same search with THREE probes per level (the range is cut into quarters): half the DEPENDENT memory round trips
-// of the bisection for 1.5x its probes.  For the float chains (lane_chain): a chain is ~17 binades x one search each,
-// every probe a scattered load the next one waits for -- latency, not bandwidth, is what a chain costs.  Same result
-// as list_search, field by field.
+// of the bisection for 1.5x its probes.  For the float chains of the FLOATS lane kernel (lane_chain<true>): a chain is
+// ~17 binades x one search each, every probe a scattered load the next one waits for.  Same result as list_search,
+// field by field.
 template <class Eval>
 PW_HD SearchResult list_search_wide(const ListView &cl, uint32_t lo_min, uint32_t n, const Eval &ev, uint64_t target, uint32_t &reads) {
     SearchResult r;
@@ -453,6 +453,10 @@ struct ChainEval {   // partial sum (in ulps of the current binade) after common
 
 // c_end (optional): receives the float32 sum of the kend elements when no partial sum reaches r (LANE_CHAIN_END) -- with
 // r = +infinity the routine is the reference's sequential row total, w.sum() (src/pecanpy/rw/sparse_rw.py:89).
+// WIDE: the per-binade searches probe three entries per level (list_search_wide) -- for the FLOATS form of the lane
+// kernel, where every step is two chains and their dependent probes are what a step waits for (+5 %); the chain
+// kernels of the dyadic path run ~60 probes per chain at full occupancy and lose 3 % of a pass to the extra traffic.
+template <bool WIDE = false>
 PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
                           const ListView &cl, uint32_t &reads, float *c_end = nullptr) {
     using B = Binade<float>;
@@ -588,7 +592,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         // first common neighbour in [k, lim) whose partial sum reaches Tt; the run of "out" neighbours before it
         // starts at s_run with partial sum `base`
         const ChainEval ev{C, ii, io, k, i0, lim};
-        const SearchResult sr = list_search_wide(cl, i0, n_in, ev, Tt, reads);
+        const SearchResult sr = WIDE ? list_search_wide(cl, i0, n_in, ev, Tt, reads) : list_search(cl, i0, n_in, ev, Tt, reads);
         const uint32_t lo = sr.f;
         uint32_t s_run = k, p_f = 0xffffffffu;
         uint64_t base = C, g_f = 0;

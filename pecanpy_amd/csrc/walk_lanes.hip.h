@@ -377,7 +377,7 @@ walk_lanes_kernel(LanesArgs a) {
                 uint32_t res = LANE_CHAIN_END;
                 for (int phase = 0; phase < 2 && res == LANE_CHAIN_END; phase++) {   // (one inlined copy of the chain)
                     uint32_t reads = 0;
-                    res = lane_chain(A.d, A.n_in, A.pp, target, xi, xo, xp, cl, reads, &rowsum);
+                    res = lane_chain<true>(A.d, A.n_in, A.pp, target, xi, xo, xp, cl, reads, &rowsum);
                     n_probes += reads;
                     if (phase == 0 && res == LANE_CHAIN_END) {   // tot known: the normalised values, float32 / float32
                         xi = 1.0f / rowsum; xo = wo / rowsum; xp = w_prev / rowsum;
