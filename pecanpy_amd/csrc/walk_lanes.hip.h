@@ -754,7 +754,9 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
             const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
             const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
-            if (mine && d_k) {
+            // single-segment rows: the COUNT pass already wrote the lists that fit their lines (below) -- nothing to fill
+            const bool done = FILL && nseg == 1 && r0.y <= EL_INLINE;
+            if (mine && d_k && !done) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
                     lo_i = lower_bound_u32(a.indices + s_k, d_k, id_lo);
@@ -766,6 +768,14 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                         uint32_t cnt = 0;
                         uint8_t *p2 = nullptr, *p1 = nullptr;
                         bool k_narrow = true;
+                        // COUNT pass, single-segment row (both rows <= 8192 entries: uint16 positions): the first
+                        // EL_INLINE matches go into the two lines right away; if the list turns out longer the line's
+                        // inline area is simply not used (the list then lives in the overflow array: FILL pass)
+                        const bool spec = !FILL && nseg == 1;
+                        if (spec) {
+                            p2 = (uint8_t *)(a.lines + e2) + 24;
+                            if (rev != NOT_FOUND) p1 = (uint8_t *)(a.lines + (s_k + rev)) + 24;
+                        }
                         if (FILL) {
                             if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) cnt += a.segcnt[it.m0 + j * nseg + sg];
                             k_narrow = list_is_narrow(d_k);
@@ -783,6 +793,9 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                                 if (FILL) {
                                     if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
                                     if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
+                                } else if (spec && cnt < EL_INLINE) {
+                                    ((uint16_t *)p2)[cnt] = (uint16_t)i;
+                                    if (p1) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx);
                                 }
                                 cnt++;
                             }
@@ -818,6 +831,11 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             uint32_t run = 0;
             uint8_t *p2 = nullptr, *p1 = nullptr;
             bool k_narrow = true;
+            const bool spec = !FILL && nseg == 1;   // (as above: lists that fit their lines are written by the COUNT pass)
+            if (spec) {
+                p2 = (uint8_t *)(a.lines + e2) + 24;
+                if (rev != NOT_FOUND) p1 = (uint8_t *)(a.lines + (s_k + rev)) + 24;
+            }
             if (FILL) {
                 if (nseg > 1) for (uint32_t sg = 0; sg < it.seg; sg++) run += a.segcnt[it.m0 + jq * nseg + sg];
                 k_narrow = list_is_narrow(d_k);
@@ -839,6 +857,12 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                     const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
                     if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
                     if (p1) { if (h_narrow) ((uint16_t *)p1)[rk] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[rk] = a0 + idx; }
+                } else if (spec && hit) {
+                    const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
+                    if (rk < EL_INLINE) {
+                        ((uint16_t *)p2)[rk] = (uint16_t)i;
+                        if (p1) ((uint16_t *)p1)[rk] = (uint16_t)(a0 + idx);
+                    }
                 }
                 run += (uint32_t)__popcll(m);
             }
