@@ -156,7 +156,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from pecanpy_amd.engine import WalkEngine, shard_bounds
+    from pecanpy_amd.engine import WalkEngine, shard_bounds, tapered_bounds
     from pecanpy_amd.synth import rmat_csr
 
     cfg = dict(CONFIGS[args.config])
@@ -220,7 +220,7 @@ def main():
     # N > 1 with gather: the shard is walked in a few chunks and the gather of chunk c (async, on RCCL's
     # stream) overlaps the walk kernel of chunk c + 1; --gather-chunks 1 = one blocking gather at the end
     n_chunks = max(1, args.gather_chunks) if do_gather else 1
-    chunk_bounds = shard_bounds(hi - lo, n_chunks)
+    chunk_bounds = tapered_bounds(hi - lo, n_chunks)   # decreasing sizes: the exposed tail is the smallest chunk's transfer
     csum = np.concatenate([[0], np.cumsum(has_nbr[starts[lo:hi]], dtype=np.int64)])
     chunk_skip = [skip + int(csum[a]) * L for a, _ in chunk_bounds]
     # The gather (N > 1): ONE preallocated [n_jobs, L + 2] matrix on rank 0; every chunk of every other rank's shard is
@@ -242,7 +242,7 @@ def main():
         d_out = gather.own_rows()
     else:
         d_out = torch.empty((hi - lo, L + 2), dtype=torch.int32, device=dev)
-    chunk_of = [shard_bounds(b[1] - b[0], n_chunks) for b in all_bounds]
+    chunk_of = [tapered_bounds(b[1] - b[0], n_chunks) for b in all_bounds]
 
     acc = {k: [] for k in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "total_steps", "list_entries_read",
                            "ambiguous_steps", "wave_chain_steps", "redo_walks", "overflow_reads")}

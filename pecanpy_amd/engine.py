@@ -26,6 +26,20 @@ def shard_bounds(n_jobs, world_size):
     return [((r * n_jobs) // world_size, ((r + 1) * n_jobs) // world_size) for r in range(world_size)]
 
 
+def tapered_bounds(n_jobs, n_chunks):
+    """Contiguous ranges [lo, hi) of decreasing size (weights n_chunks, n_chunks - 1, ..., 1): a shard walked in such
+    chunks, each travelling to rank 0 while the next is walked, leaves only its SMALLEST chunk's transfer exposed at the
+    end of the pass (4 chunks: 10 % of the shard instead of 25 %)."""
+    n_chunks = max(1, int(n_chunks))
+    total = n_chunks * (n_chunks + 1) // 2
+    cuts = [0]
+    acc = 0
+    for c in range(n_chunks):
+        acc += n_chunks - c
+        cuts.append((acc * n_jobs) // total)
+    return [(cuts[c], cuts[c + 1]) for c in range(n_chunks)]
+
+
 class WalkEngine:
     def __init__(self, handle, lib, kind, n_nodes, device):
         self._h = handle

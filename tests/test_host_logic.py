@@ -222,3 +222,18 @@ def test_holme_kim_bipartite_hubs_and_gnm_are_well_formed():
     assert (deg[:5] == 700).all() and (indices[indptr[0]:indptr[5]] >= 5).all()   # hubs only see leaves: no triangles
     deg = _check_undirected_csr(*gnm_csr(5000, 20000, seed=2))
     assert abs(deg.mean() - 8.0) < 0.2
+
+
+def test_tapered_bounds_cover_the_shard_in_decreasing_chunks():
+    from pecanpy_amd.engine import tapered_bounds
+
+    for n in (0, 1, 7, 1000, 5242880, 41943040 // 8):
+        for k in (1, 2, 4, 8):
+            b = tapered_bounds(n, k)
+            assert len(b) == k and b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(k - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert all(s >= 0 for s in sizes)
+            if n >= 1000:
+                assert all(sizes[i] >= sizes[i + 1] for i in range(k - 1))
+                assert sizes[-1] <= n * 2 // (k * (k + 1)) + 1          # the tail is 2 / (k (k + 1)) of the shard
