@@ -11,7 +11,11 @@
 // binade chain as the sparse unit path (seqscan.h, walk_sparse.hip.h: unit_chain) over the columns
 // of a 16384-column segment at a time, class counts coming from prefix popcounts (rank arrays) of
 // the two masks in LDS.  The sampled element is directly the next vertex (a column index).
-// HBM per step: 2 rows x N/8 bytes (x2 when the row is re-read for the search) instead of ~10 N bytes.
+// Two kernels: walk_dense_fast_kernel (dyadic 1/p, 1/q, rows <= 131072 columns: the exact-arithmetic decision alone,
+// entirely in registers, ONE row read per step -- the row of cur is kept as the next step's prev row) and
+// walk_dense_bits_kernel (the complete step: the same decision + the float64 chain behind it; any p, q, any width; also
+// walks the jobs the fast kernel hands over).  HBM per step: N/8 bytes (fast) .. 3 N/8 (complete, wide rows) instead of
+// ~10 N bytes.
 #pragma once
 #include "walk_sparse.hip.h"
 
