@@ -141,7 +141,9 @@ def _gather_worker(rank, world, port, ret):
     dev = torch.device("cpu")
     rg = RowGather(n_jobs, L + 2, bounds, torch.int32, dev, dst=0, known=~has, fill_known=isolated_row_filler(starts, L, dev))
     lo, hi = bounds[rank]
-    chunks = [(lo + a, lo + b) for a, b in shard_bounds(hi - lo, n_chunks)]
+    from pecanpy_amd.engine import tapered_bounds   # (bench.py's chunking: decreasing sizes)
+
+    chunks = [(lo + a, lo + b) for a, b in tapered_bounds(hi - lo, n_chunks)]
     for c in range(n_chunks):
         a, b = chunks[c]
         skip = int(has[:a].sum()) * L
@@ -149,8 +151,8 @@ def _gather_worker(rank, world, port, ret):
         rows = torch.from_numpy(mat.view(np.int32).copy())
         if rank == 0:
             rg.full[a:b] = rows                  # (the walk kernel writes rank 0's rows in place)
-            rg.expect([(bounds[r][0] + shard_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][0],
-                        bounds[r][0] + shard_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][1], r) for r in range(1, world)])
+            rg.expect([(bounds[r][0] + tapered_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][0],
+                        bounds[r][0] + tapered_bounds(bounds[r][1] - bounds[r][0], n_chunks)[c][1], r) for r in range(1, world)])
         else:
             rg.post(a, b, rows)
     full = rg.finish()
