@@ -69,7 +69,9 @@ typedef struct {
     uint32_t lane_kernel;       /* 1: the call ran on the lane kernel; 2: on its float-chain form (1/p or 1/q not a power of two) */
     uint32_t lane_rounds;       /* lane kernel launches of the call: walks whose step needs the float32 chain are parked,
                                    the chains of a whole queue run in one launch, the next round resumes the walks */
-    uint64_t redo_walks;        /* walks the lane kernel handed to the wave-per-walk kernel (overflow reads, ...) */
+    uint64_t redo_walks;        /* walks a fast kernel handed to the complete one: lane kernel -> wave-per-walk kernel
+                                   (tie budget, rows outside the exact range, overflow reads without a line), register-only
+                                   dense kernel -> column-space kernel with the float64 chain (undecided steps) */
     uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
     uint64_t ambiguous_steps;   /* steps the a-priori rounding bound left open (settled by the interval decision or the chain) */
     double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
