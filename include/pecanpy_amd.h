@@ -72,7 +72,8 @@ typedef struct {
     uint64_t redo_walks;        /* walks a fast kernel handed to the complete one: lane kernel -> wave-per-walk kernel
                                    (tie budget, rows outside the exact range, overflow reads without a line), register-only
                                    dense kernel -> column-space kernel with the float64 chain (undecided steps) */
-    uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (4 bytes each) */
+    uint64_t list_entries_read; /* common-neighbour list entries the lane kernel read (uint16 positions: 2 bytes each; uint32 for
+                                   rows of more than 65536 entries) */
     uint64_t ambiguous_steps;   /* steps the a-priori rounding bound left open (settled by the interval decision or the chain) */
     double lane_kernel_ms;      /* HIP-event time of the lane kernel launches alone */
     uint64_t wave_chain_steps;  /* of the ambiguous steps, those that needed the float32 chain itself */
@@ -203,6 +204,11 @@ int pw_sgns_train(int device, const uint32_t *walks, uint64_t n_walks, uint32_t 
 /* ---- random stream service (host side; usable without a GPU) ---------------------------- */
 /* doubles #offset.. of RandomState(seed).random_sample, produced with MT19937 jump-ahead. */
 int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out);
+
+/* Test hook: the same doubles as the DEVICE produces them for a walk call (jump-ahead tree + expansion kernels on the
+ * handle's GPU), copied to the host -- lets the tests compare the device stream with pw_mt_random_sample / NumPy at
+ * the offsets the last shards of a multi-GPU run start from. */
+int pw_stream_sample_device(pw_graph *g, uint32_t seed, uint64_t offset, uint64_t n, double *out);
 
 /* ---- node2vec+ noisy-edge thresholds (host side; usable without a GPU) --------------------- */
 /* thr[i] = max(mean(row i) + gamma * std(row i), 0) exactly as the reference's NumPy expression evaluates it

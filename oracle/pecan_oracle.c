@@ -326,6 +326,72 @@ ORC_API int orc_walks_dense_otf(const double *data, const uint8_t *nonzero, uint
     return 0;
 }
 
+/* DenseOTF walks over an UNWEIGHTED dense graph given as bit-packed adjacency rows (bit x of word
+ * x / 64 of row i set <=> data[i][x] == 1.0, nonzero[i][x] == True): the same statements as
+ * orc_dense_probs_impl / orc_walks_dense_otf above (dense_rw.py:34-72, pecanpy.py:597-612) with the
+ * float64 row never materialised -- every stored value is 1.0, so w[x] is 1.0, 1.0 / q (x a neighbour of
+ * cur but not of prev, x != prev) or 1.0 / p (x == prev), in ascending column order.  Exists so that the
+ * BASELINE C4 shape (N = 100 000, density 0.25: 80 GB as float64) can be checked on the host; pinned to
+ * the dense goldens through the float64 entry (tests/test_oracle_golden.py packs their matrices). */
+ORC_API int orc_walks_dense_otf_bits(const uint64_t *bits, uint32_t n, uint32_t wpr, double p, double q,
+                                     const uint32_t *starts, uint64_t n_jobs, uint32_t L, uint32_t seed,
+                                     uint64_t stream_skip, uint32_t *out, orc_stats_t *stats) {
+    orc_stats_t st = {0, 0, 0};
+    double *pr = (double *)malloc(sizeof(double) * (n + 1));
+    uint32_t *cols = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    orc_mt_t rng;
+    orc_mt_seed(&rng, seed);
+    for (uint64_t s = 0; s < stream_skip; s++) (void)orc_mt_random(&rng);
+    const uint64_t W = (uint64_t)L + 2;
+    for (uint64_t i = 0; i < n_jobs; i++) {
+        uint32_t *row = out + i * W;
+        memset(row, 0, sizeof(uint32_t) * W);
+        row[0] = starts[i];
+        row[L + 1] = L + 1;
+        for (uint32_t j = 1; j <= L; j++) {
+            uint32_t cur = row[j - 1];
+            const uint64_t *mc = bits + (uint64_t)cur * wpr;
+            const int has_prev = j >= 2;
+            const uint32_t prev = has_prev ? row[j - 2] : 0;
+            const uint64_t *mp = bits + (uint64_t)prev * wpr;
+            uint32_t d = 0;
+            for (uint32_t wd = 0; wd < wpr; wd++) {
+                uint64_t m = mc[wd];
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t x = wd * 64u + b;
+                    if (x >= n) continue;
+                    double w = 1.0;                                     /* copy of data[cur], dense_rw.py:57 */
+                    if (has_prev) {
+                        if (!((mp[wd] >> b) & 1ull) && x != prev) w /= q;  /* :63-66 */
+                        if (x == prev) w /= p;                          /* :67 */
+                    }
+                    pr[d] = w;
+                    cols[d] = x;
+                    d++;
+                }
+            }
+            if (d == 0) { row[L + 1] = j; break; }                      /* has_nbrs, dense_rw.py:21-32 */
+            double tot = 0.0;
+            for (uint32_t k = 0; k < d; k++) tot += pr[k];
+            double r = orc_mt_random(&rng);
+            double c = 0.0;
+            uint32_t choice = d;
+            for (uint32_t k = 0; k < d; k++) {
+                c += pr[k] / tot;
+                if (c >= r) { choice = k; break; }
+            }
+            if (choice >= d) { st.overflow_reads++; st.clamped_reads++; choice = d - 1; }
+            row[j] = cols[choice];
+            st.total_steps++;
+        }
+    }
+    free(pr); free(cols);
+    if (stats) *stats = st;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Alias tables (PreComp / PreCompFirstOrder) and first-order modes                           */
 /* ------------------------------------------------------------------------------------------ */

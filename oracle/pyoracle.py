@@ -136,6 +136,32 @@ def walks_dense_otf(data, p, q, starts, walk_length, seed, thr=None, nonzero=Non
     return (out, st) if return_stats else out
 
 
+def pack_adjacency(nonzero):
+    """bool[N, N] -> uint64[N, ceil(N / 64)], bit x of word x // 64 = column x (little-endian bit order)."""
+    nz = np.ascontiguousarray(nonzero, dtype=bool)
+    n = nz.shape[0]
+    wpr = (n + 63) // 64
+    pad = np.zeros((n, wpr * 64), dtype=np.uint8)
+    pad[:, :n] = nz
+    return np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n, wpr)
+
+
+def walks_dense_otf_bits(bits, n, p, q, starts, walk_length, seed, stream_skip=0, return_stats=False):
+    """DenseOTF on an UNWEIGHTED dense graph held as bit-packed adjacency rows (pecanpy.py:597-612 +
+    dense_rw.py:34-72 with every stored value 1.0): the BASELINE C4 shape without the 80 GB float64 matrix."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    assert bits.ndim == 2 and bits.shape[0] == n and bits.shape[1] * 64 >= n
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    out = np.zeros((starts.size, walk_length + 2), dtype=np.uint32)
+    st = Stats()
+    lib().orc_walks_dense_otf_bits(
+        _ptr(bits, C.c_uint64), C.c_uint32(n), C.c_uint32(bits.shape[1]), C.c_double(p), C.c_double(q),
+        _ptr(starts, C.c_uint32), C.c_uint64(starts.size), C.c_uint32(walk_length), C.c_uint32(seed),
+        C.c_uint64(stream_skip), _ptr(out, C.c_uint32), C.byref(st),
+    )
+    return (out, st) if return_stats else out
+
+
 def precomp_tables(indptr, indices, data, p, q, thr=None):
     """PreComp.preprocess_transition_probs (pecanpy.py:442-507)."""
     indptr, indices, data = _csr(indptr, indices, data)

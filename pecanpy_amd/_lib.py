@@ -80,6 +80,7 @@ SYMBOLS = {
     "pw_sgns_train": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pw_mt_random_sample": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pw_stream_sample_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pw_noise_thresholds_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
     "pw_noise_thresholds_csr_numpy1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),
     "pw_noise_thresholds_dense": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]),

@@ -115,6 +115,7 @@ struct pw_graph {
     hipEvent_t ev_side = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *stage[2] = {nullptr, nullptr};   // pinned staging buffers of pw_simulate's copy out
+    uint32_t *seed_state = nullptr;        // pinned: the seed's MT19937 state on its way to the device
     double lane_ms = 0;              // lane kernel time of the current call
     int n_cu = 0;
     // scratch reused across calls
@@ -251,6 +252,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->probs_scratch.release();
     for (auto &b : g->stage)
         if (b) (void)hipHostFree(b);
+    if (g->seed_state) (void)hipHostFree(g->seed_state);
     for (auto &e : g->ev)
         if (e) (void)hipEventDestroy(e);
     if (g->ev_side) (void)hipEventDestroy(g->ev_side);
@@ -1285,6 +1287,107 @@ static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *re
     return launch_wave_walks(g, wr, extend);
 }
 
+// MT19937 doubles covering [stream_skip, stream_skip + total) of the stream seeded with `seed`, expanded into g->rng
+// (double #(first_block * 312 + k) at g->rng.p[k]): n_gen generators, each expanding `per_gen` (a power of two)
+// consecutive blocks of 312 doubles; generator states come from the seed state by polynomial jump-ahead on the device
+// (binary tree of x^(624*2^m) jumps).  `cacheable`: the generator states may be taken from / kept in the handle's
+// cache (a repeated call with the same seed and shape skips the jump launches).  Events ev[0] / ev[1] bracket the
+// kernels on g->stream.
+static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t stream_skip, uint64_t total, uint64_t *rng_base) {
+    const uint64_t first_block = stream_skip / 312;
+    const uint64_t end_block = (stream_skip + total + 311) / 312;
+    const uint64_t n_blocks = end_block > first_block ? end_block - first_block : 1;
+    if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
+    uint64_t per_gen = 1;
+    int per_gen_log = 0;
+    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }   // (2048 generators: 7.4 vs 8.0 ms, 4096: 9.2)
+    const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
+    if (!g->jump_table_ready) {
+        const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
+        if (g->jump_table.ensure(words)) return PW_ERR_NOMEM;
+        HIP_TRY(hipMemcpy(g->jump_table.p, pw::MtJump::instance().pow2_table(), words * sizeof(uint64_t),
+                          hipMemcpyHostToDevice));
+        g->jump_table_ready = true;
+    }
+    if ((first_block >> (pw::MtJump::MAX_POW2 + 1)) != 0) return fail(PW_ERR_INVALID, "stream offset too large");
+    {   // every jump the tree below needs must be in the table -- checked before anything is launched
+        uint32_t top = 1;
+        int top_log = 0;
+        while (top < n_gen) { top <<= 1; top_log++; }
+        if (top_log > 0 && top_log - 1 + per_gen_log > pw::MtJump::MAX_POW2) return fail(PW_ERR_INVALID, "stream too long");
+    }
+    // generator states: from the cache when this (seed, offset, shape) was expanded before
+    pw_graph::MtCache *mc = nullptr;
+    for (auto &c : g->mt_cache)
+        if (c.valid && c.seed == seed && c.first_block == first_block && c.per_gen_log == per_gen_log && c.n_gen == n_gen) mc = &c;
+    const bool mt_hit = mc != nullptr && cacheable;
+    if (!mt_hit) {
+        mc = &g->mt_cache[0];
+        for (auto &c : g->mt_cache)
+            if (!c.valid) { mc = &c; break; } else if (c.stamp < mc->stamp) mc = &c;
+        mc->valid = false;
+        if (mc->states.ensure((size_t)pw::MT_N * n_gen)) return PW_ERR_NOMEM;
+        if (!g->jump_tmp.p) {   // (a jump's polynomial taps are split over several workgroups: partial results, kept zeroed)
+            if (g->jump_tmp.ensure((size_t)256 * pw::MT_N)) return PW_ERR_NOMEM;
+            HIP_TRY(hipMemsetAsync(g->jump_tmp.p, 0, sizeof(uint32_t) * 256 * pw::MT_N, g->stream));
+        }
+        if (!g->seed_state) HIP_TRY(hipHostMalloc((void **)&g->seed_state, sizeof(uint32_t) * pw::MT_N, hipHostMallocDefault));
+        HIP_TRY(hipStreamSynchronize(g->stream));   // (the pinned seed state of an earlier call has been consumed)
+        pw::mt_seed_state(g->seed_state, seed);
+        HIP_TRY(hipMemcpyAsync(mc->states.p, g->seed_state, sizeof(uint32_t) * pw::MT_N, hipMemcpyHostToDevice, g->stream));
+    }
+    mc->stamp = ++g->mt_stamp;
+    uint32_t *const mt_states = mc->states.p;
+    HIP_TRY(hipEventRecord(g->ev[0], g->stream));
+    if (!mt_hit) {
+        // a jump's polynomial taps are split over several workgroups while a level has fewer jumps than CUs
+        auto jump = [&](uint32_t jumps, const uint64_t *poly, uint32_t src_stride, uint32_t dst_offset) {
+            uint32_t parts = jumps >= 128 ? 1u : (uint32_t)(g->n_cu > 0 ? g->n_cu : 256) / jumps;
+            if (parts > 39) parts = 39;
+            if (parts < 1) parts = 1;
+            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
+                               dst_offset, parts, g->jump_tmp.p);
+            if (parts > 1)
+                hipLaunchKernelGGL(pw::mt_jump_store_kernel, dim3(jumps), dim3(640), 0, g->stream, mt_states, g->jump_tmp.p,
+                                   src_stride, dst_offset);
+        };
+        for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
+            if ((first_block >> m) & 1) jump(1u, g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
+        uint32_t top = 1;
+        int top_log = 0;
+        while (top < n_gen) { top <<= 1; top_log++; }
+        for (int lvl = top_log - 1; lvl >= 0; lvl--) {  // generator i -> i + 2^lvl, for i % 2^(lvl+1) == 0
+            uint32_t s = 1u << lvl;
+            if (s >= n_gen) continue;
+            uint32_t pairs = (n_gen - s + 2 * s - 1) / (2 * s);
+            int m = lvl + per_gen_log;
+            jump(pairs, g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
+        }
+        mc->valid = true;
+        mc->seed = seed; mc->first_block = first_block; mc->per_gen_log = per_gen_log; mc->n_gen = n_gen;
+    }
+    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, mt_states,
+                       (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[1], g->stream));
+    *rng_base = first_block * 312;
+    return 0;
+}
+
+// Test hook: doubles #offset .. #offset + n of RandomState(seed).random_sample as the DEVICE produces them (jump tree +
+// expansion kernels of a walk call), copied to the host.
+PW_EXPORT int pw_stream_sample_device(pw_graph *g, uint32_t seed, uint64_t offset, uint64_t n, double *out) {
+    if (!g || (n && !out)) return fail(PW_ERR_INVALID, "null pointer");
+    if (set_device(g)) return PW_ERR_HIP;
+    if (!n) return PW_OK;
+    uint64_t base = 0;
+    int rc = expand_stream(g, seed, false, offset, n, &base);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, g->rng.p + (offset - base), sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PW_OK;
+}
+
 PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
                                  const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
                                  int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
@@ -1319,84 +1422,22 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     if (rc) return rc;
 
     const bool lanes_pre = g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && mode == PW_MODE_SPARSE_OTF;
-    if (lanes_pre) {   // (zero-fill of the walk matrix for the lane kernel: overlapped with the stream expansion)
+    // (zero-fill of the walk matrix for the lane kernel: on the side stream, overlapped with the stream expansion.  No
+    //  return path may leave that write to the CALLER's buffer in flight: the guard waits for the side stream.)
+    struct SideGuard {
+        hipStream_t s;
+        bool armed;
+        ~SideGuard() { if (armed) (void)hipStreamSynchronize(s); }
+    } side_guard{g->stream2, false};
+    if (lanes_pre) {
+        side_guard.armed = true;
         HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream2));
         HIP_TRY(hipEventRecord(g->ev_side, g->stream2));
     }
-    // 2. MT19937 doubles covering [stream_skip, stream_skip + total): n_gen generators, each
-    //    expanding `per_gen` (a power of two) consecutive blocks; generator states come from the
-    //    seed state by polynomial jump-ahead on the device (binary tree of x^(624*2^m) jumps).
-    const uint64_t first_block = stream_skip / 312;
-    const uint64_t end_block = (stream_skip + total + 311) / 312;
-    const uint64_t n_blocks = end_block > first_block ? end_block - first_block : 1;
-    if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
-    uint64_t per_gen = 1;
-    int per_gen_log = 0;
-    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }   // (2048 generators: 7.4 vs 8.0 ms, 4096: 9.2)
-    const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
-    if (!g->jump_table_ready) {
-        const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
-        if (g->jump_table.ensure(words)) return PW_ERR_NOMEM;
-        HIP_TRY(hipMemcpy(g->jump_table.p, pw::MtJump::instance().pow2_table(), words * sizeof(uint64_t),
-                          hipMemcpyHostToDevice));
-        g->jump_table_ready = true;
-    }
-    if ((first_block >> (pw::MtJump::MAX_POW2 + 1)) != 0) return fail(PW_ERR_INVALID, "stream offset too large");
-    // generator states: from the cache when this (seed, offset, shape) was expanded before
-    pw_graph::MtCache *mc = nullptr;
-    for (auto &c : g->mt_cache)
-        if (c.valid && c.seed == seed && c.first_block == first_block && c.per_gen_log == per_gen_log && c.n_gen == n_gen) mc = &c;
-    const bool mt_hit = mc != nullptr && has_seed;
-    if (!mt_hit) {
-        mc = &g->mt_cache[0];
-        for (auto &c : g->mt_cache)
-            if (!c.valid) { mc = &c; break; } else if (c.stamp < mc->stamp) mc = &c;
-        mc->valid = false;
-        if (mc->states.ensure((size_t)pw::MT_N * n_gen)) return PW_ERR_NOMEM;
-        uint32_t st0[pw::MT_N];
-        pw::mt_seed_state(st0, seed);
-        HIP_TRY(hipMemcpyAsync(mc->states.p, st0, sizeof(st0), hipMemcpyHostToDevice, g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));  // st0 is on the stack
-    }
-    mc->stamp = ++g->mt_stamp;
-    uint32_t *const mt_states = mc->states.p;
-    HIP_TRY(hipEventRecord(g->ev[0], g->stream));
-    if (!mt_hit) {
-        // a jump's polynomial taps are split over several workgroups while a level has fewer jumps than CUs
-        if (!g->jump_tmp.p) {
-            if (g->jump_tmp.ensure((size_t)256 * pw::MT_N)) return PW_ERR_NOMEM;
-            HIP_TRY(hipMemsetAsync(g->jump_tmp.p, 0, sizeof(uint32_t) * 256 * pw::MT_N, g->stream));
-        }
-        auto jump = [&](uint32_t jumps, const uint64_t *poly, uint32_t src_stride, uint32_t dst_offset) {
-            uint32_t parts = jumps >= 128 ? 1u : (uint32_t)(g->n_cu > 0 ? g->n_cu : 256) / jumps;
-            if (parts > 39) parts = 39;
-            if (parts < 1) parts = 1;
-            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
-                               dst_offset, parts, g->jump_tmp.p);
-            if (parts > 1)
-                hipLaunchKernelGGL(pw::mt_jump_store_kernel, dim3(jumps), dim3(640), 0, g->stream, mt_states, g->jump_tmp.p,
-                                   src_stride, dst_offset);
-        };
-        for (int m = 0; m <= pw::MtJump::MAX_POW2; m++)  // generator 0 -> first_block
-            if ((first_block >> m) & 1) jump(1u, g->jump_table.p + (size_t)m * pw::MT_PW, 0u, 0u);
-        uint32_t top = 1;
-        int top_log = 0;
-        while (top < n_gen) { top <<= 1; top_log++; }
-        for (int lvl = top_log - 1; lvl >= 0; lvl--) {  // generator i -> i + 2^lvl, for i % 2^(lvl+1) == 0
-            uint32_t s = 1u << lvl;
-            if (s >= n_gen) continue;
-            uint32_t pairs = (n_gen - s + 2 * s - 1) / (2 * s);
-            int m = lvl + per_gen_log;
-            if (m > pw::MtJump::MAX_POW2) return fail(PW_ERR_INVALID, "stream too long");
-            jump(pairs, g->jump_table.p + (size_t)m * pw::MT_PW, 2 * s, s);
-        }
-        mc->valid = true;
-        mc->seed = seed; mc->first_block = first_block; mc->per_gen_log = per_gen_log; mc->n_gen = n_gen;
-    }
-    hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, mt_states,
-                       (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g->ev[1], g->stream));
+    // 2. the doubles [stream_skip, stream_skip + total) of the seed's MT19937 stream, expanded on the device
+    uint64_t rng_base = 0;
+    rc = expand_stream(g, seed, has_seed != 0, stream_skip, total, &rng_base);
+    if (rc) return rc;
 
     // 3. walks
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, N_COUNTERS * sizeof(unsigned long long), g->stream));
@@ -1411,7 +1452,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     wa.job_list = nullptr;
     wa.n_list = 0;
     wa.rng = g->rng.p;
-    wa.rng_base = first_block * 312;
+    wa.rng_base = rng_base;
     wa.out = d_out;
     wa.job_counter = g->counters.p;
     wa.stats = g->counters.p + 1;

@@ -754,8 +754,11 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
             const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
             const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
-            // single-segment rows: the COUNT pass already wrote the lists that fit their lines (below) -- nothing to fill
-            const bool done = FILL && nseg == 1 && r0.y <= EL_INLINE;
+            // single-segment rows: the COUNT pass already wrote the lists that fit their lines (below) -- nothing to fill.
+            // "Fits its line" includes the row of k being narrow (uint16 positions): a DIRECTED entry h -> k into a row of
+            // more than 65536 entries that has no reverse entry is taken by h whatever the degrees, and its short list
+            // lives in the overflow array as uint32 positions, which only the FILL pass writes.
+            const bool done = FILL && nseg == 1 && list_is_inline(d_k, r0.y);
             if (mine && d_k && !done) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range

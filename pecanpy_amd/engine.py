@@ -49,6 +49,7 @@ class WalkEngine:
         self.device = device
         self.last_stats = None
         self._max_degree = n_nodes   # upper bound; from_csr / from_dense narrow it
+        self._nnz = 0                # CSR entries (from_csr)
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
@@ -112,14 +113,18 @@ class WalkEngine:
 
     def lane_index(self):
         """Test hook: ``(n_in, rev_pos, offsets, entries)`` of the lane index (see ``pw_lane_index_export``)."""
-        info = self.index_info()
-        n = self._nnz
+        n = max(self._nnz, 1)   # (dense handles / no lane index: the library's PW_ERR_UNSUPPORTED surfaces below)
         n_in = np.zeros(n, dtype=np.uint32)
         rev = np.zeros(n, dtype=np.uint32)
-        entries = np.zeros(max(info["lane_list_entries"], 1), dtype=np.uint32)
-        _lib.check(self._lib.pw_lane_index_export(self._h, _np_ptr(n_in), _np_ptr(rev), _np_ptr(entries)))
+        _lib.check(self._lib.pw_lane_index_export(self._h, _np_ptr(n_in), _np_ptr(rev), None))   # counts first
+        n_in, rev = n_in[: self._nnz], rev[: self._nnz]
+        total = int(n_in.sum(dtype=np.int64))
+        if total != self.index_info()["lane_list_entries"]:
+            raise _lib.PwError("lane index: the per-entry counts do not add up to the number of list entries")
+        entries = np.zeros(max(total, 1), dtype=np.uint32)
+        _lib.check(self._lib.pw_lane_index_export(self._h, None, None, _np_ptr(entries)))
         off = np.concatenate([[0], np.cumsum(n_in, dtype=np.int64)])
-        return n_in, rev, off, entries[: info["lane_list_entries"]]
+        return n_in, rev, off, entries[:total]
 
     def close(self):
         if self._h is not None and self._h.value:
@@ -203,6 +208,13 @@ class WalkEngine:
         _lib.check(self._lib.pw_precomp_export(self._h, _np_ptr(alias_indptr), _np_ptr(alias_j),
                                                _np_ptr(alias_q), C.byref(n)))
         return alias_indptr, alias_j, alias_q
+
+    def stream_sample(self, seed, offset, n):
+        """Test hook: doubles ``#offset .. #offset + n`` of ``RandomState(seed).random_sample`` as the device's jump-ahead
+        tree and expansion kernels produce them (``pw_stream_sample_device``)."""
+        out = np.zeros(int(n), dtype=np.float64)
+        _lib.check(self._lib.pw_stream_sample_device(self._h, int(seed) & 0xFFFFFFFF, int(offset), int(n), _np_ptr(out)))
+        return out
 
     def count_stream_draws(self, starts, walk_length):
         starts = np.ascontiguousarray(starts, dtype=np.uint32)

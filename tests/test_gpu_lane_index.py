@@ -103,3 +103,56 @@ def test_directed_graph_entries_without_reverse_edge():
     eng, n_in = check(indptr, indices)
     _, rev, _, _ = eng.lane_index()
     assert (rev == NOT_FOUND).any() and (rev != NOT_FOUND).any()
+
+
+def test_directed_entry_into_a_wide_row_without_reverse_edge():
+    """a directed entry h -> k with NO reverse entry, deg(h) <= 8192 (single segment), deg(k) > 65536
+    (uint32 positions) and 1..20 common neighbours.  Its list is short enough for an edge line but a wide row's list
+    never lives there: the FILL pass has to write it (the COUNT pass's inline shortcut does not apply).  Checked through
+    the decoded index AND through walks that arrive by such entries, against the oracle."""
+    from oracle import pyoracle as orc
+
+    rng = np.random.default_rng(11)
+    hub_deg, n = 70000, 70400
+    hub_dst = np.arange(1, hub_deg + 1)                       # 0 -> 1..70000: a row of 70 000 entries
+    feeders = np.arange(hub_deg + 1, hub_deg + 301)           # 300 vertices h -> 0, none of them a neighbour of 0
+    f_src, f_dst = [], []
+    for h in feeders:
+        k = int(rng.integers(1, 21))                          # 1..20 common neighbours with the hub
+        common = rng.choice(np.arange(1, hub_deg + 1), k, replace=False)
+        common[0] = hub_deg - int(rng.integers(0, 3000))      # ... one of them beyond position 65535
+        other = rng.choice(feeders[feeders != h], 3, replace=False)
+        for t in np.concatenate([[0], common, other]):
+            f_src.append(h); f_dst.append(int(t))
+    # the hub's neighbours lead back to the feeders and to each other, so that walks keep arriving by h -> 0
+    b_src = rng.integers(1, hub_deg + 1, 200000)
+    b_dst = np.where(rng.random(200000) < 0.5, rng.choice(feeders, 200000), rng.integers(1, hub_deg + 1, 200000))
+    src = np.concatenate([np.zeros(hub_deg, np.int64), np.array(f_src), b_src])
+    dst = np.concatenate([hub_dst, np.array(f_dst), b_dst])
+    keep = src != dst
+    indptr, indices, _ = csr_from_edges(src[keep], dst[keep], n)
+    ip = indptr.astype(np.int64)
+    assert ip[1] - ip[0] == hub_deg
+    eng = WalkEngine.from_csr(indptr, indices, None)
+    n_in, rev, off, ent = eng.lane_index()
+    into_hub = np.concatenate([np.flatnonzero(indices[ip[h]:ip[h + 1]] == 0) + ip[h] for h in feeders])
+    assert into_hub.size == feeders.size and (rev[into_hub] == NOT_FOUND).all()
+    assert (n_in[into_hub] >= 1).all() and (n_in[into_hub] <= 20).all()
+    for e, (cnt, rv, pos) in zip(into_hub, expected_lists(indptr, indices, into_hub)):
+        assert n_in[e] == cnt and np.array_equal(ent[off[e]:off[e + 1]], pos), (int(e), ent[off[e]:off[e + 1]], pos)
+        assert pos.max() > 65535
+    some = np.sort(np.random.default_rng(2).choice(indices.size, 3000, replace=False))
+    for e, (cnt, rv, pos) in zip(some, expected_lists(indptr, indices, some)):
+        assert n_in[e] == cnt and rev[e] == rv and np.array_equal(ent[off[e]:off[e + 1]], pos), int(e)
+    # walks from the feeders: the second step of most of them is taken on the hub row having arrived by h -> 0
+    starts = np.repeat(feeders.astype(np.uint32), 40)
+    np.random.RandomState(4).shuffle(starts)
+    data = np.ones(indices.size, dtype=np.float32)
+    for p, q in ((0.5, 2.0), (0.3, 1.7)):
+        want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 30, 9, return_stats=True)
+        got = eng.simulate("SparseOTF", p, q, False, starts, 30, seed=9)
+        st = dict(eng.last_stats)
+        assert st["lane_kernel"] in (1, 2) and st["stream_addressing"] == 0, st
+        assert np.array_equal(got, want), (p, q)
+        via = (want[:, 1] == 0).sum()
+        assert via > 1000                                     # (walks whose first step went h -> 0)

@@ -198,7 +198,9 @@ def test_stream_skip_shard():
 
 
 def test_long_walks_and_large_offsets():
-    """walk_length > 128 and a stream offset beyond 2^32 words (jump-ahead + expansion)."""
+    """walk_length > 128 and a stream offset of 10^7 + 17 doubles (jump-ahead + expansion; the offsets the last
+    shards of a BASELINE-size run start from -- 1.4e9 doubles and beyond -- are covered by
+    test_device_stream_at_deep_offsets below and tests/test_gpu_scale.py::test_full_size_oracle_slice_deep_in_the_stream)."""
     indptr, indices, data = rmat_csr(9, seed=2)
     n = indptr.size - 1
     starts = orc.shuffled_starts(n, 1, 3)[:64]
@@ -207,6 +209,29 @@ def test_long_walks_and_large_offsets():
     eng = WalkEngine.from_csr(indptr, indices, data)
     got = eng.simulate("SparseOTF", 0.5, 2, False, starts, 200, seed=3, stream_skip=skip)
     assert np.array_equal(got, want), _diff_report(got, want)
+
+
+def test_device_stream_at_deep_offsets():
+    """The device's jump-ahead tree + expansion kernels against the host jump-ahead (pw_mt_random_sample, itself pinned
+    to NumPy's RandomState in tests/test_stream.py and the mt19937 goldens) at the stream depths of a multi-GPU
+    BASELINE run and beyond 2^32 words: offsets 2^31 and 2.2e9 DOUBLES (= 2^32 and 4.4e9 MT19937 words), unaligned
+    starts, spans that cross generator boundaries; and against NumPy itself where that is cheap."""
+    import ctypes as C
+
+    from pecanpy_amd import _lib
+
+    indptr, indices, data = rmat_csr(8, seed=1)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    lib = _lib.load()
+    for seed, off, n in ((0, 2**31, 5000), (0, 2**31 + 5, 700000), (7, 2_200_000_000, 300001), (3, 1_400_000_123, 4097),
+                         (0, 1_607_000_000, 1000), (123456789, 4_000_000_001, 3000), (5, 0, 1000), (5, 311, 2)):
+        got = eng.stream_sample(seed, off, n)
+        want = np.zeros(n, dtype=np.float64)
+        _lib.check(lib.pw_mt_random_sample(C.c_uint32(seed), C.c_uint64(off), C.c_uint64(n), want.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, want), (seed, off, n, int(np.flatnonzero(got != want)[0]))
+    rs = np.random.RandomState(11)
+    rs.random_sample(3_000_000)
+    assert np.array_equal(eng.stream_sample(11, 3_000_000, 4000), rs.random_sample(4000))
 
 
 def _dense_fixtures():

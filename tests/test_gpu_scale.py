@@ -140,6 +140,64 @@ def test_full_size_oracle_prefix(run, p, q):
         assert np.array_equal(run["out"][:n].cpu().numpy().view(np.uint32), want)
 
 
+@pytest.mark.parametrize("p,q", [(0.3, 1.7), (3.0, 0.37)])
+def test_full_size_float_lane_form_equals_the_wave_kernel(run, p, q, monkeypatch):
+    """The FLOATS form of the lane kernel (unit weights, 1/p or 1/q NOT a power of two: two closed-form float32 chains
+    per lane and step, lane_chain<true>) at BASELINE size against the wave-per-walk kernel's eager step -- the complete
+    float32 scan -- on 2^21 jobs (80 M transitions), and for one pair against the oracle on the first 20 000 jobs."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    m = 1 << 21
+    d = run["d_starts"][:m].contiguous()
+    lane = run["eng"].simulate_device("SparseOTF", p, q, False, d, L, seed=3)
+    st = dict(run["eng"].last_stats)
+    assert st["lane_kernel"] == 2, st
+    monkeypatch.setenv("PECANPY_AMD_NO_LANES", "1")
+    wave = run["eng"].simulate_device("SparseOTF", p, q, False, d, L, seed=3)
+    sw = dict(run["eng"].last_stats)
+    monkeypatch.delenv("PECANPY_AMD_NO_LANES")
+    assert sw["lane_kernel"] == 0, sw
+    assert (st["total_steps"], st["overflow_reads"]) == (sw["total_steps"], sw["overflow_reads"])
+    assert torch.equal(lane, wave), (p, q)
+    print(f"[floats] RMAT-{SCALE} p={p} q={q}: {st['total_steps']} transitions, lane == wave; {st['redo_walks']} redo walks, "
+          f"{st['overflow_reads']} overflow reads")
+    if (p, q) == (0.3, 1.7):
+        n = 20000
+        data = np.ones(run["indices"].size, dtype=np.float32)
+        want, ost = orc.walks_sparse_otf(run["indptr"], run["indices"], data, p, q, run["starts"][:n], L, 3, return_stats=True)
+        assert np.array_equal(lane[:n].cpu().numpy().view(np.uint32), want)
+        head = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"][:n].contiguous(), L, seed=3)
+        hs = dict(run["eng"].last_stats)
+        assert hs["lane_kernel"] == 2 and np.array_equal(head.cpu().numpy().view(np.uint32), want)
+        assert (hs["total_steps"], hs["overflow_reads"]) == (ost.total_steps, ost.overflow_reads)
+
+
+def test_full_size_oracle_slice_deep_in_the_stream(run):
+    """The last shard of an 8-GPU run: 5 000 jobs starting at 7/8 of the shuffled job array, i.e. ~1.4e9 doubles into the
+    seed's stream (the device's 45-entry jump tree at that depth), bit-exact against the sequential oracle, which skips
+    the same number of draws one by one."""
+    from oracle import pyoracle as orc
+
+    starts = run["starts"]
+    lo = (7 * starts.size) // 8
+    n = 5000
+    skip = run["eng"].count_stream_draws(starts[:lo], L)
+    deg = np.diff(run["indptr"].astype(np.int64))
+    assert skip == int((deg[starts[:lo]] > 0).sum()) * L and skip > 1.3e9
+    data = np.ones(run["indices"].size, dtype=np.float32)
+    want, ost = orc.walks_sparse_otf(run["indptr"], run["indices"], data, 0.5, 2, starts[lo:lo + n], L, SEED,
+                                     stream_skip=skip, return_stats=True)
+    got = run["eng"].simulate_device("SparseOTF", 0.5, 2, False, run["d_starts"][lo:lo + n].contiguous(), L, seed=SEED,
+                                     stream_skip=skip)
+    st = dict(run["eng"].last_stats)
+    got = got.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want)
+    assert (st["total_steps"], st["overflow_reads"]) == (ost.total_steps, ost.overflow_reads)
+    assert np.array_equal(run["out"][lo:lo + n].cpu().numpy().view(np.uint32), want)   # ... and the whole-array run
+
+
 # ---- BASELINE C5: weighted RMAT-20, node2vec+ ------------------------------------------------------------------------
 C5_SCALE = int(os.environ.get("PECANPY_TEST_C5_SCALE", "20"))
 
@@ -246,6 +304,44 @@ def test_c4_full_size_properties():
     lo, hi = (2 * starts.size) // 8, (3 * starts.size) // 8
     shard = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts[lo:hi].contiguous(), L, seed=SEED, stream_skip=lo * L)
     assert torch.equal(shard, out[lo:hi])
+
+
+def test_c4_full_size_fast_kernel_equals_the_complete_kernel_and_the_oracle():
+    """BASELINE C4 at its real shape (N = 100 000, density 0.25: WPL = 25, ~25 000 set bits per row): the register-only
+    walk_dense_fast_kernel against walk_dense_bits_kernel (the same decision + the float64 chain) on all 80 M steps,
+    and against the packed-bits oracle (oracle/pecan_oracle.c: orc_walks_dense_otf_bits, pinned to the dense goldens)
+    on the first 100 jobs x 80 steps."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    n = int(os.environ.get("PECANPY_TEST_C4_NODES", "100000"))
+    bits, deg = _er_bits(n, 0.25)
+    eng = WalkEngine.from_dense_bits(bits, n)
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * W)
+    np.random.RandomState(SEED).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    fast = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts, L, seed=SEED)
+    st = dict(eng.last_stats)
+    os.environ["PECANPY_AMD_DENSE_NO_FAST"] = "1"
+    try:
+        full = eng.simulate_device("DenseOTF", 0.5, 2, False, d_starts, L, seed=SEED)
+        sf = dict(eng.last_stats)
+    finally:
+        del os.environ["PECANPY_AMD_DENSE_NO_FAST"]
+    assert st["total_steps"] == sf["total_steps"] == starts.size * L
+    assert st["redo_walks"] <= 16 and sf["redo_walks"] == 0, (st, sf)
+    assert torch.equal(fast, full)
+    m = 100
+    hb = bits.cpu().numpy().view(np.uint64).reshape(n, -1)
+    want, ost = orc.walks_dense_otf_bits(hb, n, 0.5, 2, starts[:m], L, SEED, return_stats=True)
+    assert np.array_equal(fast[:m].cpu().numpy().view(np.uint32), want)
+    assert ost.overflow_reads == 0
+    # a non-dyadic pair takes the complete kernel alone (no exact decision without dyadic weights in float64? it has one:
+    # the chain is the fallback) -- the same oracle
+    want2 = orc.walks_dense_otf_bits(hb, n, 0.3, 1.7, starts[:40], L, 2)
+    got2 = eng.simulate_device("DenseOTF", 0.3, 1.7, False, d_starts[:40].contiguous(), L, seed=2)
+    assert np.array_equal(got2.cpu().numpy().view(np.uint32), want2)
 
 
 def test_c4_density_oracle_prefix_on_a_20k_slice():
