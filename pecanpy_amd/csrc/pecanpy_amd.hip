@@ -1195,6 +1195,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         fprintf(stderr, "[lane_prof] iterations %llu  refinement passes %llu (%.1f lanes each, %.0f cycles)  chain passes %llu (%.1f lanes each, %.0f cycles)\n",
                 hp[8], hp[9], hp[9] ? (double)hp[10] / (double)hp[9] : 0.0, hp[9] ? (double)hp[2] / (double)hp[9] : 0.0, hp[5],
                 hp[5] ? (double)hp[6] / (double)hp[5] : 0.0, hp[5] ? (double)hp[4] / (double)hp[5] : 0.0);
+        fprintf(stderr, "[lane_prof] per iteration: deepest search %.2f probes, all probes %.1f, runnable lanes %.1f, lanes on overflow lists %.1f\n",
+                (double)hp[11] / (double)hp[8], (double)hp[14] / (double)hp[8], (double)hp[13] / (double)hp[8], (double)hp[12] / (double)hp[8]);
     }
 #endif
     *n_redo = nr;

@@ -368,6 +368,15 @@ struct MassEval {   // E(P_i) in units of the smallest weight
     }
 };
 
+// exact row total of a unit-weight row: n_in common neighbours (1), prev (w_prev) when pp names it, the rest w_out.
+// ONE definition: lane_decide takes the step's total from here, and so does the lane kernel's deferred interval
+// decision, which recomputes it instead of carrying it (n_in + [pp present] <= d: lane_decide checked)
+PW_HD double lane_row_total(uint32_t d, uint32_t n_in, uint32_t pp, float w_out, float w_prev) {
+    const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
+    const uint32_t n_out = d - n_in - n_pv;
+    return (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
+}
+
 PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
                            const ListView &cl, LaneStep &ls) {
     const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
@@ -377,7 +386,7 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     float u = 1.0f;
     if (n_out && w_out < u) u = w_out;
     if (n_pv && w_prev < u) u = w_prev;
-    const double td = (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
+    const double td = lane_row_total(d, n_in, pp, w_out, w_prev);
     if (!(td <= 16777216.0 * (double)u)) return LANE_REDO;   // every partial sum exact: tot = exact sum
     ls.tot = (float)td;
     const uint32_t sh_u = (FloatTraits<float>::bits(u) >> 23) & 0xffu;
@@ -394,7 +403,11 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0, f_below = 0;
     if (n_in) {
         const MassEval ev{pp, sh_in, sh_out, sh_prev};
+#if defined(PW_LANES_WIDE_DECIDE) && PW_LANES_WIDE_DECIDE
+        const SearchResult sr = list_search_wide(cl, 0u, n_in, ev, (uint64_t)lo_th, ls.probes);   // (same result, field by field)
+#else
         const SearchResult sr = list_search(cl, 0u, n_in, ev, (uint64_t)lo_th, ls.probes);
+#endif
         if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
         if (sr.f < n_in) { p_f = sr.p_at; e_f = (uint32_t)sr.v_at; }
         f_below = sr.f;   // entries whose mass stays below lo_th: exactly the common neighbours before k1

@@ -135,6 +135,24 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_MIN_WAVES_Q
 #define PW_LANES_MIN_WAVES_Q 6   // ... of the queueing form (no chain code; statistics in scalar registers): 80 VGPRs, six waves without spilling
 #endif
+#ifndef PW_LANES_DEFER
+#define PW_LANES_DEFER 1         // queueing form: ambiguous steps wait in a per-wavefront LDS pool for a full-width interval decision
+#endif
+#ifndef PW_LANES_MIN_WAVES_D
+#define PW_LANES_MIN_WAVES_D 5   // ... its occupancy (96 VGPRs; 5 KB of pool + 2 KB of job window per wavefront: 5 x 4 x 7 KB = 140 KB of LDS per CU)
+#endif
+#ifndef PW_LANES_DEFER_TH
+#define PW_LANES_DEFER_TH 32     // deferred steps that trigger a pass of the interval decision (lanes enabled in it)
+#endif
+#ifndef PW_LANES_POOL
+#define PW_LANES_POOL 64         // slots of the pool (slot s is decided by lane s: at most 64)
+#endif
+#ifndef PW_LANES_WIN
+#define PW_LANES_WIN 64          // jobs prefetched into the job window at a time
+#endif
+#ifndef PW_LANES_DRAW_LDS
+#define PW_LANES_DRAW_LDS 0      // 1: a walk's draws are fetched a 64-byte sector (8 draws) at a time, straight into LDS
+#endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
                               // its share of the work at most)
@@ -199,7 +217,8 @@ __device__ unsigned long long g_lprof[16];
                     for (uint32_t z_ = A.j; z_ <= L; z_++) row_[z_] = 0;                        \
                 }                                                                               \
                 A.flags = 0;                                                                    \
-            } else r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */   \
+            } else if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff + (A.j - 1)); }                \
+            else r = a.rng[A.soff + (A.j - 1)];     /* the next step's draw, asked for now */   \
         }                                                                                       \
     } while (0)
 
@@ -216,9 +235,20 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // form per binade (lane_chain): the row total w.sum() (sparse_rw.py:89), then cumsum / searchsorted over w / tot
 // (pecanpy.py:556-557).  ~6x fewer wave instructions per step than walk_kernel's eager step, which gives every walk a
 // whole wavefront.
+// DEFER (queueing form, !INPLACE, PW_LANES_DEFER): the interval decision (lane_tight, ~850 instructions, no memory access)
+// is NOT run where the ambiguity turns up -- 12 % of the lanes, so nearly every loop iteration would pay for it with an
+// eighth of its lanes enabled (round 3: ~40 % of the kernel's vector instructions).  The lane writes the walk's context
+// (80 bytes: walk state, draw, what lane_decide found, staged output cells) into a POOL of 64 slots in LDS, one pool per
+// wavefront, and takes another walk at once; when PW_LANES_DEFER_TH slots wait (or nothing else can run) one PASS decides
+// them all, slot s by lane s -- half of the lanes or more enabled.  Settled walks stay in the pool until a lane is free
+// (they are picked up BEFORE fresh jobs, with their step's choice known: the resume path, F_PRE); the ones the interval
+// decision leaves open go to the global queue of parked walks from there.  Slots are handed out by rank (r-th deferring
+// lane <- r-th free slot, through a 64-byte map in LDS); a step that finds no free slot is parked in the global queue
+// undecided (lanes_chain_kernel settles it by the float chain: any ambiguous step may go there).
 template <bool INPLACE, bool VERIFY, bool FLOATS = false>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : PW_LANES_MIN_WAVES_Q)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q))
 walk_lanes_kernel(LanesArgs a) {
+    constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS;
     const int lane = lane_id();
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
@@ -249,11 +279,41 @@ walk_lanes_kernel(LanesArgs a) {
     // parked in LDS; a refill then costs one LDS read instead of that chain (nearly every loop iteration refills a lane
     // or two: ~40 steps per walk, 64 lanes).  Entries [win_lo, win_lo + win_n) of the job array are in the window.
     struct JobSlot { uint32_t job, start, s0, d; uint32_t soff_lo, soff_hi, r_lo, r_hi; };
-    __shared__ JobSlot s_win[WAVES_PER_BLOCK][WAVE];
+    __shared__ JobSlot s_win[WAVES_PER_BLOCK][PW_LANES_WIN];
     JobSlot *const win = s_win[readfirst_u32(threadIdx.x / WAVE)];
     uint64_t win_lo = 0;
     uint32_t win_n = 0;
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
+    // POOL of deferred steps (DEFER): slot s = words pool[q][s], q = 0..4:
+    //   { job, j, s0, d } { n_in, pp, e, coff } { kmax -> choice once settled, soff lo, soff hi, k1 }
+    //   { commons before k1, shifts, p_next, staged cell 0 } { draw lo, draw hi, staged cells 1, 2 }
+    // m_def / m_set (wave-uniform): slots waiting for the interval decision / settled, waiting for a free lane
+    __shared__ uint4 s_pool[DEFER ? WAVES_PER_BLOCK : 1][5][PW_LANES_POOL];
+    __shared__ uint8_t s_map[DEFER ? WAVES_PER_BLOCK : 1][WAVE];
+    uint4 (*const pool)[PW_LANES_POOL] = s_pool[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    constexpr uint64_t POOL_MASK = PW_LANES_POOL >= 64 ? ~0ull : ((1ull << (PW_LANES_POOL & 63)) - 1ull);
+    uint8_t *const pmap = s_map[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    uint64_t m_def = 0, m_set = 0;
+    bool force_pass = false;
+    // queue slots for `pm` parked walks of this wavefront (wave-uniform mask; rank of a lane = its order in pm): what is
+    // left of the previous reservation is used up first (only a wavefront's LAST reservation leaves void slots: the queue
+    // never holds more than parked walks + susp_chunk slots per wavefront -- the host sizes it for that)
+    auto queue_slot = [&](uint64_t pm) -> uint64_t {
+        const uint64_t np = (uint64_t)__popcll(pm);
+        const uint64_t left = sp_hi - sp_lo;
+        const uint64_t old_lo = sp_lo;
+        uint64_t new_lo = 0;
+        if (left < np) {
+            const unsigned long long chunk = a.susp_chunk > np - left ? a.susp_chunk : np - left;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(a.susp_count, chunk);
+            new_lo = readfirst_u64(base);
+            sp_lo = new_lo + (np - left);
+            sp_hi = new_lo + chunk;
+        } else sp_lo += np;
+        const uint64_t rk = (uint64_t)__popcll(pm & lane_lt);
+        return rk < left ? old_lo + rk : new_lo + (rk - left);
+    };
     const uint64_t grid_lanes = (uint64_t)gridDim.x * (WAVES_PER_BLOCK * WAVE);
     // statistics: wave-uniform sums of ballots where a count of lanes is all that is needed (scalar registers), 32-bit
     // per-lane counters for the rest
@@ -265,12 +325,123 @@ walk_lanes_kernel(LanesArgs a) {
     float tot = 1.0f, wo = 1.0f;
     uint32_t kmax = 0;
 
+    // DRAWS (PW_LANES_DRAW_LDS): the draws of a walk are consecutive doubles of the stream, but between two steps of a lane
+    // every other lane of the GPU touches its own sectors and the sector is gone from L2 -- one 64-byte fetch per 8-byte
+    // draw.  Instead the whole sector (8 draws) is fetched ONCE, straight into LDS (global_load_lds_dwordx4: lane t's
+    // 16-byte piece c lands at s_draw[c][t], no VGPRs), when the walk's stream position enters it.
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    __shared__ uint4 s_draw[PW_LANES_DRAW_LDS ? WAVES_PER_BLOCK : 1][4][WAVE];
+    uint4 (*const dslot)[WAVE] = s_draw[PW_LANES_DRAW_LDS ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    uint32_t dsec = 0xffffffffu;         // the sector (stream position / 8) this lane's slot holds
+#define PW_DRAW_STAGE(di)                                                                                              \
+    do {                                                                                                               \
+        const uint32_t sec_ = (uint32_t)((uint64_t)(di) >> 3);                                                         \
+        if (sec_ != dsec) {                                                                                            \
+            const double *src_ = a.rng + (uint64_t)sec_ * 8u;                                                          \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src_ + 0), (lds_ptr_t)&dslot[0][0], 16, 0, 0);               \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src_ + 2), (lds_ptr_t)&dslot[1][0], 16, 0, 0);               \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src_ + 4), (lds_ptr_t)&dslot[2][0], 16, 0, 0);               \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src_ + 6), (lds_ptr_t)&dslot[3][0], 16, 0, 0);               \
+            dsec = sec_;                                                                                               \
+        }                                                                                                              \
+    } while (0)
+    // (the compiler does not order an LDS read behind the LDS-DMA that fills it: the wait is explicit)
+#define PW_DRAW_READ(di)                                                                                               \
+    (*(const double *)((const char *)&dslot[((uint32_t)(di) & 7u) >> 1][lane] + (((uint32_t)(di) & 1u) << 3)))
+
 #ifdef PW_LANES_WATCHDOG
     unsigned long long wd_main = 0, wd_refill = 0;
     uint32_t choice_wd = 0;
 #endif
     for (;;) {
         PW_WD(1, 2000000ull, wd_main);
+        if (DEFER) {
+            // ---- PASS: the interval decision of every deferred step, slot s by lane s ---------------------------------
+            if (m_def && (force_pass || (uint32_t)__popcll(m_def) >= PW_LANES_DEFER_TH || (uint32_t)__popcll(m_def | m_set) >= (uint32_t)(PW_LANES_POOL - PW_LANES_POOL / 8))) {
+                force_pass = false;
+                LPROF_C(9, 1);
+                LPROF_C(10, __popcll(m_def));
+                const bool mine = (m_def >> lane) & 1ull;
+                uint32_t ch = LANE_AMBIGUOUS, kmax_s = 0;
+                if (mine) {
+                    const uint4 p0 = pool[0][lane];
+                    const uint2 p1 = *(const uint2 *)&pool[1][lane];
+                    const uint4 p2 = pool[2][lane];
+                    const uint4 p3 = pool[3][lane];
+                    const uint2 p4 = *(const uint2 *)&pool[4][lane];
+                    const float wo_s = p0.y >= 2u ? w_out : 1.0f;
+                    const double r_s = __longlong_as_double((long long)(((unsigned long long)p4.y << 32) | p4.x));
+                    LaneStep ls;
+                    ls.tot = (float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev);
+                    kmax_s = p2.x;
+                    ls.kmax = p2.x; ls.probes = 0; ls.k1 = p2.w; ls.f = p3.x; ls.shifts = p3.y; ls.p_next = p3.z;
+                    ch = lane_tight(p0.w, p1.y, r_s, wo_s, w_prev, ls);
+                    if (ch != LANE_AMBIGUOUS) *(uint32_t *)&pool[2][lane] = ch;   // settled: the choice takes kmax's place
+                }
+                if (VERIFY) {   // keep what the float chain needs to decide this step again (lanes_verify_kernel)
+                    const bool rec = mine && ch != LANE_AMBIGUOUS;
+                    const uint64_t vm = ballot(rec);
+                    if (vm) {
+                        unsigned long long vb = 0;
+                        if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                        vb = readfirst_u64(vb);
+                        const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
+                        if (rec && slot < a.ver_cap) {
+                            const uint4 p0 = pool[0][lane], p1 = pool[1][lane], p4 = pool[4][lane];
+                            const float wo_s = p0.y >= 2u ? w_out : 1.0f;
+                            uint4 *vp = (uint4 *)(a.ver + slot);
+                            vp[0] = make_uint4(kmax_s, p1.x, p1.y, (a.ver_poison && (slot & 1023u) == 0u) ? ch ^ 1u : ch);
+                            vp[1] = make_uint4(p1.z, p1.w, p0.w, 0u);
+                            vp[2] = make_uint4(__float_as_uint((float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev)), __float_as_uint(wo_s), p4.x, p4.y);
+                        }
+                    }
+                }
+                const uint64_t settled = ballot(mine && ch != LANE_AMBIGUOUS);
+                const uint64_t pm = m_def & ~settled;
+                if (pm) {   // left open: the float chain (lanes_chain_kernel) -- the walk is parked from its slot
+                    const uint64_t qs = queue_slot(pm);
+                    if (mine && ch == LANE_AMBIGUOUS) {
+                        const uint4 p0 = pool[0][lane], p1 = pool[1][lane], p2 = pool[2][lane], p4 = pool[4][lane];
+                        const float wo_s = p0.y >= 2u ? w_out : 1.0f;
+                        uint4 *qp = (uint4 *)(a.susp + qs);
+                        qp[0] = p0;
+                        qp[1] = p1;
+                        qp[2] = make_uint4(p2.x, LANE_AMBIGUOUS, p2.y, p2.z);
+                        qp[3] = make_uint4(__float_as_uint((float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev)), __float_as_uint(wo_s), p4.x, p4.y);
+                        const uint32_t slot = (p0.y - 1u) & 3u;      // staged output cells: written out now
+                        uint32_t *cell = a.out + (uint64_t)p0.x * W + (p0.y - slot);
+                        if (slot >= 1u) cell[0] = pool[3][lane].w;
+                        if (slot >= 2u) cell[1] = p4.z;
+                        if (slot >= 3u) cell[2] = p4.w;
+                    }
+                }
+                m_set |= settled;
+                m_def = 0;
+                wave_lds_fence();
+                LPROF_T(2);
+            }
+            // ---- settled walks first: free lanes take them up with their step's choice known -------------------------
+            const uint64_t freel = ballot(!(A.flags & F_ACTIVE));
+            if (m_set && freel) {
+                const uint32_t ns = (uint32_t)__popcll(m_set), nf = (uint32_t)__popcll(freel);
+                const bool give = ((m_set >> lane) & 1ull) && (uint32_t)__popcll(m_set & lane_lt) < nf;
+                if (give) pmap[__popcll(m_set & lane_lt)] = (uint8_t)lane;
+                wave_lds_fence();
+                if (!(A.flags & F_ACTIVE) && (uint32_t)__popcll(freel & lane_lt) < ns) {
+                    const uint32_t sl = pmap[__popcll(freel & lane_lt)];
+                    const uint4 p0 = pool[0][sl], p1 = pool[1][sl], p2 = pool[2][sl], p4 = pool[4][sl];
+                    A.job = p0.x; A.j = p0.y; A.s0 = p0.z; A.d = p0.w;
+                    A.n_in = p1.x; A.pp = p1.y; A.e = p1.z; A.coff = p1.w;
+                    pre = p2.x;
+                    A.soff = ((uint64_t)p2.z << 32) | p2.y;
+                    ob.v[0] = pool[3][sl].w; ob.v[1] = p4.z; ob.v[2] = p4.w;
+                    A.flags = F_ACTIVE | F_PRE;
+                }
+                m_set &= ~ballot(give);
+                wave_lds_fence();
+            }
+        }
         // ---- refill idle lanes from the job counter -------------------------------------------------------
         for (;;) {
             PW_WD(2, 2000000ull, wd_refill);
@@ -293,12 +464,13 @@ walk_lanes_kernel(LanesArgs a) {
             const uint64_t avail = pool_hi - pool_lo;
             const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
             const uint64_t pool_base = pool_lo;
-            pool_lo += avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+            uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+            if (PW_LANES_WIN < WAVE && take > (uint64_t)PW_LANES_WIN) take = PW_LANES_WIN;   // (the rest: the next trip of this loop)
+            pool_lo += take;
             if (!a.resume) {
-                const uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
-                if (pool_base < win_lo || pool_base + take > win_lo + win_n) {   // (wave-uniform) window used up: the next 64 jobs
+                if (pool_base < win_lo || pool_base + take > win_lo + win_n) {   // (wave-uniform) window used up: the next jobs
                     win_lo = pool_base;
-                    win_n = avail < (uint64_t)WAVE ? (uint32_t)avail : (uint32_t)WAVE;
+                    win_n = avail < (uint64_t)PW_LANES_WIN ? (uint32_t)avail : (uint32_t)PW_LANES_WIN;
                     wave_lds_fence();                                      // (earlier reads of the window are over)
                     if ((uint32_t)lane < win_n) {
                         const uint64_t widx = pool_base + (uint64_t)lane;
@@ -309,7 +481,7 @@ walk_lanes_kernel(LanesArgs a) {
                         js.s0 = vr.x; js.d = vr.y;
                         uint64_t so = 0;
                         double r0 = 0.0;
-                        if (vr.y) { so = a.stream_off[js.job] - a.rng_base; r0 = a.rng[so]; }
+                        if (vr.y) { so = a.stream_off[js.job] - a.rng_base; if (!PW_LANES_DRAW_LDS) r0 = a.rng[so]; }
                         js.soff_lo = (uint32_t)so; js.soff_hi = (uint32_t)(so >> 32);
                         js.r_lo = (uint32_t)__double_as_longlong(r0);
                         js.r_hi = (uint32_t)((unsigned long long)__double_as_longlong(r0) >> 32);
@@ -320,7 +492,7 @@ walk_lanes_kernel(LanesArgs a) {
                     wave_lds_fence();
                 }
             }
-            if (!(A.flags & F_ACTIVE) && !exhausted && rank < avail) {
+            if (!(A.flags & F_ACTIVE) && !exhausted && rank < take) {
                 const uint64_t widx = pool_base + rank;
                 if (a.resume) {
                     const uint4 *qp = (const uint4 *)(a.resume + widx);
@@ -352,13 +524,17 @@ walk_lanes_kernel(LanesArgs a) {
                     } else {
                         A.soff = ((uint64_t)j1.y << 32) | j1.x;
                         A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
-                        r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
+                        if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff); }
+                        else r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
                         A.flags = F_ACTIVE;
                     }
                 }
             }
         }
-        if (!ballot(A.flags & F_ACTIVE)) break;
+        if (!ballot(A.flags & F_ACTIVE)) {
+            if (DEFER && m_def) { force_pass = true; continue; }   // (nothing else can run: decide what waits)
+            break;                                                 // (m_set is empty: every lane was free to take from it)
+        }
         LPROF_T(0);
         LPROF_C(8, 1);
 
@@ -368,6 +544,10 @@ walk_lanes_kernel(LanesArgs a) {
         // their chains together once a few have gathered or nothing else can run.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
+        if (PW_LANES_DRAW_LDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sectors requested when the last steps were applied have landed)
+            if (runnable) r = PW_DRAW_READ(A.soff + (A.j - 1));
+        }
         if (FLOATS) {
             if (runnable) {
                 wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
@@ -398,10 +578,48 @@ walk_lanes_kernel(LanesArgs a) {
             choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), ls);
             n_probes += ls.probes;
         }
+#ifdef PW_PROF_LANES
+        {   // [11] sum over iterations of the DEEPEST list search of the wavefront, [12] lanes whose list lives in the overflow
+            // array, [13] runnable lanes, [14] sum of all probes
+            uint32_t pm_ = runnable ? ls.probes : 0u, ps_ = pm_;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o_ = (uint32_t)__shfl_down((int)pm_, (unsigned)off, WAVE);
+                pm_ = o_ > pm_ ? o_ : pm_;
+                ps_ += (uint32_t)__shfl_down((int)ps_, (unsigned)off, WAVE);
+            }
+            LPROF_C(11, pm_);
+            LPROF_C(14, ps_);
+            LPROF_C(12, __popcll(ballot(runnable && !(A.d <= 65536u && A.n_in <= EL_INLINE))));
+            LPROF_C(13, __popcll(ballot(runnable)));
+        }
+#endif
         LPROF_T(1);
         // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
         const bool amb0 = runnable && choice == LANE_AMBIGUOUS;
-        if (ballot(amb0)) {
+        if (DEFER) {
+            // the step waits in the pool for the next pass of the interval decision; this lane takes another walk
+            const uint64_t am = ballot(amb0);
+            if (am) {
+                n_amb += (unsigned long long)__popcll(am);
+                const uint64_t freem = ~(m_def | m_set) & POOL_MASK;
+                const uint32_t nfree = (uint32_t)__popcll(freem), nd = (uint32_t)__popcll(am);
+                const bool taken = ((freem >> lane) & 1ull) && (uint32_t)__popcll(freem & lane_lt) < nd;   // (slot `lane`)
+                if (taken) pmap[__popcll(freem & lane_lt)] = (uint8_t)lane;
+                wave_lds_fence();
+                if (amb0 && (uint32_t)__popcll(am & lane_lt) < nfree) {
+                    const uint32_t sl = pmap[__popcll(am & lane_lt)];
+                    pool[0][sl] = make_uint4(A.job, A.j, A.s0, A.d);
+                    pool[1][sl] = make_uint4(A.n_in, A.pp, A.e, A.coff);
+                    pool[2][sl] = make_uint4(ls.kmax, (uint32_t)A.soff, (uint32_t)(A.soff >> 32), ls.k1);
+                    pool[3][sl] = make_uint4(ls.f, ls.shifts, ls.p_next, ob.v[0]);
+                    pool[4][sl] = make_uint4((uint32_t)__double_as_longlong(r), (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32),
+                                             ob.v[1], ob.v[2]);
+                    A.flags = 0;
+                }
+                m_def |= ballot(taken);
+                wave_lds_fence();
+            }
+        } else if (ballot(amb0)) {
             n_amb += (unsigned long long)__popcll(ballot(amb0));
             LPROF_C(9, 1);
             LPROF_C(10, __popcll(ballot(amb0)));
@@ -428,27 +646,13 @@ walk_lanes_kernel(LanesArgs a) {
         }
         if (!INPLACE || a.susp) {
             // park the walk: the chain runs later, at full width (lanes_chain_kernel); this lane takes another walk
-            const bool park = runnable && choice == LANE_AMBIGUOUS;
+            // (DEFER: only the steps that found no free pool slot arrive here, undecided -- the float chain settles them)
+            const bool park = runnable && choice == LANE_AMBIGUOUS && A.flags == F_ACTIVE;
             const uint64_t pm = ballot(park);
             if (pm) {
-                // queue slots come from a wavefront-local reservation too; what is left of the previous reservation is
-                // used up first (only a wavefront's LAST reservation leaves void slots: the queue never holds more
-                // than parked walks + susp_chunk slots per wavefront -- the host sizes it for that)
-                const uint64_t np = (uint64_t)__popcll(pm);
-                const uint64_t left = sp_hi - sp_lo;
-                const uint64_t old_lo = sp_lo;
-                uint64_t new_lo = 0;
-                if (left < np) {
-                    const unsigned long long chunk = a.susp_chunk > np - left ? a.susp_chunk : np - left;
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.susp_count, chunk);
-                    new_lo = readfirst_u64(base);
-                    sp_lo = new_lo + (np - left);
-                    sp_hi = new_lo + chunk;
-                } else sp_lo += np;
+                const uint64_t qs = queue_slot(pm);   // (queue slots come from a wavefront-local reservation too)
                 if (park) {
-                    const uint64_t rk = (uint64_t)__popcll(pm & lane_lt);
-                    uint4 *qp = (uint4 *)(a.susp + (rk < left ? old_lo + rk : new_lo + (rk - left)));
+                    uint4 *qp = (uint4 *)(a.susp + qs);
                     qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
                     qp[1] = make_uint4(A.n_in, A.pp, A.e, A.coff);
                     qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
@@ -498,6 +702,8 @@ walk_lanes_kernel(LanesArgs a) {
         LPROF_T(3);
     }
 #undef PW_LANE_APPLY
+#undef PW_DRAW_STAGE
+#undef PW_DRAW_READ
     if (a.susp)
         for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES

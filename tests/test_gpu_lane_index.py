@@ -127,8 +127,9 @@ def test_directed_entry_into_a_wide_row_without_reverse_edge():
     # the hub's neighbours lead back to the feeders and to each other, so that walks keep arriving by h -> 0
     b_src = rng.integers(1, hub_deg + 1, 200000)
     b_dst = np.where(rng.random(200000) < 0.5, rng.choice(feeders, 200000), rng.integers(1, hub_deg + 1, 200000))
-    src = np.concatenate([np.zeros(hub_deg, np.int64), np.array(f_src), b_src])
-    dst = np.concatenate([hub_dst, np.array(f_dst), b_dst])
+    every = np.arange(1, hub_deg + 1)                         # ... and every one of them has an out-edge: no dead ends
+    src = np.concatenate([np.zeros(hub_deg, np.int64), np.array(f_src), b_src, every])
+    dst = np.concatenate([hub_dst, np.array(f_dst), b_dst, feeders[every % feeders.size]])
     keep = src != dst
     indptr, indices, _ = csr_from_edges(src[keep], dst[keep], n)
     ip = indptr.astype(np.int64)
