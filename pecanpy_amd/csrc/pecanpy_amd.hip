@@ -383,6 +383,8 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e)));
     ba.clist = g->d_clist;
     lists(true);
+    hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines,
+                       g->d_clist, n_lines);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (fill pass): ") + hipGetErrorString(e)));
@@ -1949,8 +1951,9 @@ struct LaneRow {
     std::vector<uint16_t> cl16;
     std::vector<uint32_t> cl32;
     uint32_t n_cl = 0, pp = 0xffffffffu, wide = 0;
+    uint32_t piv_off = 0;   // element offset of the list's pivots inside cl16 / cl32 (0: none) -- as the index build lays them out
     float tot = 0, x_in = 0, x_out = 0, x_prev = 0;
-    pw::ListView view() const { return pw::ListView{wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide}; }
+    pw::ListView view() const { return pw::list_view_of(wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide, n_cl, piv_off); }
 };
 
 int lane_row_setup(const uint8_t *cls, uint32_t n, float w_out, float w_prev, LaneRow &row, bool need_pow2 = true) {
@@ -1969,6 +1972,14 @@ int lane_row_setup(const uint8_t *cls, uint32_t n, float w_out, float w_prev, La
     row.n_cl = cnt[1];
     row.cl16.resize(row.cl16.size() + 8, 0xffffu);       // a list window may read past the end of the list
     row.cl32.resize(row.cl32.size() + 8, 0xffffffffu);
+    if (pw::list_has_pivots(row.wide, row.n_cl) && !getenv("PW_SELFTEST_NO_PIVOTS")) {   // pivots, as eline_pivots_kernel writes them
+        const uint32_t np = pw::list_pivot_count(row.wide), step = pw::list_pivot_step(row.wide, row.n_cl);
+        row.piv_off = (uint32_t)(row.wide ? row.cl32.size() : row.cl16.size());
+        for (uint32_t k = 0; k < np; k++) {
+            if (row.wide) row.cl32.push_back(row.cl32[(size_t)(k + 1) * step]);
+            else row.cl16.push_back(row.cl16[(size_t)(k + 1) * step]);
+        }
+    }
     row.tot = (float)((double)cnt[1] + (double)cnt[0] * (double)w_out + (double)cnt[2] * (double)w_prev);
     row.x_in = 1.0f / row.tot;
     row.x_out = row.x_in * w_out;
@@ -1996,7 +2007,7 @@ PW_HD void lane_selftest_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint
 }
 
 __global__ void __launch_bounds__(256)
-lane_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t n_cl, uint32_t pp, float w_out,
+lane_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t piv_off, uint32_t n_cl, uint32_t pp, float w_out,
                      float w_prev, const double *r, uint32_t n_r, uint32_t *chain, uint32_t *out4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_r) return;
@@ -2013,7 +2024,7 @@ lane_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wi
     }
     chain[i] = kc;
     uint32_t o[4];
-    lane_selftest_one(n, ListView{cl, wide}, n_cl, pp, w_out, w_prev, r[i], o);
+    lane_selftest_one(n, list_view_of(cl, wide, n_cl, piv_off), n_cl, pp, w_out, w_prev, r[i], o);
     out4[4 * i] = o[0]; out4[4 * i + 1] = o[1]; out4[4 * i + 2] = o[2]; out4[4 * i + 3] = o[3];
 }
 }  // namespace pw
@@ -2036,7 +2047,7 @@ PW_HD void lane_floats_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint32
 }
 
 __global__ void __launch_bounds__(256)
-lane_floats_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t n_cl, uint32_t pp, float w_out,
+lane_floats_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint32_t wide, uint32_t piv_off, uint32_t n_cl, uint32_t pp, float w_out,
                             float w_prev, const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_r) return;
@@ -2052,7 +2063,7 @@ lane_floats_selftest_kernel(const uint8_t *cls, uint32_t n, const void *cl, uint
     chain[i] = kc;
     float tl = 0.0f;
     uint32_t ch = 0;
-    lane_floats_one(n, ListView{cl, wide}, n_cl, pp, w_out, w_prev, r[i], &ch, &tl);
+    lane_floats_one(n, list_view_of(cl, wide, n_cl, piv_off), n_cl, pp, w_out, w_prev, r[i], &ch, &tl);
     lane[i] = ch;
     tots[2 * i] = tot;
     tots[2 * i + 1] = tl;
@@ -2113,7 +2124,7 @@ PW_EXPORT int pw_selftest_lane_floats(int on_device, int device, const uint8_t *
     if (e == hipSuccess) e = hipMemcpy(d_cl, cl_host, cl_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_r) e = hipMemcpy(d_r, r, sizeof(double) * (size_t)n_r, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_r) {
-        hipLaunchKernelGGL(pw::lane_floats_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.n_cl,
+        hipLaunchKernelGGL(pw::lane_floats_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.piv_off, row.n_cl,
                            row.pp, w_out, w_prev, d_r, n_r, d_chain, d_lane, d_tots);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -2183,7 +2194,7 @@ PW_EXPORT int pw_selftest_lane(int on_device, int device, const uint8_t *cls, ui
     if (e == hipSuccess && n_r) e = hipMemcpy(d_r, r, sizeof(double) * (size_t)n_r, hipMemcpyHostToDevice);
     std::vector<uint32_t> out4((size_t)4 * n_r);
     if (e == hipSuccess && n_r) {
-        hipLaunchKernelGGL(pw::lane_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.n_cl, row.pp,
+        hipLaunchKernelGGL(pw::lane_selftest_kernel, dim3((n_r + 255) / 256), dim3(256), 0, 0, d_cls, n, d_cl, row.wide, row.piv_off, row.n_cl, row.pp,
                            w_out, w_prev, d_r, n_r, d_chain, d_out);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();

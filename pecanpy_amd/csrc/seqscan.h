@@ -243,11 +243,29 @@ PW_HD uint32_t solve_out_run(uint32_t s, uint32_t base, uint32_t th, uint32_t pr
 struct ListWin {
     uint32_t v[4];
 };
+// PIVOTS (round 4).  A list that does not fit its edge line leaves the line's 40-byte inline area unused; the index build
+// stores there every step-th entry of the list -- 20 uint16 (10 uint32) pivots, entry (k + 1) * step for k = 0.., step =
+// n / 21 (n / 11) -- and the searches below bisect the pivots first: the upper ~4.4 (3.5) levels of a long list's
+// bisection are then probes of the line the step has fetched anyway (cache hits) instead of dependent trips to the
+// overflow array.  One lane's search depth sets the pace of its whole wavefront (the deepest search of an iteration
+// averages 9 probes at RMAT-22 against 2.4 for the average lane), and each level is a memory round trip.
+constexpr uint32_t LIST_PIVOTS_NARROW = 20, LIST_PIVOTS_WIDE = 10;
+PW_HD uint32_t list_pivot_count(uint32_t wide) { return wide ? LIST_PIVOTS_WIDE : LIST_PIVOTS_NARROW; }
+// a list of n entries has pivots iff n exceeds their number (then step >= 1; such a list is never inline)
+PW_HD bool list_has_pivots(uint32_t wide, uint32_t n) { return n > list_pivot_count(wide); }
+PW_HD uint32_t list_pivot_step(uint32_t wide, uint32_t n) { return wide ? n / (LIST_PIVOTS_WIDE + 1u) : n / (LIST_PIVOTS_NARROW + 1u); }
+
 struct ListView {
     const void *p;      // first entry
     uint32_t wide;      // 1: uint32 entries, 0: uint16 entries
+    const void *piv = nullptr;   // pivots (same entry width), or nullptr
+    uint32_t npiv = 0;           // their number (0: none)
+    uint32_t step = 0;           // pivot k = entry (k + 1) * step
     PW_HD uint32_t at(uint32_t i) const {
         return wide ? ((const uint32_t *)p)[i] : (uint32_t)((const uint16_t *)p)[i];
+    }
+    PW_HD uint32_t pivot(uint32_t k) const {
+        return wide ? ((const uint32_t *)piv)[k] : (uint32_t)((const uint16_t *)piv)[k];
     }
     // entries [i & ~3, (i & ~3) + 4) in one access (16 / 8 bytes, aligned to 4 entries); entries past the end of
     // the list are garbage the callers never use (the allocations are padded)
@@ -266,6 +284,17 @@ struct ListView {
         return w;
     }
 };
+
+// the view of a list held in one buffer (self tests): entries at cl, pivots (when the list has them) piv_off entries further on
+PW_HD ListView list_view_of(const void *cl, uint32_t wide, uint32_t n_cl, uint32_t piv_off) {
+    ListView v{cl, wide};
+    if (piv_off && list_has_pivots(wide, n_cl)) {
+        v.piv = wide ? (const void *)((const uint32_t *)cl + piv_off) : (const void *)((const uint16_t *)cl + piv_off);
+        v.npiv = list_pivot_count(wide);
+        v.step = list_pivot_step(wide, n_cl);
+    }
+    return v;
+}
 
 // floor(a / b) for a, b < 2^52, b > 0, through one float64 division (a 64-bit integer division costs ~200
 // instructions on the GPU; this is ~35)
@@ -286,11 +315,29 @@ struct SearchResult {
     uint64_t v_below, v_at;
     bool has_below;
 };
+// The first levels of either search, over the list's pivots: ordinary bisection steps whose probe index is restricted
+// to the pivot entries (k + 1) * step inside [lo, hi) -- the invariants of the search (below = entry lo - 1, at = entry
+// hi) hold after every step, so the plain bisection continues from whatever range is left.
+template <class Eval>
+PW_HD void list_search_pivots(const ListView &cl, const Eval &ev, uint64_t target, uint32_t &lo, uint32_t &hi, SearchResult &r) {
+    uint32_t klo = 0, khi = cl.npiv;
+    while (klo < khi) {
+        const uint32_t km = (klo + khi) >> 1;
+        const uint32_t ik = (km + 1u) * cl.step;     // (< hi: hi is n or a pivot further right)
+        if (ik < lo) { klo = km + 1u; continue; }    // left of the range asked for: nothing to learn
+        const uint32_t P = cl.pivot(km);
+        const uint64_t v = ev(ik, P);
+        if (v >= target) { khi = km; hi = ik; r.p_at = P; r.v_at = v; }
+        else { klo = km + 1u; lo = ik + 1u; r.p_below = P; r.v_below = v; r.has_below = true; }
+    }
+}
+
 template <class Eval>
 PW_HD SearchResult list_search(const ListView &cl, uint32_t lo_min, uint32_t n, const Eval &ev, uint64_t target, uint32_t &reads) {
     SearchResult r;
     r.p_below = 0; r.v_below = 0; r.has_below = false; r.p_at = 0xffffffffu; r.v_at = 0;
     uint32_t lo = lo_min, hi = n;
+    if (cl.npiv) list_search_pivots(cl, ev, target, lo, hi, r);
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         const uint32_t P = cl.at(mid);
@@ -312,6 +359,8 @@ PW_HD SearchResult list_search_wide(const ListView &cl, uint32_t lo_min, uint32_
     SearchResult r;
     r.p_below = 0; r.v_below = 0; r.has_below = false; r.p_at = 0xffffffffu; r.v_at = 0;
     uint32_t lo = lo_min, hi = n;   // invariants: below = entry lo - 1 (when has_below), at = entry hi (when hi < n)
+    // (the pivots are NOT used here: their bisection is one dependent probe per level, this search resolves two levels per
+    //  round trip -- with pivots the FLOATS form at RMAT-22 went from 963 to 1053 ms per pass)
     while (hi - lo >= 3u && hi > lo) {
         const uint32_t m2 = lo + ((hi - lo) >> 1);
         const uint32_t m1 = lo + ((m2 - lo) >> 1);

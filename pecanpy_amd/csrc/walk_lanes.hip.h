@@ -1099,6 +1099,28 @@ __device__ __forceinline__ uint32_t list_units(const ELine *lines, uint64_t e) {
     return (r0.y * (list_is_narrow(r0.w) ? 2u : 4u) + 15u) >> 4;
 }
 
+// PIVOTS of the lists that live in the overflow array, written into the unused inline area of their lines after the FILL
+// pass (seqscan.h: ListView / list_search_pivots): entry (k + 1) * step of the list, k = 0 .. 19 (9 for uint32 lists)
+__global__ void __launch_bounds__(256)
+eline_pivots_kernel(ELine *lines, const uint8_t *__restrict__ clist, uint32_t n_lines) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_lines) return;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    if (r0.x == NOT_FOUND) return;                    // (an overflow line without a target)
+    const uint32_t n_in = r0.y, d = r0.w;
+    if (list_is_inline(d, n_in)) return;
+    const uint32_t wide = list_is_narrow(d) ? 0u : 1u;
+    if (!list_has_pivots(wide, n_in)) return;
+    const uint32_t np = list_pivot_count(wide), step = list_pivot_step(wide, n_in);
+    const uint8_t *p = clist + (uint64_t)lines[e].coff * 16u;
+    uint8_t *dst = (uint8_t *)(lines + e) + 24;
+    for (uint32_t k = 0; k < np; k++) {
+        const uint32_t idx = (k + 1u) * step;
+        if (wide) ((uint32_t *)dst)[k] = ((const uint32_t *)p)[idx];
+        else ((uint16_t *)dst)[k] = ((const uint16_t *)p)[idx];
+    }
+}
+
 constexpr int CL_BLOCK = 256;
 constexpr int CL_ITEMS = 16;
 constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;

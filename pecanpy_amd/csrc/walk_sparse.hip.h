@@ -46,7 +46,8 @@ struct ELine {
     uint32_t deg;       // degree(v)       (these four words: the record walk_kernel's lazy step reads)
     uint32_t s0;        // indptr[v]
     uint32_t coff;      // list in the overflow array: offset in 16-byte units (n_in > EL_INLINE or degree(v) > 65536)
-    uint16_t inl[20];   // the list itself when n_in <= EL_INLINE and degree(v) <= 65536: uint16 positions in row v
+    uint16_t inl[20];   // the list itself when n_in <= EL_INLINE and degree(v) <= 65536: uint16 positions in row v;
+                        // otherwise the list's PIVOTS (seqscan.h): every (n_in / 21)-th entry, 20 of them (10 uint32 for wider rows)
 };
 static_assert(sizeof(ELine) == 64, "edge line is one 64-byte sector");
 constexpr uint32_t EL_INLINE = 20;
@@ -55,8 +56,15 @@ constexpr uint32_t EL_INLINE = 20;
 __device__ __forceinline__ ListView edge_list(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t d, uint32_t n_in,
                                               uint32_t coff) {
     const bool narrow = d <= 65536u;
-    const uint8_t *p = (narrow && n_in <= EL_INLINE) ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
-    return ListView{p, narrow ? 0u : 1u};
+    const bool inl = narrow && n_in <= EL_INLINE;
+    const uint8_t *p = inl ? (const uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+    ListView v{p, narrow ? 0u : 1u};
+    if (!inl && list_has_pivots(v.wide, n_in)) {   // the unused inline area holds the list's pivots (eline_pivots_kernel)
+        v.piv = (const uint8_t *)(lines + e) + 24;
+        v.npiv = list_pivot_count(v.wide);
+        v.step = list_pivot_step(v.wide, n_in);
+    }
+    return v;
 }
 
 struct CsrDev {
