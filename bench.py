@@ -59,6 +59,12 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: chunks per shard whose gathers overlap the next chunk's walk kernel")
+    ap.add_argument("--rank0-share", default="auto",
+                    help="rank 0's shard as a fraction of a uniform one (it also assembles the matrix); 'auto' = the model of "
+                         "DESIGN.md section 6 (0.5 at 8 GPUs), 1 = uniform")
+    ap.add_argument("--gather-mode", choices=("rccl", "peer"), default="rccl",
+                    help="rccl: send/recv into row slices + scatter on rank 0; peer: every rank writes its rows into rank 0's "
+                         "matrix itself (CUDA IPC mapping, stores over xGMI; no receive-side work)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: leave the walk shards on their GPUs (skip the gather on rank 0)")
     return ap.parse_args()
@@ -156,7 +162,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from pecanpy_amd.engine import WalkEngine, shard_bounds, tapered_bounds
+    from pecanpy_amd.engine import WalkEngine, auto_rank0_share, shard_bounds, tapered_bounds
     from pecanpy_amd.synth import rmat_csr
 
     cfg = dict(CONFIGS[args.config])
@@ -181,7 +187,9 @@ def main():
         indptr, indices, data = rmat_csr(cfg["scale"], seed=1, weighted=cfg["weighted"])
         n_nodes = indptr.size - 1
         t_graph = time.time() - t0
+        t_create = time.perf_counter()
         eng = WalkEngine.from_csr(indptr, indices, data, device=local_rank)
+        create_wall_ms = (time.perf_counter() - t_create) * 1e3   # the whole of pw_csr_create as the caller sees it
         if extend:
             from pecanpy_amd import pecanpy as node2vec
 
@@ -198,7 +206,9 @@ def main():
         bits, deg_t = er_bits_gpu(n_nodes, cfg["density"], dev)
         torch.cuda.synchronize()
         t_graph = time.time() - t0
+        t_create = time.perf_counter()
         eng = WalkEngine.from_dense_bits(bits, n_nodes, device=local_rank)
+        create_wall_ms = (time.perf_counter() - t_create) * 1e3
         del bits
         has_nbr = (deg_t > 0).cpu().numpy()
         nnz = int(deg_t.sum().item())
@@ -211,12 +221,13 @@ def main():
     n_jobs = starts.size
     t_prep = time.time() - t0
 
-    all_bounds = shard_bounds(n_jobs, world)
+    do_gather = world > 1 and not args.no_gather
+    rank0_share = auto_rank0_share(world, do_gather) if args.rank0_share == "auto" else float(args.rank0_share)
+    all_bounds = shard_bounds(n_jobs, world, rank0_share)
     lo, hi = all_bounds[rank]
     d_starts = torch.from_numpy(starts[lo:hi].view(np.int32)).to(dev)
     # stream address of this shard (undirected graph: nominal counts are exact)
     skip = int(has_nbr[starts[:lo]].sum()) * L
-    do_gather = world > 1 and not args.no_gather
     # N > 1 with gather: the shard is walked in a few chunks and the gather of chunk c (async, on RCCL's
     # stream) overlaps the walk kernel of chunk c + 1; --gather-chunks 1 = one blocking gather at the end
     n_chunks = max(1, args.gather_chunks) if do_gather else 1
@@ -230,14 +241,25 @@ def main():
     gather = None
     job_has_nbr = has_nbr[starts]
     if do_gather:
-        from pecanpy_amd.sharding import RowGather, isolated_row_filler
+        from pecanpy_amd.sharding import PeerRowWriter, RowGather, isolated_row_filler
 
         fill = isolated_row_filler(starts, L, cdev)
-
-        def new_gather():
-            return RowGather(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
-
-        gather = new_gather()          # (allocates the matrix on rank 0: outside the timed region, like d_out)
+        gather_mode = args.gather_mode if cdev == dev else "rccl"
+        if gather_mode == "peer":
+            # every rank must end up in the same mode: agree on whether the IPC mapping worked everywhere
+            try:
+                gather = PeerRowWriter(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
+                ok = 1
+            except Exception as exc:   # noqa: BLE001 (any failure of the mapping: fall back, loudly)
+                print(f"bench.py rank {rank}: peer gather unavailable ({exc!r}); falling back to RCCL send/recv", file=sys.stderr)
+                gather, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                gather, gather_mode = None, "rccl"
+        if gather is None:
+            gather = RowGather(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
+        # (the matrix is allocated on rank 0 here: outside the timed region, like d_out)
     if do_gather and rank == 0 and cdev == dev:
         d_out = gather.own_rows()
     else:
@@ -486,13 +508,21 @@ def main():
             "nominal_value": round(int(n_jobs) * L / sec_per_step / 1e6, 3),
             "parallelism": f"jobs sharded over {world} GPU(s), graph replicated",
             "gather_on_rank0": bool(do_gather), "gather_chunks": n_chunks if do_gather else 0,
+            "gather_mode": (gather_mode if do_gather else None), "rank0_share": round(rank0_share, 3),
+            "shard_jobs": [b[1] - b[0] for b in all_bounds],
             "per_rank_walk_kernel_ms": [round(x, 3) for x in rank_ms],
             "overflow_reads": st["overflow_reads"], "host_prep_s": round(t_prep, 1),
             "graph_gen_s": round(t_graph, 1),
             # per-graph index built once by pw_csr_create (membership filters, adjacency index, per-edge
             # common-neighbour lists and records); NOT in the timed region -- the second figure charges it to
             # ONE pass of 10 x 80 walks (every rank builds its own replica)
+            # graph_index_build_ms = device time of the index KERNELS (event pairs around them); graph_create_wall_ms =
+            # wall clock of the whole handle creation as the caller sees it -- HIP runtime start-up in a fresh process,
+            # host passes over the CSR, its H2D copy, device allocations (a fresh box's first multi-GB hipMalloc can take
+            # > 100 ms) and the kernels; value_first_call charges THAT and one pass to one 10 x 80 run
             "graph_index_build_ms": round(info["build_ms"], 1),
+            "graph_create_wall_ms": round(create_wall_ms, 1),
+            "value_first_call": round(total_steps / (sec_per_step + create_wall_ms * 1e-3 + param_index_ms[0] * 1e-3) / 1e6, 3),
             # index that depends on (p, q, extend), built inside the first (warm-up) call and cached in the handle:
             # per-edge normalisers of weighted graphs
             "param_index_build_ms": round(param_index_ms[0], 1),

@@ -107,7 +107,8 @@ struct pw_graph {
     double tot_build_ms = 0;
     double param_ms_call = 0;                           // (p, q)-dependent index time of the current call
     uint64_t n_clist = 0;
-    double index_build_ms = 0;                          // device time of all index kernels of pw_csr_create
+    double index_build_ms = 0;                          // device time of all index KERNELS of pw_csr_create (event pairs around them)
+    double create_wall_ms = 0;                          // wall clock of pw_csr_create: runtime start-up, host passes, H2D, allocations, kernels
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
     uint32_t words_per_row = 0;
     hipStream_t stream = nullptr;
@@ -284,33 +285,64 @@ static pw::CsrDev csr_dev(const pw_graph *g);
 // adjacent pair, row of the larger endpoint in LDS (lane_lists_kernel: count pass, offsets, fill pass).  Skipped (the
 // wave-per-walk kernel then serves every call, eager step) when lines + lists would take more than half of the free
 // device memory.  `indptr` = the caller's host array.
-static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t *d_edge_row) {
-    if (!g->nnz) return 0;
-    const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
-    // work items: one per (vertex, segment of its row, chunk of its neighbours)
+// Work items of the lane-index build: one per (vertex, segment of its row, chunk of its neighbours), the longest rows
+// first.  Needs the host indptr only: pw_csr_create computes them on a helper thread while the runtime starts up and the
+// CSR travels to the device.
+struct LaneWorkItems {
     std::vector<pw::LaneBuildItem> small, large;
     uint64_t segcnt_total = 0;
+};
+static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneWorkItems &w) {
     const uint32_t JCHUNK = 16384;
     for (uint32_t h = 0; h < n_nodes; h++) {
         const uint32_t d = indptr[h + 1] - indptr[h];
         if (d < 2) continue;   // one neighbour k: N(h) & N(k) = {k} & N(k) is empty without self loops
-        if (d <= (uint32_t)pw::LB_SMALL) { small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
+        if (d <= (uint32_t)pw::LB_SMALL) { w.small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
         const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
         uint32_t m0 = 0;
-        if (nseg > 1) { m0 = (uint32_t)segcnt_total; segcnt_total += (uint64_t)d * nseg; }
+        if (nseg > 1) { m0 = (uint32_t)w.segcnt_total; w.segcnt_total += (uint64_t)d * nseg; }
         for (uint32_t sg = 0; sg < nseg; sg++)
-            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
+            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) w.large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
     }
+    // the longest rows first (their workgroups run longest)
+    std::stable_sort(w.large.begin(), w.large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
+        return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];
+    });
+}
+
+// device time of a group of index kernels: g->ev[2] / g->ev[3] around it, added to g->index_build_ms once it has run
+#define INDEX_KERNELS_BEGIN(g) (void)hipEventRecord((g)->ev[2], (g)->stream)
+#define INDEX_KERNELS_END(g)                                                                                     \
+    do {                                                                                                         \
+        (void)hipEventRecord((g)->ev[3], (g)->stream);                                                           \
+        if (hipEventSynchronize((g)->ev[3]) == hipSuccess) {                                                     \
+            float ms_ = 0;                                                                                       \
+            if (hipEventElapsedTime(&ms_, (g)->ev[2], (g)->ev[3]) == hipSuccess) (g)->index_build_ms += ms_;     \
+        }                                                                                                        \
+    } while (0)
+
+static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d_edge_row) {
+    if (!g->nnz) return 0;
+    const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
+    const bool dbg = getenv("PECANPY_AMD_CREATE_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto stamp = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(g->stream);
+        const double t = now();
+        fprintf(stderr, "[create]   lane index: %-22s %8.2f ms\n", what, (t - t_last) * 1e3);
+        t_last = t;
+    };
+    std::vector<pw::LaneBuildItem> &small = items.small, &large = items.large;
+    const uint64_t segcnt_total = items.segcnt_total;
     if (segcnt_total >= 0xffffffffull) return 0;   // (rows this long and this many: no lane index)
     // + one OVERFLOW line per vertex (walk_lanes.hip.h: vline_init_kernel): the pair of its mirrored choice == degree read
     const bool vlines = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
     const uint32_t n_lines = vlines ? nnz + n_nodes : nnz;
-    // the longest rows first (their workgroups run longest)
-    std::stable_sort(large.begin(), large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
-        return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];
-    });
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
+    stamp("hipMemGetInfo");
     const uint64_t line_bytes = (uint64_t)n_lines * sizeof(pw::ELine) + 64;
     if (line_bytes > free_b / 2) return 0;
     pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
@@ -341,6 +373,7 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     if (e == hipSuccess && !large.empty())
         e = hipMemcpyAsync(d_large, large.data(), sizeof(pw::LaneBuildItem) * large.size(), hipMemcpyHostToDevice, g->stream);
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index: ") + hipGetErrorString(e)));
+    stamp("hipMalloc + item upload");
     pw::CsrDev c = csr_dev(g);
     pw::LaneBuildArgs ba;
     ba.indptr = g->d_indptr;
@@ -348,6 +381,7 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     ba.lines = g->d_lines;
     ba.clist = nullptr;
     ba.segcnt = d_segcnt;
+    INDEX_KERNELS_BEGIN(g);
     hipLaunchKernelGGL(pw::eline_init_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c, d_edge_row, g->d_lines);
     if (vlines) hipLaunchKernelGGL(pw::vline_init_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, g->stream, c, g->d_lines);
     const unsigned vgrid = (unsigned)(((uint64_t)n_nodes * pw::WAVE + 255) / 256);
@@ -374,21 +408,28 @@ static int build_lane_index(pw_graph *g, const uint32_t *indptr, const uint32_t 
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&units, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&entries, d_etiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (count pass): ") + hipGetErrorString(e)));
+    stamp("count pass + offsets");
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t list_bytes = units * 16 + 64;
     if (units >= 0xffffffffull || list_bytes > free_b / 2) return drop(0);   // leave room for the stream and the walk matrix
     e = hipMalloc((void **)&g->d_clist, list_bytes);
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e)));
+    stamp("hipMalloc of the lists");
     ba.clist = g->d_clist;
+    INDEX_KERNELS_BEGIN(g);
     lists(true);
     hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines,
                        g->d_clist, n_lines);
     e = hipGetLastError();
+    INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (fill pass): ") + hipGetErrorString(e)));
+    stamp("fill pass + pivots");
     cleanup();
+    stamp("hipFree of the scratch");
     g->n_clist = entries;
     g->vlines = vlines;
     g->clist_bytes = list_bytes;
@@ -401,9 +442,28 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (!indptr || !out || (nnz && !indices)) return fail(PW_ERR_INVALID, "null pointer");
     if (indptr[0] != 0) return fail(PW_ERR_INVALID, "indptr[0] != 0");
     if (indptr[n_nodes] != nnz) return fail(PW_ERR_INVALID, "indptr[n_nodes] != nnz");
+    const bool dbg = getenv("PECANPY_AMD_CREATE_DEBUG") != nullptr;   // wall-clock stamps of the stages on stderr
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_last = t_begin;
+    auto stamp = [&](const char *what) {
+        if (!dbg) return;
+        const double t = now();
+        fprintf(stderr, "[create] %-34s %8.2f ms (at %8.2f)\n", what, (t - t_last) * 1e3, (t - t_begin) * 1e3);
+        t_last = t;
+    };
+    // the lane index's work items need the host indptr only: a helper thread makes them while the runtime starts and the CSR
+    // is copied (validated below before anyone relies on them: a non-monotone indptr returns before the items are used)
+    LaneWorkItems items;
+    bool monotone = true;
+    for (uint32_t i = 0; i < n_nodes && monotone; i++) monotone = indptr[i + 1] >= indptr[i];
+    if (!monotone) return fail(PW_ERR_INVALID, "indptr not monotone");
+    std::thread item_thread([&]() { if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{item_thread};
     pw_graph *g = new pw_graph();
     int rc = graph_common_init(g, device);
     if (rc) { pw_graph_destroy(g); return rc; }
+    stamp("runtime / streams / events");
     g->kind = 0;
     g->n_nodes = n_nodes;
     g->nnz = nnz;
@@ -439,6 +499,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
     if (!rc && data) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
     if (rc) { pw_graph_destroy(g); return rc; }
+    stamp("host pass + H2D of the CSR");
 
     // ---- device side: validation, weight scan, membership index ------------------------------------------------
     uint32_t *d_edge_row = nullptr;
@@ -454,13 +515,15 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 4 * sizeof(unsigned long long));
     unsigned long long h_flags[4] = {~0ull, ~0ull, 0ull, 0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, g->stream);
-    if (e == hipSuccess) e = hipEventRecord(g->ev[0], g->stream);
+    g->index_build_ms = 0;
+    INDEX_KERNELS_BEGIN(g);
     if (e == hipSuccess && nnz) {
         hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, n_nodes, d_edge_row);
         hipLaunchKernelGGL(pw::csr_validate_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream,
                            g->d_indptr, g->d_indices, (const float *)g->d_data, d_edge_row, n_nodes, nnz, d_flags);
         e = hipGetLastError();
     }
+    INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("CSR validation: ") + hipGetErrorString(e));
@@ -477,6 +540,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
                                         "): column indices must be strictly ascending within a row (sorted, no duplicates), "
                                         "as the reference's to_csr produces them (graph.py:336)");
     }
+    stamp("validation kernels");
     g->unit = !(data && h_flags[2]);
     if (g->unit && g->d_data) { (void)hipFree(g->d_data); g->d_data = nullptr; }   // unit weights are never read
     const bool has_loop = h_flags[3] != 0;
@@ -492,6 +556,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (e == hipSuccess) e = hipMemsetAsync(g->d_slots, 0xff, sizeof(uint64_t) * (trun ? trun : 1), g->stream);
     if (e != hipSuccess) return bail(PW_ERR_NOMEM, std::string("membership index: ") + hipGetErrorString(e));
     g->index_bytes = sizeof(uint64_t) * (frun + trun) + sizeof(uint2) * (uint64_t)nnz + sizeof(uint4) * ((uint64_t)n_nodes + 1);
+    INDEX_KERNELS_BEGIN(g);
     hipLaunchKernelGGL(pw::vrec_build_kernel, dim3((n_nodes + 256) / 256), dim3(256), 0, g->stream, g->d_indptr, g->d_foff,
                        g->d_tab_off, n_nodes, g->d_vrec);
     if (n_nodes && nnz)
@@ -499,19 +564,21 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
                            g->d_indptr, g->d_indices, d_edge_row, g->d_foff, g->d_tab_off, (unsigned long long *)g->d_fbits, g->d_kf,
                            (unsigned long long *)g->d_slots, nnz, 4294967296.0 / (double)nnz);
     e = hipGetLastError();
+    INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
+    stamp("membership index");
     if (nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {   // (weighted graphs too: membership does not depend on the weights)
         // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel); skipped for
         // graphs with self loops, where "common neighbour" and the reference's prev handling differ
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
-        rc = build_lane_index(g, indptr, d_edge_row);
+        item_thread.join();
+        rc = build_lane_index(g, items, d_edge_row);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
-    (void)hipEventRecord(g->ev[1], g->stream);
     (void)hipStreamSynchronize(g->stream);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, g->ev[0], g->ev[1]) == hipSuccess) g->index_build_ms = ms;
+    stamp("lane index");
+    g->create_wall_ms = (now() - t_begin) * 1e3;
     (void)hipFree(d_edge_row);
     (void)hipFree(d_flags);
     *out = g;

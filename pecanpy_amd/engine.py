@@ -14,16 +14,35 @@ import numpy as np
 from . import _lib
 from ._lib import MODE_IDS, PwError, PwStats
 
-__all__ = ["WalkEngine", "shard_bounds", "PwError"]
+__all__ = ["WalkEngine", "shard_bounds", "auto_rank0_share", "tapered_bounds", "PwError"]
 
 
 def _np_ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
 
 
-def shard_bounds(n_jobs, world_size):
-    """Contiguous job ranges [lo, hi) per rank."""
-    return [((r * n_jobs) // world_size, ((r + 1) * n_jobs) // world_size) for r in range(world_size)]
+def shard_bounds(n_jobs, world_size, rank0_share=None):
+    """Contiguous job ranges [lo, hi) per rank.
+
+    ``rank0_share`` (default 1.0 = uniform): rank 0's shard as a fraction of a uniform one.  Rank 0 is where the walk
+    matrix is assembled -- it also writes the rows nobody sends and scatters what arrives -- so giving it fewer jobs to
+    walk takes that work off the pass's critical path (``auto_rank0_share``); the other ranks share the rest evenly."""
+    if rank0_share is None or world_size <= 1 or rank0_share == 1.0:
+        return [((r * n_jobs) // world_size, ((r + 1) * n_jobs) // world_size) for r in range(world_size)]
+    share = min(max(float(rank0_share), 0.0), float(world_size))
+    n0 = min(n_jobs, int(round(share * n_jobs / world_size)))
+    rest = n_jobs - n0
+    cuts = [0, n0] + [n0 + ((r * rest) // (world_size - 1)) for r in range(1, world_size)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def auto_rank0_share(world_size, gather=True):
+    """Rank 0's share of a uniform shard when it assembles the matrix (model of DESIGN.md section 6: at 8 GPUs its
+    prefill of the other shards' isolated rows, the receive kernels and the scatter of 7/8 of the rows cost about half
+    of a 1/8 shard's walk time; nothing extra at 1 GPU, proportionally less in between)."""
+    if not gather or world_size <= 1:
+        return 1.0
+    return max(0.4, 1.0 - 0.5 * (min(world_size, 8) - 1) / 7.0)
 
 
 def tapered_bounds(n_jobs, n_chunks):

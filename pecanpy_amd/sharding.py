@@ -9,9 +9,9 @@ MT19937 stream, obtained from an all-gather of per-shard draw counts.
 """
 import numpy as np
 
-from .engine import shard_bounds
+from .engine import auto_rank0_share, shard_bounds
 
-__all__ = ["sharded_walk_matrix", "shard_bounds", "RowGather", "isolated_row_filler"]
+__all__ = ["sharded_walk_matrix", "shard_bounds", "auto_rank0_share", "RowGather", "PeerRowWriter", "isolated_row_filler"]
 
 
 def _dist():
@@ -45,6 +45,9 @@ class RowGather:
         self.device = device
         self.full = torch.empty((n_rows, width), dtype=dtype, device=device) if self.rank == dst else None
         self._works, self._scatters, self._sent = [], [], []
+        self._side = None      # CUDA receiver: side stream on which every piece is scattered as soon as IT has landed
+        if self.rank == dst and torch.device(device).type == "cuda":
+            self._side = torch.cuda.Stream(device=device)
         self._sel_cache = {}
         self._known_idx, self._fill_known = None, fill_known
         if self.rank == dst and self.known is not None and fill_known is not None:
@@ -105,16 +108,111 @@ class RowGather:
                 ops.append(self.dist.P2POp(self.dist.irecv, stage, src, self.group))
                 self._scatters.append((sel, stage))
         if ops:
-            self._works += self.dist.batch_isend_irecv(ops)
+            works = self.dist.batch_isend_irecv(ops)
+            group_scatters, self._scatters = self._scatters, []
+            if self._side is not None and group_scatters:
+                # scatter THIS group's pieces as soon as its receives are over, on the side stream: work.wait() on a
+                # CUDA stream is a stream-level dependency, the host goes on to walk the next chunk, and at the end of
+                # the pass only the last (smallest) group's scatter is left -- not all of them (round 3's finish())
+                with torch.cuda.stream(self._side):
+                    for w in works:
+                        w.wait()
+                    for idx, stage in group_scatters:
+                        self.full.index_copy_(0, idx, stage)
+                        stage.record_stream(self._side)
+                self._works += works        # (finish() still waits for them: direct row-slice receives have no scatter)
+            else:
+                self._works += works
+                self._pending = getattr(self, "_pending", []) + group_scatters
 
     def finish(self):
         """Waits for every transfer; the receiver then holds the complete matrix (returned; others get None)."""
         for w in self._works:
             w.wait()
-        for idx, stage in self._scatters:
+        for idx, stage in getattr(self, "_pending", []):   # (CPU receiver / no side stream: scatter now)
             self.full.index_copy_(0, idx, stage)
+        self._pending = []
+        if self._side is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._works, self._scatters, self._sent = [], [], []
         return self.full
+
+
+class PeerRowWriter:
+    """The same assembly WITHOUT receive-side work: rank ``dst`` shares its preallocated ``[n_rows, width]`` matrix with
+    the other ranks of the node (CUDA IPC: every process maps the allocation; xGMI peer access), and every sender
+    WRITES its rows into the matrix itself -- ``full[idx] = rows`` is one scatter kernel on the SENDER's GPU whose stores
+    travel over the sender's xGMI link to rank ``dst``.  Rank ``dst`` runs no receive kernels, allocates no staging
+    tensors and scatters nothing: it only walks its own shard and prefills the rows nobody sends.  Same interface as
+    ``RowGather`` (``post`` / ``expect`` / ``finish`` / ``prefill`` / ``own_rows``); ``expect`` is a no-op.
+    Selected by ``bench.py --gather-mode peer``; the RCCL send/recv form stays the default until an 8-GPU run has
+    compared them (single node, CUDA tensors and the nccl backend only)."""
+
+    def __init__(self, n_rows, width, bounds, dtype, device, dst=0, group=None, known=None, fill_known=None):
+        import torch
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        self.dist = _dist()
+        self.torch = torch
+        self.group, self.dst = group, dst
+        self.rank = self.dist.get_rank(group)
+        self.bounds = bounds
+        self.known = None if known is None else np.asarray(known, dtype=bool)
+        self.device = device
+        if torch.device(device).type != "cuda":
+            raise ValueError("PeerRowWriter needs CUDA tensors (peer writes over xGMI)")
+        self._owner = torch.empty((n_rows, width), dtype=dtype, device=device) if self.rank == dst else None
+        handle = [reduce_tensor(self._owner) if self.rank == dst else None]
+        self.dist.broadcast_object_list(handle, src=dst, group=group)
+        if self.rank == dst:
+            self.full = self._owner
+        else:
+            rebuild, args = handle[0]
+            args = list(args)
+            args[6] = torch.cuda.current_device()     # (storage device index: the mapping lives in THIS process's context)
+            self.full = rebuild(*args)                # dst's matrix, mapped into this process: stores go over xGMI
+        self._sel_cache = {}
+        self._known_idx, self._fill_known = None, fill_known
+        if self.rank == dst and self.known is not None and fill_known is not None:
+            lo, hi = bounds[dst]
+            other = self.known.copy()
+            other[lo:hi] = False
+            self._known_idx = torch.from_numpy(np.flatnonzero(other)).to(device)
+        self.prefill()
+
+    def prefill(self):
+        if self._known_idx is not None and self._known_idx.numel():
+            self._fill_known(self.full, self._known_idx)
+
+    def own_rows(self):
+        lo, hi = self.bounds[self.dst]
+        return self.full[lo:hi]
+
+    def post(self, lo, hi, rows):
+        """Sender: writes its rows [lo, hi) (minus the known ones) into rank dst's matrix, on its own current stream."""
+        if hi <= lo or self.rank == self.dst:
+            return
+        sel = None
+        if self.known is not None:
+            key = (lo, hi)
+            if key not in self._sel_cache:
+                k = self.known[lo:hi]
+                self._sel_cache[key] = None if not k.any() else self.torch.from_numpy(np.flatnonzero(~k)).to(rows.device)
+            sel = self._sel_cache[key]
+        if sel is None:
+            self.full[lo:hi].copy_(rows, non_blocking=True)
+        elif sel.numel():
+            self.full.index_copy_(0, sel + lo, rows.index_select(0, sel))
+
+    def expect(self, pieces):
+        return None
+
+    def finish(self):
+        """Every rank: its own writes are over (device synchronize), then a barrier -- after it rank dst's matrix is
+        complete.  Returns the matrix on rank dst, None elsewhere."""
+        self.torch.cuda.synchronize()
+        self.dist.barrier(group=self.group)
+        return self.full if self.rank == self.dst else None
 
 
 def isolated_row_filler(starts, walk_length, device):
@@ -132,7 +230,7 @@ def isolated_row_filler(starts, walk_length, device):
 
 
 def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None, dst=None,
-                        max_rounds=None, gather=True):
+                        max_rounds=None, gather=True, bounds=None):
     """Walk ``starts`` cooperatively across the ranks of ``group``.
 
     run_shard(starts_slice, stream_skip) -> (walks, actual_draws)
@@ -151,7 +249,8 @@ def sharded_walk_matrix(run_shard, count_draws, starts, walk_length, group=None,
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_jobs = int(starts.shape[0])
-    bounds = shard_bounds(n_jobs, world)
+    if bounds is None:
+        bounds = shard_bounds(n_jobs, world)      # (uneven bounds -- e.g. a smaller shard for the assembling rank -- may be passed in)
     lo, hi = bounds[rank]
     mine = starts[lo:hi]
 

@@ -126,7 +126,7 @@ def test_unseeded_ranks_shuffle_the_same_job_array():
         assert np.array_equal(np.bincount(ret["starts0"], minlength=n), np.full(n, 3))
 
 
-def _gather_worker(rank, world, port, ret):
+def _gather_worker(rank, world, port, ret, share=None):
     """bench.py's data path: every shard walked in chunks, each chunk's rows posted while the next is walked; rows of
     isolated starts are not sent (rank 0 writes them itself); rank 0 walks its own shard in place."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -137,7 +137,7 @@ def _gather_worker(rank, world, port, ret):
     starts = orc.shuffled_starts(indptr.size - 1, 3, seed)
     has = (indptr[1:] != indptr[:-1])[starts]
     n_jobs = starts.size
-    bounds = shard_bounds(n_jobs, world)
+    bounds = shard_bounds(n_jobs, world, share)   # (share: a smaller shard for rank 0, which also assembles the matrix)
     dev = torch.device("cpu")
     rg = RowGather(n_jobs, L + 2, bounds, torch.int32, dev, dst=0, known=~has, fill_known=isolated_row_filler(starts, L, dev))
     lo, hi = bounds[rank]
@@ -160,6 +160,7 @@ def _gather_worker(rank, world, port, ret):
         want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, L, seed)
         ret["ok"] = bool(np.array_equal(to_uint32_numpy(full), want))
         ret["isolated"] = int((~has).sum())
+        ret["shards"] = [hi_ - lo_ for lo_, hi_ in bounds]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -170,3 +171,62 @@ def test_chunked_gather_into_row_slices_skipping_isolated_rows(world):
     ret = mgr.dict()
     mp.spawn(_gather_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret["ok"] and ret["isolated"] > 0
+
+
+@pytest.mark.parametrize("world,share", [(2, 0.6), (3, 0.4), (3, 0.0)])
+def test_chunked_gather_with_a_smaller_shard_for_the_assembling_rank(world, share):
+    """bench.py --rank0-share: rank 0 walks fewer jobs (it also prefills and scatters); every shard's stream address
+    follows from the bounds alone, so the assembled matrix is the single-stream matrix whatever the split."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, _free_port(), ret, share), nprocs=world, join=True)
+    assert ret["ok"] and ret["isolated"] > 0
+    shards = ret["shards"]
+    assert shards[0] < min(shards[1:]) and max(shards[1:]) - min(shards[1:]) <= 1
+
+
+def test_weighted_shard_bounds():
+    from pecanpy_amd.engine import auto_rank0_share
+
+    for n, w, sh in [(41943040, 8, 0.5), (10, 3, 0.4), (7, 8, 0.5), (100, 2, 0.9), (5, 4, 0.0), (1000, 4, 1.0), (1000, 1, 0.3)]:
+        b = shard_bounds(n, w, sh)
+        assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1)) and all(hi >= lo for lo, hi in b)
+        if w > 1 and sh < 1.0:
+            assert b[0][1] - b[0][0] <= round(sh * n / w) + 1
+            rest = [hi - lo for lo, hi in b[1:]]
+            assert max(rest) - min(rest) <= 1
+    assert shard_bounds(41943040, 8, 1.0) == shard_bounds(41943040, 8)
+    assert auto_rank0_share(1) == 1.0 and auto_rank0_share(8) == 0.5 and 0.5 < auto_rank0_share(4) < auto_rank0_share(2) < 1.0
+    assert auto_rank0_share(8, gather=False) == 1.0
+
+
+def _uneven_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    indptr, indices, data = _graph("directed_with_sinks")
+    L, seed = 12, 3
+    starts = orc.shuffled_starts(indptr.size - 1, 3, seed)
+    has = indptr[1:] != indptr[:-1]
+
+    def run_shard(sl, skip):
+        mat = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, sl, L, seed, stream_skip=skip)
+        return torch.from_numpy(mat.view(np.int32).copy()), int((mat[:, -1].astype(np.int64) - 1).sum())
+
+    bounds = shard_bounds(starts.size, world, 0.5)
+    full = sharded_walk_matrix(run_shard, lambda sl: int(has[sl].sum()) * L, starts, L, dst=0, bounds=bounds)
+    if rank == 0:
+        ret["full"] = to_uint32_numpy(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_walk_matrix_with_uneven_bounds_and_dead_ends():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_uneven_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    indptr, indices, data = _graph("directed_with_sinks")
+    starts = orc.shuffled_starts(indptr.size - 1, 3, 3)
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 12, 3)
+    assert np.array_equal(ret["full"], want)
