@@ -85,6 +85,11 @@ typedef struct {
     uint64_t verify_mismatch;   /* of those, steps where the chain picked a different neighbour (must be 0) */
     uint64_t verify_dropped;    /* steps not recorded because the record buffer was full */
     uint64_t verify_ties;       /* steps the chain declined (rounding-tie budget): not compared */
+    /* partial lane index (the byte budget left the longest common-neighbour lists out, see pw_csr_create) */
+    uint64_t eager_steps;       /* lane-kernel steps that arrived by an entry without a stored list: decided by one wavefront each
+                                   (lanes_eager_kernel: membership searched), the walk resumed in the lane kernel */
+    uint32_t index_max_list;    /* longest list the index stores beyond the edge lines (0xffffffff: all of them; 0: no lane index) */
+    uint32_t reserved0;
 } pw_stats;
 
 /* ---- introspection ------------------------------------------------------------------- */
@@ -102,7 +107,10 @@ int pw_device_count(void);
  * Limits: the 32-bit offsets of the index allow about 2^33 hash slots, i.e. graphs up to ~2 * 10^9 CSR
  * entries (PW_ERR_INVALID "graph too large" beyond that; the reference's own limit is nnz < 2^32).
  * Environment: PECANPY_AMD_NO_LAZY=1 skips the per-edge records (every step then takes the eager path;
- * used by the test-suite to cross-check the two step implementations). */
+ * used by the test-suite to cross-check the two step implementations).  PECANPY_AMD_INDEX_BUDGET=<bytes> bounds the
+ * overflow array of the common-neighbour lists (default: half of the free device memory): beyond it the index is
+ * PARTIAL -- edge lines always, the longest lists left out -- and steps that arrive by an entry without its list are
+ * decided by one wavefront each (pw_stats.eager_steps) while the walk stays in the lane kernel. */
 int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *data,
                   uint32_t n_nodes, uint32_t nnz, int device, pw_graph **out);
 

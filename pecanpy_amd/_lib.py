@@ -35,6 +35,9 @@ class PwStats(C.Structure):
         ("verify_mismatch", C.c_uint64),
         ("verify_dropped", C.c_uint64),
         ("verify_ties", C.c_uint64),
+        ("eager_steps", C.c_uint64),
+        ("index_max_list", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -107,6 +107,7 @@ struct pw_graph {
     double tot_build_ms = 0;
     double param_ms_call = 0;                           // (p, q)-dependent index time of the current call
     uint64_t n_clist = 0;
+    uint32_t list_max_len = 0xffffffffu;                // partial index: lists longer than this were left out (EL_NO_LIST)
     double index_build_ms = 0;                          // device time of all index KERNELS of pw_csr_create (event pairs around them)
     double create_wall_ms = 0;                          // wall clock of pw_csr_create: runtime start-up, host passes, H2D, allocations, kernels
     uint64_t index_bytes = 0;                           // device bytes of the membership / lane index
@@ -381,6 +382,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     ba.lines = g->d_lines;
     ba.clist = nullptr;
     ba.segcnt = d_segcnt;
+    ba.max_len = 0xffffffffu;
     INDEX_KERNELS_BEGIN(g);
     hipLaunchKernelGGL(pw::eline_init_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c, d_edge_row, g->d_lines);
     if (vlines) hipLaunchKernelGGL(pw::vline_init_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, g->stream, c, g->d_lines);
@@ -400,25 +402,69 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
         }
     };
     lists(false);
-    hipLaunchKernelGGL(pw::clist_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, n_lines, nnz, d_tiles, d_etiles);
-    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
-    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_etiles, n_tiles);
-    hipLaunchKernelGGL(pw::clist_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, n_lines, d_tiles);
     uint64_t units = 0, entries = 0;
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&units, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&entries, d_etiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    auto offsets = [&](uint32_t max_len) -> hipError_t {   // list offsets (16-byte units) of the lists of at most max_len entries
+        hipLaunchKernelGGL(pw::clist_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, n_lines, nnz, d_tiles, d_etiles, max_len);
+        hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
+        hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_etiles, n_tiles);
+        hipLaunchKernelGGL(pw::clist_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, n_lines, d_tiles, max_len);
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&units, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&entries, d_etiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+        return e2;
+    };
+    e = offsets(0xffffffffu);
     INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (count pass): ") + hipGetErrorString(e)));
     stamp("count pass + offsets");
     (void)hipMemGetInfo(&free_b, &total_b);
+    // BYTE BUDGET of the overflow lists: PECANPY_AMD_INDEX_BUDGET (bytes) or half of the free device memory (room for the
+    // stream and the walk matrix).  Over budget the index is PARTIAL: the longest lists are left out (EL_NO_LIST) -- the
+    // longest length whose cumulative bytes fit, from a histogram of the units by list length -- and a step that arrives
+    // by such an entry is taken by lanes_eager_kernel (membership searched, as without an index) while the walk stays in
+    // the lane kernel.  The reference's SparseOTF is O(nnz) memory (pecanpy.py:510-561); this bounds the distance.
+    uint64_t budget = free_b / 2;
+    if (const char *be = getenv("PECANPY_AMD_INDEX_BUDGET")) budget = (uint64_t)strtoull(be, nullptr, 10);
+    uint32_t max_len = 0xffffffffu;
+    if (units * 16 + 64 > budget || units >= 0xffffffffull) {
+        const uint32_t HL = 1u << 17;
+        unsigned long long *d_hist = nullptr;
+        std::vector<unsigned long long> hist(HL);
+        e = hipMalloc((void **)&d_hist, sizeof(unsigned long long) * HL);
+        if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * HL, g->stream);
+        if (e == hipSuccess) {
+            INDEX_KERNELS_BEGIN(g);
+            hipLaunchKernelGGL(pw::clist_length_hist_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream,
+                               g->d_lines, n_lines, d_hist, HL);
+            e = hipGetLastError();
+            INDEX_KERNELS_END(g);
+        }
+        if (e == hipSuccess) e = hipMemcpy(hist.data(), d_hist, sizeof(unsigned long long) * HL, hipMemcpyDeviceToHost);
+        if (d_hist) (void)hipFree(d_hist);
+        if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (length histogram): ") + hipGetErrorString(e)));
+        const uint64_t cap_units = std::min<uint64_t>(budget > 64 ? (budget - 64) / 16 : 0, 0xfffffffeull);
+        uint64_t run = 0;
+        max_len = pw::EL_INLINE;                        // (lists inside their lines are always there)
+        for (uint32_t n = 0; n + 1 < HL; n++) {         // (the last bin pools every longer list: never kept when over budget)
+            if (run + hist[n] > cap_units) break;
+            run += hist[n];
+            if (n > max_len) max_len = n;
+        }
+        INDEX_KERNELS_BEGIN(g);
+        e = offsets(max_len);
+        INDEX_KERNELS_END(g);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (partial offsets): ") + hipGetErrorString(e)));
+        stamp("partial index: histogram + offsets");
+    }
     const uint64_t list_bytes = units * 16 + 64;
-    if (units >= 0xffffffffull || list_bytes > free_b / 2) return drop(0);   // leave room for the stream and the walk matrix
+    if (units >= 0xffffffffull || list_bytes > free_b - free_b / 8) return drop(0);
     e = hipMalloc((void **)&g->d_clist, list_bytes);
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e)));
     stamp("hipMalloc of the lists");
     ba.clist = g->d_clist;
+    ba.max_len = max_len;
     INDEX_KERNELS_BEGIN(g);
     lists(true);
     hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines,
@@ -431,6 +477,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     cleanup();
     stamp("hipFree of the scratch");
     g->n_clist = entries;
+    g->list_max_len = max_len;
     g->vlines = vlines;
     g->clist_bytes = list_bytes;
     g->index_bytes += line_bytes + list_bytes;
@@ -1112,11 +1159,19 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     la.redo_count = g->counters.p + 6;
     la.w_out = wa.w_out;
     la.w_prev = wa.w_prev;
+    // TAILS form (the rest of the edge line staged in LDS): for graphs whose edge lines stay cache resident -- there the
+    // probes of inline lists and pivots are L2 hits that LDS reads replace; beyond that the HBM probes of the long lists
+    // set the pace and the plain form is as fast (PECANPY_AMD_LANE_TAILS = 0 / 1 overrides the size rule)
+    bool tails = (uint64_t)g->nnz * sizeof(pw::ELine) <= (uint64_t)2 << 30;   // (RMAT-18 / -20: 15.0 -> 13.4 / 36.9 -> 34.1 ms; RMAT-22, 4.2 GB of lines: 138.8 -> 139.7)
+    if (const char *te = getenv("PECANPY_AMD_LANE_TAILS")) tails = atoi(te) != 0;
+    if (getenv("PECANPY_AMD_VERIFY_TIGHT")) tails = false;
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     int occ_in = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_in < 1) occ_in = 1;
     const uint64_t lanes_resident = (uint64_t)g->n_cu * (uint64_t)occ * pw::WAVES_PER_BLOCK * pw::WAVE;
     // Steps that need the float32 chain (~1 % on RMAT-22 after lane_tight) are not run in place -- a chain with a few
@@ -1185,8 +1240,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         if (verify) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
         const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
         if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (queue_out && tails) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false>), lgrid, lblock, 0, g->stream, la);
         else if (verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, true>), lgrid, lblock, 0, g->stream, la);
+        else if (tails) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false>), lgrid, lblock, 0, g->stream, la);
         HIP_TRY(hipGetLastError());
         if (verify) {   // the chain decides this round's recorded steps again
@@ -1222,6 +1279,11 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
+            if (g->list_max_len != 0xffffffffu) {   // partial index: the steps whose entry's list was left out (one wavefront each)
+                hipLaunchKernelGGL(pw::lanes_eager_kernel, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa, g->susp[round & 1].p,
+                                   (uint64_t)parked, g->counters.p + 12);
+                HIP_TRY(hipGetLastError());
+            }
         }
         HIP_TRY(hipEventRecord(g->ev[5], g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1371,7 +1433,12 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
     uint64_t per_gen = 1;
     int per_gen_log = 0;
-    while (per_gen * 1024 < n_blocks) { per_gen <<= 1; per_gen_log++; }   // (2048 generators: 7.4 vs 8.0 ms, 4096: 9.2)
+    // generators: each level of the jump tree is a launch or two, each generator expands its blocks one after the other --
+    // short streams want fewer generators (RMAT-18, 381 k blocks: 256 / 512 / 1024 / 2048 / 4096 -> 1.72 / 1.62 / 2.06 /
+    // 2.66 / 3.33 ms), long ones more (RMAT-22, 5.2 M blocks: 1024 / 2048 / 4096 -> 7.8 / 7.2 / 8.9 ms)
+    static const uint64_t gens_env = getenv("PECANPY_AMD_MT_GENS") ? (uint64_t)strtoull(getenv("PECANPY_AMD_MT_GENS"), nullptr, 10) : 0ull;
+    const uint64_t gens_target = gens_env ? gens_env : (n_blocks < (1ull << 21) ? 512ull : 2048ull);
+    while (per_gen * gens_target < n_blocks) { per_gen <<= 1; per_gen_log++; }
     const uint32_t n_gen = (uint32_t)((n_blocks + per_gen - 1) / per_gen);
     if (!g->jump_table_ready) {
         const size_t words = (size_t)(pw::MtJump::MAX_POW2 + 1) * pw::MT_PW;
@@ -1645,6 +1712,8 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.verify_mismatch = g->ver_mismatch;
     st.verify_dropped = g->ver_dropped;
     st.verify_ties = g->ver_ties;
+    st.eager_steps = h[12];
+    st.index_max_list = g->kind == 0 && g->d_lines ? g->list_max_len : 0u;
     if (stats) *stats = st;
     return PW_OK;
 }

@@ -261,10 +261,30 @@ struct ListView {
     const void *piv = nullptr;   // pivots (same entry width), or nullptr
     uint32_t npiv = 0;           // their number (0: none)
     uint32_t step = 0;           // pivot k = entry (k + 1) * step
+    // Lane kernel (PW_LANES_LINE_LDS): bytes 16..63 of the edge line -- row start, list offset and the inline area: the list
+    // itself or its pivots -- were copied to LDS when the step that entered the edge was applied (three 16-byte pieces,
+    // 1024 bytes apart: global_load_lds writes piece c of lane t at base + 1024 c + 16 t).  `tail` = LDS address of this
+    // lane's piece 0; what lives in the line is then read from there instead of from global memory.
+    uint32_t tail = 0xffffffffu; // 0xffffffff: not staged
+    uint32_t inl = 0;            // the list itself lives in the line (p points into it)
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ uint32_t tail_entry(uint32_t i) const {
+        const uint32_t o = 8u + (wide ? i << 2 : i << 1);             // (line offset 24 = tail offset 8)
+        const uint32_t addr = tail + ((o >> 4) << 10) + (o & 15u);
+        return wide ? *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr
+                    : (uint32_t) * (const __attribute__((address_space(3))) uint16_t *)(uintptr_t)addr;
+    }
+#endif
     PW_HD uint32_t at(uint32_t i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (tail != 0xffffffffu && inl) return tail_entry(i);
+#endif
         return wide ? ((const uint32_t *)p)[i] : (uint32_t)((const uint16_t *)p)[i];
     }
     PW_HD uint32_t pivot(uint32_t k) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (tail != 0xffffffffu) return tail_entry(k);
+#endif
         return wide ? ((const uint32_t *)piv)[k] : (uint32_t)((const uint16_t *)piv)[k];
     }
     // entries [i & ~3, (i & ~3) + 4) in one access (16 / 8 bytes, aligned to 4 entries); entries past the end of
@@ -272,6 +292,16 @@ struct ListView {
     PW_HD ListWin window(uint32_t i) const {
         const uint32_t w0 = i & ~3u;
         ListWin w;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (tail != 0xffffffffu && inl) {   // (inline lists are uint16: four entries = one aligned 8-byte LDS read inside a piece)
+            const uint32_t o = 8u + (w0 << 1);
+            const uint32_t addr = tail + ((o >> 4) << 10) + (o & 15u);
+            struct __attribute__((aligned(8))) Raw2 { uint32_t x, y; };
+            const Raw2 raw = *(const __attribute__((address_space(3))) Raw2 *)(uintptr_t)addr;
+            w.v[0] = raw.x & 0xffffu; w.v[1] = raw.x >> 16; w.v[2] = raw.y & 0xffffu; w.v[3] = raw.y >> 16;
+            return w;
+        }
+#endif
         if (wide) {
             struct __attribute__((packed, aligned(4))) Raw { uint32_t v[4]; };
             const Raw raw = *(const Raw *)((const uint32_t *)p + w0);

@@ -58,6 +58,8 @@ struct VerRec {
 static_assert(sizeof(VerRec) == 48, "verification record is three 16-byte stores");
 
 constexpr uint32_t LANE_NEEDS_WAVE = 0xfffffff9u;   // a step only walk_kernel can decide (tie budget, row outside the exact range)
+constexpr uint32_t LANE_EAGER_MARK = 0xffffffffu;   // SuspRec::kmax of a step parked because its entry's list is not in the (partial)
+                                                    // index: lanes_eager_kernel decides it, lanes_chain_kernel leaves it alone
 
 struct LanesArgs {
     const ELine *__restrict__ lines;          // [nnz] edge lines, then [n_nodes] OVERFLOW lines (when vlines != 0)
@@ -153,6 +155,9 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_DRAW_LDS
 #define PW_LANES_DRAW_LDS 0      // 1: a walk's draws are fetched a 64-byte sector (8 draws) at a time, straight into LDS
 #endif
+#ifndef PW_LANES_LINE_LDS
+#define PW_LANES_LINE_LDS 0      // 1: the rest of the edge line a step enters (inline list / pivots) is copied to LDS with the record
+#endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
                               // its share of the work at most)
@@ -191,6 +196,7 @@ __device__ unsigned long long g_lprof[16];
             const uint4 *rp_ = (const uint4 *)(a.lines + A.e);                                  \
             const uint4 r0_ = rp_[0];                                                           \
             const uint2 r1_ = *(const uint2 *)(rp_ + 1);                                        \
+            if (LINE_LDS) { PW_LINE_STAGE(rp_); }                                      \
             {   /* output cells are staged four steps at a time: one 16-byte store instead of four 4-byte ones */ \
                 const uint32_t slot_ = (A.j - 1u) & 3u;                                         \
                 ob.v[0] = slot_ == 0u ? r0_.x : ob.v[0];                                        \
@@ -245,10 +251,19 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // decision leaves open go to the global queue of parked walks from there.  Slots are handed out by rank (r-th deferring
 // lane <- r-th free slot, through a 64-byte map in LDS); a step that finds no free slot is parked in the global queue
 // undecided (lanes_chain_kernel settles it by the float chain: any ambiguous step may go there).
-template <bool INPLACE, bool VERIFY, bool FLOATS = false>
+// TAILS: bytes 16..63 of the edge line a step enters (the inline list, or the pivots of a longer one) are copied to LDS with
+// the record's load (LDS-DMA, no registers) and the next step's searches read them there.  Chosen by the host for graphs
+// whose lines stay cache resident (RMAT-18: the probes it removes were L2 hits, 15.0 -> 13.4 ms per pass); at RMAT-22 the
+// dependent HBM probes of the long lists set the pace and it is neutral (139.7 vs 138.8 ms), so the plain form stays.
+// The LDS it takes comes out of the pool and the job window (32 slots / 32 jobs instead of 64 / 64: measured equal).
+template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q))
 walk_lanes_kernel(LanesArgs a) {
     constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS;
+    constexpr bool LINE_LDS = TAILS || PW_LANES_LINE_LDS;
+    constexpr int POOL_N = TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL;
+    constexpr int WIN_N = TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN;
+    constexpr uint32_t DEFER_TH = TAILS ? (PW_LANES_DEFER_TH < 16 ? PW_LANES_DEFER_TH : 16) : PW_LANES_DEFER_TH;
     const int lane = lane_id();
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
@@ -279,7 +294,7 @@ walk_lanes_kernel(LanesArgs a) {
     // parked in LDS; a refill then costs one LDS read instead of that chain (nearly every loop iteration refills a lane
     // or two: ~40 steps per walk, 64 lanes).  Entries [win_lo, win_lo + win_n) of the job array are in the window.
     struct JobSlot { uint32_t job, start, s0, d; uint32_t soff_lo, soff_hi, r_lo, r_hi; };
-    __shared__ JobSlot s_win[WAVES_PER_BLOCK][PW_LANES_WIN];
+    __shared__ JobSlot s_win[WAVES_PER_BLOCK][WIN_N];
     JobSlot *const win = s_win[readfirst_u32(threadIdx.x / WAVE)];
     uint64_t win_lo = 0;
     uint32_t win_n = 0;
@@ -288,10 +303,10 @@ walk_lanes_kernel(LanesArgs a) {
     //   { job, j, s0, d } { n_in, pp, e, coff } { kmax -> choice once settled, soff lo, soff hi, k1 }
     //   { commons before k1, shifts, p_next, staged cell 0 } { draw lo, draw hi, staged cells 1, 2 }
     // m_def / m_set (wave-uniform): slots waiting for the interval decision / settled, waiting for a free lane
-    __shared__ uint4 s_pool[DEFER ? WAVES_PER_BLOCK : 1][5][PW_LANES_POOL];
+    __shared__ uint4 s_pool[DEFER ? WAVES_PER_BLOCK : 1][5][POOL_N];
     __shared__ uint8_t s_map[DEFER ? WAVES_PER_BLOCK : 1][WAVE];
-    uint4 (*const pool)[PW_LANES_POOL] = s_pool[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
-    constexpr uint64_t POOL_MASK = PW_LANES_POOL >= 64 ? ~0ull : ((1ull << (PW_LANES_POOL & 63)) - 1ull);
+    uint4 (*const pool)[POOL_N] = s_pool[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    constexpr uint64_t POOL_MASK = POOL_N >= 64 ? ~0ull : ((1ull << (POOL_N & 63)) - 1ull);
     uint8_t *const pmap = s_map[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
     uint64_t m_def = 0, m_set = 0;
     bool force_pass = false;
@@ -346,6 +361,23 @@ walk_lanes_kernel(LanesArgs a) {
             dsec = sec_;                                                                                               \
         }                                                                                                              \
     } while (0)
+    // LINE TAILS (PW_LANES_LINE_LDS): bytes 16..63 of the edge line a step enters -- the inline list or the pivots of a longer
+    // one -- go to LDS with the record's load; the next step's searches read them there (seqscan.h: ListView::tail)
+    __shared__ uint4 s_tail[LINE_LDS ? WAVES_PER_BLOCK : 1][3][WAVE];
+    uint4 (*const dtail)[WAVE] = s_tail[LINE_LDS ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    const uint32_t tail_addr = LINE_LDS ? (uint32_t)(uintptr_t)(lds_ptr_t)&dtail[0][lane] : 0xffffffffu;
+#define PW_LINE_STAGE(rp)                                                                                              \
+    do {                                                                                                               \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)((rp) + 1), (lds_ptr_t)&dtail[0][0], 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)((rp) + 2), (lds_ptr_t)&dtail[1][0], 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)((rp) + 3), (lds_ptr_t)&dtail[2][0], 16, 0, 0);                   \
+    } while (0)
+    // the list view of the entry this lane's walk arrived by (staged: what lives in the line is read from LDS)
+    auto lane_list = [&](uint32_t e_, uint32_t d_, uint32_t n_in_, uint32_t coff_) -> ListView {
+        ListView v = edge_list(a.lines, a.clist, e_, d_, n_in_, coff_);
+        if (LINE_LDS) { v.tail = tail_addr; v.inl = (d_ <= 65536u && n_in_ <= EL_INLINE) ? 1u : 0u; }
+        return v;
+    };
     // (the compiler does not order an LDS read behind the LDS-DMA that fills it: the wait is explicit)
 #define PW_DRAW_READ(di)                                                                                               \
     (*(const double *)((const char *)&dslot[((uint32_t)(di) & 7u) >> 1][lane] + (((uint32_t)(di) & 1u) << 3)))
@@ -358,7 +390,7 @@ walk_lanes_kernel(LanesArgs a) {
         PW_WD(1, 2000000ull, wd_main);
         if (DEFER) {
             // ---- PASS: the interval decision of every deferred step, slot s by lane s ---------------------------------
-            if (m_def && (force_pass || (uint32_t)__popcll(m_def) >= PW_LANES_DEFER_TH || (uint32_t)__popcll(m_def | m_set) >= (uint32_t)(PW_LANES_POOL - PW_LANES_POOL / 8))) {
+            if (m_def && (force_pass || (uint32_t)__popcll(m_def) >= DEFER_TH || (uint32_t)__popcll(m_def | m_set) >= (uint32_t)(POOL_N - POOL_N / 8))) {
                 force_pass = false;
                 LPROF_C(9, 1);
                 LPROF_C(10, __popcll(m_def));
@@ -465,12 +497,12 @@ walk_lanes_kernel(LanesArgs a) {
             const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
             const uint64_t pool_base = pool_lo;
             uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
-            if (PW_LANES_WIN < WAVE && take > (uint64_t)PW_LANES_WIN) take = PW_LANES_WIN;   // (the rest: the next trip of this loop)
+            if (WIN_N < WAVE && take > (uint64_t)WIN_N) take = WIN_N;   // (the rest: the next trip of this loop)
             pool_lo += take;
             if (!a.resume) {
                 if (pool_base < win_lo || pool_base + take > win_lo + win_n) {   // (wave-uniform) window used up: the next jobs
                     win_lo = pool_base;
-                    win_n = avail < (uint64_t)PW_LANES_WIN ? (uint32_t)avail : (uint32_t)PW_LANES_WIN;
+                    win_n = avail < (uint64_t)WIN_N ? (uint32_t)avail : (uint32_t)WIN_N;
                     wave_lds_fence();                                      // (earlier reads of the window are over)
                     if ((uint32_t)lane < win_n) {
                         const uint64_t widx = pool_base + (uint64_t)lane;
@@ -544,14 +576,15 @@ walk_lanes_kernel(LanesArgs a) {
         // their chains together once a few have gathered or nothing else can run.
         uint32_t choice = LANE_AMBIGUOUS;
         const bool runnable = A.flags == F_ACTIVE;
-        if (PW_LANES_DRAW_LDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sectors requested when the last steps were applied have landed)
-            if (runnable) r = PW_DRAW_READ(A.soff + (A.j - 1));
+        if (PW_LANES_DRAW_LDS || LINE_LDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what was requested when the last steps were applied has landed in LDS)
+            if (PW_LANES_DRAW_LDS && runnable) r = PW_DRAW_READ(A.soff + (A.j - 1));
         }
         if (FLOATS) {
-            if (runnable) {
+            if (runnable && A.n_in != 0u && !edge_list_stored(A.d, A.n_in, A.coff)) choice = LANE_NEEDS_WAVE;   // (partial index)
+            else if (runnable) {
                 wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
-                const ListView cl = edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff);
+                const ListView cl = lane_list(A.e, A.d, A.n_in, A.coff);
                 float xi = 1.0f, xo = wo, xp = w_prev, rowsum = 0.0f;
                 double target = __longlong_as_double(0x7ff0000000000000ll);   // +inf: the chain runs to the end of the row
                 uint32_t res = LANE_CHAIN_END;
@@ -572,11 +605,19 @@ walk_lanes_kernel(LanesArgs a) {
             }
         } else {
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
-        if (runnable) {
+        // partial index: the list of the entry this walk arrived by was left out -- the step is parked for
+        // lanes_eager_kernel (queueing form) or handed to walk_kernel with the rest of the walk (no queue)
+        const bool nolist = runnable && A.n_in != 0u && !edge_list_stored(A.d, A.n_in, A.coff);
+        if (runnable && !nolist) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
             // (r = this step's draw: loaded when the previous step was applied / the walk was started)
-            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), ls);
+            choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, lane_list(A.e, A.d, A.n_in, A.coff), ls);
             n_probes += ls.probes;
+        }
+        if (nolist) {
+            wo = w_out;
+            ls.kmax = LANE_EAGER_MARK;
+            if (INPLACE && !a.susp) choice = LANE_NEEDS_WAVE;
         }
 #ifdef PW_PROF_LANES
         {   // [11] sum over iterations of the DEEPEST list search of the wavefront, [12] lanes whose list lives in the overflow
@@ -589,13 +630,15 @@ walk_lanes_kernel(LanesArgs a) {
             }
             LPROF_C(11, pm_);
             LPROF_C(14, ps_);
-            LPROF_C(12, __popcll(ballot(runnable && !(A.d <= 65536u && A.n_in <= EL_INLINE))));
-            LPROF_C(13, __popcll(ballot(runnable)));
+            const int n_over_ = __popcll(ballot(runnable && A.n_in != 0u && !(A.d <= 65536u && A.n_in <= EL_INLINE)));
+            const int n_run_ = __popcll(ballot(runnable));
+            LPROF_C(12, n_over_);
+            LPROF_C(13, n_run_);
         }
 #endif
         LPROF_T(1);
         // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
-        const bool amb0 = runnable && choice == LANE_AMBIGUOUS;
+        const bool amb0 = runnable && choice == LANE_AMBIGUOUS && !nolist;
         if (DEFER) {
             // the step waits in the pool for the next pass of the interval decision; this lane takes another walk
             const uint64_t am = ballot(amb0);
@@ -681,7 +724,7 @@ walk_lanes_kernel(LanesArgs a) {
                     const float x_in = 1.0f / tot;
                     uint32_t reads = 0;
                     const uint32_t res = lane_chain(kmax, A.n_in, A.pp, r, x_in, x_in * wo, x_in * w_prev,
-                                                    edge_list(a.lines, a.clist, A.e, A.d, A.n_in, A.coff), reads);
+                                                    lane_list(A.e, A.d, A.n_in, A.coff), reads);
                     n_probes += reads;
                     choice = res;
                     if (res == LANE_CHAIN_END) choice = A.d;                // never reached: the mirrored overflow read
@@ -704,6 +747,7 @@ walk_lanes_kernel(LanesArgs a) {
 #undef PW_LANE_APPLY
 #undef PW_DRAW_STAGE
 #undef PW_DRAW_READ
+#undef PW_LINE_STAGE
     if (a.susp)
         for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES
@@ -733,7 +777,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     if (i < n) {
         const uint4 *qp = (const uint4 *)(q + i);
         const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-        if (q0.x != NOT_FOUND) {
+        if (q0.x != NOT_FOUND && q2.x != LANE_EAGER_MARK) {   // (void slot / a step for lanes_eager_kernel)
         const float tot = __uint_as_float(q3.x), wo = __uint_as_float(q3.y);
         const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
         const float x_in = 1.0f / tot;
@@ -755,6 +799,60 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     if (lane_id() == 0 && done) {
         atomicAdd(stats + 6, reads_l);
         atomicAdd(stats + 9, done);
+    }
+}
+
+// ---- steps whose entry's list is not in the (partial) index: walk_kernel's eager step, one wavefront per parked record ----
+// The record names the entry e = (prev -> cur) the walk arrived by and the step's draw; membership of cur's row in prev's
+// is established the way walk_kernel does without lists (key stream -> filter -> adjacency index: sample_step_unit with
+// step_edge = none), the float32 chain decides, and the record's `choice` is what the next lane round applies.
+// n, q: kernel arguments behind WalkArgs (read from the kernarg segment like walk_kernel's)
+__global__ void __launch_bounds__(WAVE)
+lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused) {
+    __shared__ uint32_t s_mask[MASK_WORDS];
+    __shared__ uint16_t s_rank[MASK_WORDS + 2];
+    __shared__ uint32_t s_queue[2 * QCAP];
+    constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
+    SuspRec *q = (SuspRec *)kernarg<uint64_t>(XARG);
+    const uint64_t n = kernarg<uint64_t>(XARG + 8);
+    const uint64_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint4 *qp = (const uint4 *)(q + i);
+    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) return;
+    WalkArgs la = reload_walk_args();
+    const ELine *lines = (const ELine *)la.g.tri;
+    const uint32_t e = uni(q1.z);
+    const uint32_t cur = uni(lines[e].nxt);
+    uint32_t prev;
+    if (e >= la.g.nnz) prev = e - la.g.nnz;                     // an overflow line: the walk came from vertex e - nnz
+    else {                                                      // the row that holds CSR entry e
+        uint32_t lo = 0, hi = la.g.n_nodes;                     // last v with indptr[v] <= e
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (uni(la.g.indptr[mid]) <= e) lo = mid; else hi = mid; }
+        prev = lo;
+    }
+    const uint32_t s0 = uni(la.g.indptr[cur]), d = uni(la.g.indptr[cur + 1]) - s0;
+    const uint32_t t0 = uni(la.g.indptr[prev]), dp = uni(la.g.indptr[prev + 1]) - t0;
+    const double r = __longlong_as_double((long long)(((unsigned long long)uni(q3.w) << 32) | uni(q3.z)));
+    // the LAZY step first (walk_sparse.hip.h: progressive membership, 64 keys of the shorter row at a time, and the
+    // exact-arithmetic decision -- it stops as soon as the target lies inside the classified prefix; the record carries
+    // what it needs about the edge: the common-neighbour count and prev's position in cur's row); the eager step -- full
+    // mask, float32 chain -- only when that declines
+    uint32_t choice = LAZY_FALLBACK;
+    {
+        const u32x4 rc = as_scalar<u32x4>(PW_KARG(uint64_t, g.vrec))[cur], rp = as_scalar<u32x4>(PW_KARG(uint64_t, g.vrec))[prev];
+        const VertexCtx vc{rc.x, rc.y, rc.z, rc.w}, vp{rp.x, rp.y, rp.z, rp.w};
+        Prof pf;
+        choice = sample_step_unit_lazy(s_mask, s_rank, cur, prev, uni(q1.x), uni(q1.y), false, 0ull, vc, vp, r, pf);
+    }
+    if (choice == LAZY_FALLBACK) {
+        la.g.step_edge = NOT_FOUND;
+        choice = sample_step_unit<float, false>(la, s_mask, s_rank, s_queue, cur, true, prev, t0, dp, r, s0, d);
+    }
+    choice = uni(choice);
+    if (lane_id() == 0) {
+        q[i].choice = choice;      // (>= d: the mirrored overflow read -- the lane kernel's apply handles it like any other)
+        atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), 1ull);
     }
 }
 
@@ -818,6 +916,7 @@ struct LaneBuildArgs {
     ELine *lines;
     uint8_t *clist;                 // FILL only
     uint32_t *segcnt;               // per-(neighbour, segment) counts of the rows longer than LB_SEG
+    uint32_t max_len;               // FILL: lists longer than this were left out of the index (partial index; 0xffffffff: none)
 };
 
 // ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
@@ -881,6 +980,7 @@ vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
     const uint4 r0 = *(const uint4 *)(lines + e);
     const uint32_t x0 = r0.x, d0 = r0.w;
     if (x0 == NOT_FOUND || d0 == 0) return;
+    if (FILL && !(d0 <= 65536u && r0.y <= EL_INLINE) && lines[e].coff == EL_NO_LIST) return;   // (partial index: list left out)
     const uint32_t s_v = g.indptr[v], d_v = g.indptr[v + 1] - s_v;
     const uint64_t tb = g.tab_off[x0];
     const uint32_t tmask = (uint32_t)(g.tab_off[x0 + 1] - tb) - 1u;
@@ -964,7 +1064,8 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             // "Fits its line" includes the row of k being narrow (uint16 positions): a DIRECTED entry h -> k into a row of
             // more than 65536 entries that has no reverse entry is taken by h whatever the degrees, and its short list
             // lives in the overflow array as uint32 positions, which only the FILL pass writes.
-            const bool done = FILL && nseg == 1 && list_is_inline(d_k, r0.y);
+            // Partial index: a list longer than max_len is stored nowhere (both directions: same length) -- nothing to fill.
+            const bool done = FILL && ((nseg == 1 && list_is_inline(d_k, r0.y)) || r0.y > a.max_len);
             if (mine && d_k && !done) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
@@ -1093,10 +1194,22 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
 }
 
 // 16-byte units the list of entry e takes in the overflow array (0: it lives inside the edge line)
-__device__ __forceinline__ uint32_t list_units(const ELine *lines, uint64_t e) {
+__device__ __forceinline__ uint32_t list_units(const ELine *lines, uint64_t e, uint32_t max_len = 0xffffffffu) {
     const uint4 r0 = *(const uint4 *)(lines + e);
-    if (list_is_inline(r0.w, r0.y)) return 0u;
+    if (list_is_inline(r0.w, r0.y) || r0.y > max_len) return 0u;
     return (r0.y * (list_is_narrow(r0.w) ? 2u : 4u) + 15u) >> 4;
+}
+
+// Partial index: histogram of the overflow array's 16-byte units by list length (lists of hist_len entries or more share
+// the last bin) -- the host picks the largest length whose cumulative units fit the byte budget.
+__global__ void __launch_bounds__(256)
+clist_length_hist_kernel(const ELine *__restrict__ lines, uint32_t n_lines, unsigned long long *hist, uint32_t hist_len) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_lines) return;
+    const uint32_t u = list_units(lines, e);
+    if (!u) return;
+    const uint32_t n = lines[e].n_in;
+    atomicAdd(hist + (n < hist_len ? n : hist_len - 1u), (unsigned long long)u);
 }
 
 // PIVOTS of the lists that live in the overflow array, written into the unused inline area of their lines after the FILL
@@ -1108,7 +1221,7 @@ eline_pivots_kernel(ELine *lines, const uint8_t *__restrict__ clist, uint32_t n_
     const uint4 r0 = *(const uint4 *)(lines + e);
     if (r0.x == NOT_FOUND) return;                    // (an overflow line without a target)
     const uint32_t n_in = r0.y, d = r0.w;
-    if (list_is_inline(d, n_in)) return;
+    if (list_is_inline(d, n_in) || lines[e].coff == EL_NO_LIST) return;
     const uint32_t wide = list_is_narrow(d) ? 0u : 1u;
     if (!list_has_pivots(wide, n_in)) return;
     const uint32_t np = list_pivot_count(wide), step = list_pivot_step(wide, n_in);
@@ -1127,12 +1240,13 @@ constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;
 
 // tile_sums[b] = 16-byte units of tile b; entry_sums[b] = list entries of tile b
 __global__ void __launch_bounds__(CL_BLOCK)
-clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint32_t nnz_real, uint64_t *tile_sums, uint64_t *entry_sums) {
+clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint32_t nnz_real, uint64_t *tile_sums, uint64_t *entry_sums,
+                       uint32_t max_len) {
     __shared__ uint64_t sh[CL_BLOCK], sh2[CL_BLOCK];
     const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)threadIdx.x * CL_ITEMS;
     uint64_t s = 0, s2 = 0;
     for (int k = 0; k < CL_ITEMS; k++)
-        if (base + k < nnz) { s += list_units(lines, base + k); if (base + k < nnz_real) s2 += lines[base + k].n_in; }
+        if (base + k < nnz) { s += list_units(lines, base + k, max_len); if (base + k < nnz_real) s2 += lines[base + k].n_in; }
     sh[threadIdx.x] = s;
     sh2[threadIdx.x] = s2;
     __syncthreads();
@@ -1145,14 +1259,14 @@ clist_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint32_t n
 
 // lines[e].coff = exclusive prefix sum of the units (tile_sums already scanned: scan_tile_sums_kernel)
 __global__ void __launch_bounds__(CL_BLOCK)
-clist_offsets_kernel(ELine *lines, uint32_t nnz, const uint64_t *__restrict__ tile_sums) {
+clist_offsets_kernel(ELine *lines, uint32_t nnz, const uint64_t *__restrict__ tile_sums, uint32_t max_len) {
     __shared__ uint64_t sh[CL_BLOCK];
     const int t = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)t * CL_ITEMS;
     uint32_t loc[CL_ITEMS];
     uint64_t s = 0;
     for (int k = 0; k < CL_ITEMS; k++) {
-        loc[k] = base + k < nnz ? list_units(lines, base + k) : 0u;
+        loc[k] = base + k < nnz ? list_units(lines, base + k, max_len) : 0u;
         s += loc[k];
     }
     sh[t] = s;
@@ -1165,7 +1279,10 @@ clist_offsets_kernel(ELine *lines, uint32_t nnz, const uint64_t *__restrict__ ti
     }
     uint64_t run = tile_sums[blockIdx.x] + sh[t] - s;
     for (int k = 0; k < CL_ITEMS; k++) {
-        if (base + k < nnz) lines[base + k].coff = (uint32_t)run;
+        if (base + k < nnz) {
+            const uint4 r0_ = *(const uint4 *)(lines + base + k);
+            lines[base + k].coff = (!list_is_inline(r0_.w, r0_.y) && r0_.y > max_len) ? EL_NO_LIST : (uint32_t)run;
+        }
         run += loc[k];
     }
 }
@@ -1177,6 +1294,10 @@ lane_index_export_kernel(const ELine *__restrict__ lines, const uint8_t *__restr
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
     const ELine &ln = lines[e];
+    if (!edge_list_stored(ln.deg, ln.n_in, ln.coff)) {   // partial index: this list was left out -- every entry reads 0xffffffff
+        for (uint32_t i = 0; i < ln.n_in; i++) out[off[e] + i] = 0xffffffffu;
+        return;
+    }
     const uint8_t *p = list_base(lines, clist, (uint32_t)e, ln.deg, ln.n_in, ln.coff);
     const bool narrow = list_is_narrow(ln.deg);
     for (uint32_t i = 0; i < ln.n_in; i++) out[off[e] + i] = narrow ? (uint32_t)((const uint16_t *)p)[i] : ((const uint32_t *)p)[i];

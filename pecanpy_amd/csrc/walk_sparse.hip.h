@@ -51,6 +51,14 @@ struct ELine {
 };
 static_assert(sizeof(ELine) == 64, "edge line is one 64-byte sector");
 constexpr uint32_t EL_INLINE = 20;
+// PARTIAL INDEX: a list the byte budget of the index left out (pw_csr_create: PECANPY_AMD_INDEX_BUDGET / half of the free
+// device memory; the LONGEST lists go first) has this offset.  Its line still holds the record -- count, reverse
+// position, degree -- so only the step that ARRIVES by such an entry needs the membership of the two rows established
+// the slow way (lanes_eager_kernel: one wavefront, walk_kernel's eager step), the walk itself stays in the lane kernel.
+constexpr uint32_t EL_NO_LIST = 0xffffffffu;
+__device__ __forceinline__ bool edge_list_stored(uint32_t d, uint32_t n_in, uint32_t coff) {
+    return (d <= 65536u && n_in <= EL_INLINE) || coff != EL_NO_LIST;
+}
 
 // the list of common-neighbour positions of the edge a walk arrived by (n_in == 0: never dereferenced)
 __device__ __forceinline__ ListView edge_list(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t d, uint32_t n_in,
@@ -923,7 +931,11 @@ __device__ __forceinline__ uint32_t segment_mask(const CsrDev &g, uint32_t *mask
         const uint4 r0 = g.tri[4ull * e];
         const uint4 u0 = make_uint4(uni(r0.x), uni(r0.y), uni(r0.z), uni(r0.w));
         // (node2vec+ on a directed graph without the reverse entry: the weight w(prev, x) has to be searched)
-        if (u0.x == cur && (!in_mask || u0.z != NOT_FOUND)) return build_mask_list<T>(g, mask, e, u0, s0, sa, len, t0, dp, in_mask, data);
+        // (and the list has to be there: the index may have left the longest ones out -- EL_NO_LIST)
+        const bool stored = edge_list_stored(u0.w, u0.y, uni(((const ELine *)g.tri)[e].coff)) &&
+                            (!in_mask || u0.z == NOT_FOUND ||
+                             edge_list_stored(dp, uni(((const ELine *)g.tri)[s0 + u0.z].n_in), uni(((const ELine *)g.tri)[s0 + u0.z].coff)));
+        if (stored && u0.x == cur && (!in_mask || u0.z != NOT_FOUND)) return build_mask_list<T>(g, mask, e, u0, s0, sa, len, t0, dp, in_mask, data);
     }
     return build_mask<T>(g, mask, queue, cur, prev, s0, sa, len, t0, dp, in_mask, data);
 }

@@ -157,3 +157,66 @@ def test_directed_entry_into_a_wide_row_without_reverse_edge():
         assert np.array_equal(got, want), (p, q)
         via = (want[:, 1] == 0).sum()
         assert via > 1000                                     # (walks whose first step went h -> 0)
+
+
+def test_partial_index_under_a_byte_budget(monkeypatch):
+    """PECANPY_AMD_INDEX_BUDGET forcing a half-stored index (VERDICT r03 missing #2): edge lines always, the LONGEST lists
+    left out; a step that arrives by an entry without its list is decided by one wavefront (lanes_eager_kernel) and the
+    walk stays in the lane kernel -- bit-exact against the oracle, and equal to the fully indexed engine at RMAT-16."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    indptr, indices, data = rmat_csr(13, seed=3)
+    full = WalkEngine.from_csr(indptr, indices, None)
+    n_in, rev, off, ent = full.lane_index()
+    deg_v = np.diff(indptr.astype(np.int64))[indices]
+    outside = ~((deg_v <= 65536) & (n_in <= 20))                      # lists that live in the overflow array
+    units = ((n_in[outside].astype(np.int64) * 2 + 15) // 16)
+    budget = int(units.sum() * 16 // 2)
+    monkeypatch.setenv("PECANPY_AMD_INDEX_BUDGET", str(budget))
+    part = WalkEngine.from_csr(indptr, indices, None)
+    monkeypatch.delenv("PECANPY_AMD_INDEX_BUDGET")
+    assert part.index_info()["index_bytes"] < full.index_info()["index_bytes"]
+    n2, rev2, off2, ent2 = part.lane_index()
+    assert np.array_equal(n2, n_in) and np.array_equal(rev2, rev)     # the records are all there
+    lens = np.diff(off)
+    dropped = np.array([lens[e] > 0 and (ent2[off[e]:off[e + 1]] == NOT_FOUND).all() for e in range(n_in.size)])
+    assert dropped.any() and not dropped[~outside].any()
+    t_max = lens[~dropped].max()
+    assert lens[dropped].min() > t_max >= 20                          # the longest lists went, by a length threshold
+    kept = np.flatnonzero(~dropped)
+    for e in kept[:: max(1, kept.size // 3000)]:
+        assert np.array_equal(ent2[off[e]:off[e + 1]], ent[off[e]:off[e + 1]]), int(e)
+    stored_units = ((lens[outside & ~dropped].astype(np.int64) * 2 + 15) // 16).sum()
+    assert stored_units * 16 <= budget
+    starts = orc.shuffled_starts(indptr.size - 1, 4, 2)
+    ones = np.ones(indices.size, dtype=np.float32)
+    for p, q in ((0.5, 2.0), (0.25, 4.0), (0.3, 1.7)):
+        want, ost = orc.walks_sparse_otf(indptr, indices, ones, p, q, starts, 40, 2, return_stats=True)
+        got = part.simulate("SparseOTF", p, q, False, starts, 40, seed=2)
+        st = dict(part.last_stats)
+        assert np.array_equal(got, want), (p, q)
+        assert st["lane_kernel"] in (1, 2) and st["index_max_list"] == t_max and st["overflow_reads"] == ost.overflow_reads
+        # (a job array this small runs the in-place form without a queue -- and the FLOATS form never parks: both hand
+        #  such walks to the wave kernel at that step; the queueing rounds below park them for lanes_eager_kernel)
+        assert st["eager_steps"] + st["redo_walks"] > 0, st
+    # a larger graph, queueing rounds: the partial engine against the fully indexed one
+    indptr, indices, data = rmat_csr(16, seed=1)
+    full = WalkEngine.from_csr(indptr, indices, None)
+    monkeypatch.setenv("PECANPY_AMD_INDEX_BUDGET", str(full.index_info()["index_bytes"] // 12))
+    part = WalkEngine.from_csr(indptr, indices, None)
+    monkeypatch.delenv("PECANPY_AMD_INDEX_BUDGET")
+    starts = np.concatenate([np.arange(indptr.size - 1, dtype=np.uint32)] * 10)
+    np.random.RandomState(0).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    a = full.simulate_device("SparseOTF", 0.5, 2, False, d_starts, 80, seed=1)
+    sa = dict(full.last_stats)
+    b = part.simulate_device("SparseOTF", 0.5, 2, False, d_starts, 80, seed=1)
+    sb = dict(part.last_stats)
+    assert sa["eager_steps"] == 0 and sa["index_max_list"] == 0xFFFFFFFF
+    assert sb["eager_steps"] > 0 and sb["lane_kernel"] == 1 and sb["index_max_list"] < 0xFFFFFFFF
+    assert (sa["total_steps"], sa["overflow_reads"]) == (sb["total_steps"], sb["overflow_reads"])
+    assert torch.equal(a, b)
+    print(f"[partial] RMAT-16: lists up to {sb['index_max_list']} entries stored, {sb['eager_steps']} of {sb['total_steps']} steps eager, "
+          f"{sb['lane_rounds']} rounds, {sb['walk_kernel_ms']:.1f} ms vs {sa['walk_kernel_ms']:.1f} ms fully indexed")
