@@ -769,11 +769,22 @@ walk_lanes_kernel(LanesArgs a) {
 }
 
 // ---- the float32 chains of a whole queue of parked walks, one lane each, every lane busy ------------------------------
-__global__ void __launch_bounds__(256)
+#ifndef PW_CHAIN_TAILS
+#define PW_CHAIN_TAILS 1   // the chain's ~17 searches bisect the same pivots (or the same inline list): bytes 16..63 of the entry's
+                           // line are staged in LDS once per chain (seqscan.h: ListView::tail).  RMAT-22 pass 137.6 -> 134.3 ms
+#endif
+#ifndef PW_CHAIN_WAVES
+#define PW_CHAIN_WAVES 5   // 88 VGPRs; six waves (80) spill 44 bytes and gain 0.5 %
+#endif
+__global__ void __launch_bounds__(256, PW_CHAIN_WAVES)
 lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
                    unsigned long long *stats) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long reads_l = 0, done = 0;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    __shared__ uint4 s_tail[PW_CHAIN_TAILS ? 4 : 1][3][WAVE];
+    uint4 (*const dtail)[WAVE] = s_tail[PW_CHAIN_TAILS ? readfirst_u32(threadIdx.x / WAVE) : 0];
     if (i < n) {
         const uint4 *qp = (const uint4 *)(q + i);
         const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
@@ -782,8 +793,17 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
         const double r = __longlong_as_double((long long)(((unsigned long long)q3.w << 32) | q3.z));
         const float x_in = 1.0f / tot;
         uint32_t reads = 0;
-        const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev,
-                                        edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w), reads);
+        ListView cl = edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w);
+        if (PW_CHAIN_TAILS && q1.x != 0u) {   // bytes 16..63 of the entry's line -> LDS (the inline list or the pivots)
+            const uint4 *rp = (const uint4 *)(lines + q1.z);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 1), (lds_ptr_t)&dtail[0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 2), (lds_ptr_t)&dtail[1][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 3), (lds_ptr_t)&dtail[2][0], 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cl.tail = (uint32_t)(uintptr_t)(lds_ptr_t)&dtail[0][threadIdx.x & (WAVE - 1)];
+            cl.inl = (q0.w <= 65536u && q1.x <= EL_INLINE) ? 1u : 0u;
+        }
+        const uint32_t res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_in * wo, x_in * w_prev, cl, reads);
         uint32_t choice = res;
         if (res == LANE_CHAIN_END) choice = q0.w;          // never reached: the mirrored overflow read (choice == degree)
         if (res == LANE_TIE) choice = LANE_NEEDS_WAVE;     // tie budget: the wave kernel redoes the walk
