@@ -128,10 +128,10 @@ def er_bits_gpu(n, density, dev, seed=1):
 
 def load_pmc(key):
     """HBM-side traffic and issue counters of this exact workload from the committed rocprofv3 --pmc passes
-    (profiles/r03_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
+    (profiles/r04_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
     inside a timed run."""
     try:
-        with open(os.path.join(REPO, "profiles", "r03_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r04_traffic.json")) as f:
             return json.load(f)["workloads"].get(key)
     except (OSError, KeyError, ValueError):
         return None
@@ -403,7 +403,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "declared_bytes_per_launch": int(declared), "declared_format": fmt,
         "avg_launch_ms": round(k_ms, 3), "rng_jump_and_expand_ms": round(float(np.mean(acc["rng_kernel_ms"])), 3),
-        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r03_traffic.json)"),
+        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r04_traffic.json)"),
         "random_sector_peak_GBps": RANDOM_SECTOR_GBS,
         "reference_format_bytes": ref_bytes,
     }
