@@ -81,10 +81,12 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
-def reference_format_bytes(walks, deg, L):
+def reference_format_bytes(walks, deg, L, common=None):
     """bytes the REFERENCE's data layout moves for these walks -- per sampled step
     8*d_cur + 4*d_prev + 28 (first step of a walk: 8*d_cur + 20).  Reported for comparison only: the lane kernel
-    does not stream rows, so this figure is not what its roofline is computed from."""
+    does not stream rows, so this figure is not what its roofline is computed from.
+    node2vec+ (``common`` = (sorted edge keys row * n + col, per-entry common-neighbour counts, n)): every step with a prev
+    adds 4*d_prev (prev's weights) + 4*|N(cur) & N(prev)| (threshold gathers) + 4, section 8(d)'s n2v+ formula."""
     import torch
 
     total = 0
@@ -102,6 +104,14 @@ def reference_format_bytes(walks, deg, L):
         total -= int(8 * valid[:, 0].sum().item())
         d_prev = deg[w[:, : L - 1]] * valid[:, 1:]
         total += int((4 * d_prev).sum().item())
+        if common is not None:
+            keys, n_in, n_nodes = common
+            total += int((4 * d_prev).sum().item()) + int((4 * valid[:, 1:]).sum().item())
+            # the entry (prev -> cur) of every step with a prev: its common-neighbour count (0 for the rare non-edge arrival)
+            qk = (w[:, : L - 1] * n_nodes + w[:, 1:L])[valid[:, 1:]]
+            pos = torch.searchsorted(keys, qk).clamp(max=keys.numel() - 1)
+            hit = keys[pos] == qk
+            total += int((4 * n_in[pos] * hit).sum().item())
     return total
 
 
@@ -356,7 +366,16 @@ def main():
     ref_bytes = None
     if cfg["graph"] == "rmat":
         deg_t = torch.from_numpy(np.diff(indptr.astype(np.int64))).to(dev)
-        ref_bytes = reference_format_bytes(d_out, deg_t, L)
+        common = None
+        if extend:   # section 8(d)'s node2vec+ formula needs |N(cur) & N(prev)| of every step: the lane index's per-entry counts
+            try:
+                cnt, _, _, _ = eng.lane_index()
+                rows_np = np.repeat(np.arange(n_nodes, dtype=np.int64), np.diff(indptr.astype(np.int64)))
+                common = (torch.from_numpy(rows_np * n_nodes + indices.astype(np.int64)).to(dev),
+                          torch.from_numpy(cnt.astype(np.int64)).to(dev), n_nodes)
+            except Exception:   # noqa: BLE001 (no lane index: the counts are left out, the figure says so)
+                common = None
+        ref_bytes = reference_format_bytes(d_out, deg_t, L, common)
     if lane:
         # declared format of the lane kernel: per sampled step one 64-byte edge line (the record
         # of the edge the walk arrives by and -- for lists of up to 20 entries -- the list itself), one 8-byte draw, one
@@ -381,13 +400,26 @@ def main():
         else:
             declared = steps0 * (3 * wpr * 8 + 12)
             fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
-        kernel = "walk_dense_fast_kernel"
+        # which kernel ran (launch_dense_bits' own conditions): the register-only kernel needs dyadic 1/p, 1/q, rows of at most
+        # 131 072 columns and no PECANPY_AMD_DENSE_NO_FAST
+        def _pow2(x):
+            m, _ = np.frexp(np.float32(1.0 / x))
+            return float(m) == 0.5
+        fast = wpr <= 2048 and _pow2(p) and _pow2(q) and not os.environ.get("PECANPY_AMD_DENSE_NO_FAST")
+        kernel = "walk_dense_fast_kernel" if fast else "walk_dense_bits_kernel"
+        if not fast:
+            declared = steps0 * (3 * wpr * 8 + 12)
+            fmt = "packed adjacency: rows of cur and prev (count pass) + cur's row again (search segment) + draw + output"
     else:
         # the wave-per-walk kernel streams rows (keys of the shorter row, weights of cur's row): SURVEY 8(d)'s
         # figure in the reference's element sizes is its declared format
         declared = ref_bytes
         kernel = "walk_kernel<float,false,%s,%s>" % ("true" if not cfg["weighted"] else "false", "true" if extend else "false")
-        fmt = "SURVEY 8(d): 8*d_cur + 4*d_prev + 28 per step (rows are streamed by this kernel)"
+        fmt = ("SURVEY 8(d): 8*d_cur + 4*d_prev + 28 per step" +
+               (" + 4*d_prev + 4*|N(cur)&N(prev)| + 4 (node2vec+)" if extend else "") +
+               " -- the REFERENCE's row traffic, which this kernel's rows mostly take from L2 / Infinity Cache: `frac` here is an "
+               "algorithmic-byte rate, NOT an HBM utilisation (that is traffic_frac_of_peak, from the PMC passes); the kernel is "
+               "instruction bound (issue_bound)")
     achieved = declared / (k_ms * 1e-3) / 1e9
     key = f"{key_graph}_{mode}_p{p:g}_q{q:g}{'_ext' if extend else ''}_w{W}_l{L}_seed{args.seed}"
     pmc = load_pmc(key) if world == 1 else None
@@ -397,7 +429,8 @@ def main():
         # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half the bytes of a wide coalesced streaming
         # read (128-byte requests tallied at 64 B) -- the packed rows are read that way (8 B per lane, 512 B per wavefront load)
         traffic = int(2 * pmc["fetch_bytes"] + pmc["write_bytes"])
-        wide_note = " FETCH_SIZE doubled: wide coalesced row reads are tallied at half their bytes on gfx950 (MI355X_MICROARCH.md, HBM section)."
+        wide_note = (" FETCH_SIZE doubled: wide coalesced row reads are tallied at half their bytes on gfx950 (the build image's "
+                     "/opt/skills/guides/MI355X_MICROARCH.md, HBM section); raw counter value in traffic_raw_counter_bytes.")
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -407,6 +440,8 @@ def main():
         "random_sector_peak_GBps": RANDOM_SECTOR_GBS,
         "reference_format_bytes": ref_bytes,
     }
+    if pmc and wide_note:
+        roofline["traffic_raw_counter_bytes"] = int(pmc["fetch_bytes"] + pmc["write_bytes"])
     if traffic:
         roofline["traffic_GBps"] = round(traffic / (k_ms * 1e-3) / 1e9, 1)
         roofline["traffic_frac_of_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

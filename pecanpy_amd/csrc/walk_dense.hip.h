@@ -729,15 +729,24 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
     }
 }
 
-// degrees from the packed rows (one wavefront per row)
+// degrees from the packed rows (one wavefront per row).  The bits of the last word beyond column n - 1 are CLEARED in the
+// handle's copy first: the register-only kernels count whole words, and a caller's padding bits would be phantom
+// neighbours.
 __global__ void __launch_bounds__(256)
-dense_degree_kernel(const uint64_t *__restrict__ adjbits, uint32_t n, uint32_t wpr, uint32_t *deg) {
+dense_degree_kernel(uint64_t *__restrict__ adjbits, uint32_t n, uint32_t wpr, uint32_t *deg) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint32_t n_waves = (gridDim.x * blockDim.x) / WAVE;
     const int lane = lane_id();
+    const uint64_t tail_mask = (n & 63u) ? ((1ull << (n & 63u)) - 1ull) : ~0ull;
     for (uint32_t u = wave; u < n; u += n_waves) {
+        if (lane == 0 && tail_mask != ~0ull) adjbits[(uint64_t)u * wpr + (wpr - 1u)] &= tail_mask;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         uint32_t acc = 0;
-        for (uint32_t w = lane; w < wpr; w += WAVE) acc += (uint32_t)__popcll(adjbits[(uint64_t)u * wpr + w]);
+        for (uint32_t w = lane; w < wpr; w += WAVE) {
+            const uint64_t v = adjbits[(uint64_t)u * wpr + w];
+            acc += (uint32_t)__popcll(w == wpr - 1u ? v & tail_mask : v);
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += (uint32_t)__shfl_xor((int)acc, off, WAVE);
         if (lane == 0) deg[u] = acc;

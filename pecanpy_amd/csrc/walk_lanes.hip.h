@@ -1,36 +1,47 @@
 // walk_lanes.hip.h -- SparseOTF walk kernel, ONE LANE PER WALK (gfx950), for the headline regime: unit weights,
-// 1/p and 1/q powers of two, no self loops (the regime of walk_sparse.hip.h's lazy step).
+// 1/p and 1/q powers of two, no self loops (the regime of walk_sparse.hip.h's lazy step); a FLOATS form covers unit
+// weights with arbitrary p, q.
 //
 // Why a second kernel.  walk_kernel (walk_sparse.hip.h) gives every walk a whole wavefront and spends ~1.4 k
 // wave instructions per step establishing which neighbours of `cur` are neighbours of `prev` (keys -> Bloom word
 // -> index slot) before the exact-arithmetic CDF search can run; it is instruction-issue bound (round-1 PMC:
 // scalar unit 72 %, VALU 62 %, HBM 33 %).  With 288 GB of HBM the membership question can be answered ONCE per
-// graph instead of once per step:
+// graph instead of once per step -- the LANE INDEX, built by the kernels at the end of this file:
 //
-//   clist : for every CSR entry e = (u -> v) the ascending positions, in row v, of the common neighbours of u and
-//           v (sum over edges of the per-edge triangle count: 2.7 G entries = 11 GB at RMAT-22).
-//   erec  : 32-byte record per CSR entry e = (u -> v): { v, |N(u) & N(v)|, position of u in row v, degree(v),
-//           indptr[v], offset of e's list in clist } -- everything a step needs about the edge it arrives by.
+//   lines : one 64-byte EDGE LINE per CSR entry e = (u -> v) (walk_sparse.hip.h: ELine): the record { v, |N(u) & N(v)|,
+//           position of u in row v, degree(v), indptr[v], list offset } -- everything a step needs about the edge it
+//           arrives by, 24 bytes -- and a 40-byte inline area that holds THE LIST ITSELF when it has at most 20
+//           entries (uint16 positions, in row v, of the common neighbours of u and v; rows beyond 65 536 entries use
+//           uint32 positions and never live in a line).  RMAT-22: 4.2 GB.  One more line per VERTEX behind them
+//           (lines[nnz + v]) serves the reference's mirrored "choice == degree" read (App. D quirk 1).
+//   clist : the lists that do not fit their line, 16-byte aligned (RMAT-22: 2.7 G entries, 5.2 GB).  The line of such
+//           a list keeps 20 (10) PIVOTS of it in its inline area -- every (n / 21)-th entry (seqscan.h: ListView) -- so
+//           that the upper levels of a search are probes of the line the step has fetched anyway.
+//           A byte budget (PECANPY_AMD_INDEX_BUDGET, default half of the free memory) may leave the LONGEST lists out
+//           (EL_NO_LIST): a step that arrives by such an entry is decided by lanes_eager_kernel, the walk stays here.
 //
 // A step of the reference (SparseOTF.move_forward, src/pecanpy/pecanpy.py:543-559; get_normalized_probs,
 // src/pecanpy/rw/sparse_rw.py:51-91) then is: the exact-arithmetic decision of seqscan.h (E(k) = exact mass of
 // elements 0..k in units of the smallest weight; first k with E(k) >= ceil(R - z) and E(k) >= ceil(R + z))
-// evaluated by ONE LANE: a binary search over the edge's common-neighbour positions (each P_i splits the row into
+// evaluated by ONE LANE: a bisection over the edge's common-neighbour positions (each P_i splits the row into
 // runs of "out" neighbours whose mass is a closed form), no membership work at all.  64 walks advance per
-// wavefront instruction; a step costs one 32-byte record, ~log2(n_common) list probes, one draw and one store.
+// wavefront instruction; a step costs one 64-byte line, ~log2(n_common / 21) probes of the overflow array for the
+// lists that have one, one 8-byte draw and one 4-byte output cell.
 //
 // Steps the a-priori bound cannot settle (a partial sum of the exact CDF lies within the float32 drift bound of
-// the target, 12 % of the steps at RMAT-22) go through two more routines of seqscan.h, both evaluated by the lane:
+// the target, 12 % of the steps at RMAT-22) go through two more routines of seqscan.h:
 //   lane_tight : the chain's SYSTEMATIC drift bounded from the class counts the decision already has -- arithmetic
-//                only, settles nine in ten of them on the spot;
-//   lane_chain : the float32 chain itself.  Not run in place: a chain with a handful of the wavefront's lanes enabled
-//                costs the others ~300 us.  The walk is PARKED (SuspRec into a queue), the lane takes another walk,
+//                only, ~850 instructions, settles nine in ten of them.  Round 4: NOT run where the ambiguity turns up
+//                (an eighth of the lanes enabled, nearly every loop iteration: 40 % of the kernel's vector
+//                instructions in round 3) but DEFERRED: the walk's context waits in a per-wavefront POOL in LDS, the
+//                lane takes another walk, and one PASS decides 32+ waiting steps at once (DEFER, below).
+//   lane_chain : the float32 chain itself.  Not run in place either: the walk is PARKED (SuspRec into a global queue),
 //                lanes_chain_kernel settles a whole queue at full width and the next ROUND of this kernel resumes the
 //                walks (host loop: pecanpy_amd.hip, launch_lane_walks).  The last, small round runs them in place.
-// The rare rest -- the mirrored overflow read (choice == degree, App. D quirk 1), rows whose total is not exact in
-// float32 -- is not handled here: the job is appended to a redo list and walk_kernel takes the walk over at that step.
-// Registers decide everything here: at 6 waves/SIMD (80 VGPRs) the compiler spilled 160 registers into the hot loop
-// and the kernel ran at half its speed; 96 VGPRs / 5 waves (queueing form), 128 / 4 (in-place form) hold it all.
+// The rare rest -- rows whose total is not exact in float32, tie binades beyond the budget, overflow reads without a
+// line -- is not handled here: the job is appended to a redo list and walk_kernel takes the walk over at that step.
+// Registers decide everything here: the queueing form needs 92 VGPRs (5 waves/SIMD, no scratch; with lane_tight in
+// place it was 80 / 6 waves), the in-place form ~120 (4 waves); any spill in the step loop costs more than a wave brings.
 #pragma once
 #include "walk_sparse.hip.h"
 
@@ -167,7 +178,7 @@ __device__ unsigned long long g_lprof[16];
 #endif
 
 // Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
-// otherwise one 32-byte record names the next vertex and everything the next step needs.
+// otherwise the record of the sampled entry's 64-byte line names the next vertex and everything the next step needs.
 #define PW_LANE_APPLY()                                                                         \
     do {                                                                                        \
         uint32_t oe_ = NOT_FOUND;                                                               \

@@ -234,6 +234,27 @@ def test_device_stream_at_deep_offsets():
     assert np.array_equal(eng.stream_sample(11, 3_000_000, 4000), rs.random_sample(4000))
 
 
+def test_dense_bits_handle_ignores_padding_bits():
+    """pw_dense_create_bits with garbage in the bits beyond column n - 1 of every row's last word: the handle
+    clears them in its copy -- same walks as from clean rows, on the register-only kernel and on the complete one."""
+    n = 1000                                             # 1000 & 63 = 40: 24 padding bits per row
+    rs = np.random.RandomState(4)
+    adj = rs.random_sample((n, n)) < 0.2
+    adj = np.triu(adj, 1)
+    adj = adj | adj.T
+    clean = orc.pack_adjacency(adj)
+    dirty = clean.copy()
+    dirty[:, -1] |= np.uint64(0xFFFFFF) << np.uint64(40)
+    starts = orc.shuffled_starts(n, 4, 1)
+    want = orc.walks_dense_otf_bits(clean, n, 0.5, 2, starts, 30, 1)
+    for p, q in ((0.5, 2.0), (0.3, 1.7)):
+        a = WalkEngine.from_dense_bits(clean, n).simulate("DenseOTF", p, q, False, starts, 30, seed=1)
+        b = WalkEngine.from_dense_bits(dirty, n).simulate("DenseOTF", p, q, False, starts, 30, seed=1)
+        assert np.array_equal(a, b), (p, q)
+        if (p, q) == (0.5, 2.0):
+            assert np.array_equal(a, want)
+
+
 def _dense_fixtures():
     return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if "_DenseOTF_" in os.path.basename(f))
 
