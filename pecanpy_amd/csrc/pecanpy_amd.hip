@@ -116,6 +116,8 @@ struct pw_graph {
     hipStream_t stream2 = nullptr;   // side stream: the zero-fill of the walk matrix runs under the stream expansion
     hipEvent_t ev_side = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;     // pw_simulate: the D2H of one part of the walk matrix runs here, under the walks of the next
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
     void *stage[2] = {nullptr, nullptr};   // pinned staging buffers of pw_simulate's copy out
     uint32_t *seed_state = nullptr;        // pinned: the seed's MT19937 state on its way to the device
     double lane_ms = 0;              // lane kernel time of the current call
@@ -258,6 +260,9 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     for (auto &e : g->ev)
         if (e) (void)hipEventDestroy(e);
     if (g->ev_side) (void)hipEventDestroy(g->ev_side);
+    for (auto &e : g->ev_copy)
+        if (e) (void)hipEventDestroy(e);
+    if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
@@ -276,6 +281,8 @@ static int graph_common_init(pw_graph *g, int device) {
     HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming));
     for (auto &e : g->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+    for (auto &e : g->ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
 
@@ -1723,12 +1730,17 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
 // the PCIe rate; the walk matrix is 13.8 GB at RMAT-22).  The buffers live in the handle.
 static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t bytes) {
     const size_t CH = (size_t)64 << 20;
-    if (bytes < CH / 2) { HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return 0; }
+    if (bytes < CH / 2) {
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g->copy_stream));
+        HIP_TRY(hipStreamSynchronize(g->copy_stream));
+        return 0;
+    }
     for (auto &b : g->stage)
         if (!b && hipHostMalloc(&b, CH, hipHostMallocDefault) != hipSuccess) {
             b = nullptr;
             (void)hipGetLastError();
-            HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));   // no pinned memory: plain copy
+            HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g->copy_stream));   // no pinned memory: plain copy
+            HIP_TRY(hipStreamSynchronize(g->copy_stream));
             return 0;
         }
     // (the destination is usually fresh pageable memory: the copy is bound by first-touch page faults per thread)
@@ -1751,13 +1763,13 @@ static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t byt
     for (size_t c = 0; c <= n_ch; c++) {
         if (c < n_ch) {
             const size_t off = c * CH, len = off + CH < bytes ? CH : bytes - off;
-            HIP_TRY(hipMemcpyAsync(g->stage[c & 1], (const char *)d_src + off, len, hipMemcpyDeviceToHost, g->stream));
-            HIP_TRY(hipEventRecord(g->ev[c & 1 ? 5 : 4], g->stream));
+            HIP_TRY(hipMemcpyAsync(g->stage[c & 1], (const char *)d_src + off, len, hipMemcpyDeviceToHost, g->copy_stream));
+            HIP_TRY(hipEventRecord(g->ev_copy[c & 1], g->copy_stream));
         }
         if (c > 0) {
             const size_t off = (c - 1) * CH, len = off + CH < bytes ? CH : bytes - off;
             const double t0 = now();
-            HIP_TRY(hipEventSynchronize(g->ev[(c - 1) & 1 ? 5 : 4]));
+            HIP_TRY(hipEventSynchronize(g->ev_copy[(c - 1) & 1]));
             const double t1 = now();
             fan_out((char *)dst + off, (const char *)g->stage[(c - 1) & 1], len);
             t_wait += t1 - t0;
@@ -1786,10 +1798,52 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
     const double t2 = now();
-    if (!rc) rc = pw_simulate_device(g, mode, p, q, extend, d_starts, n_jobs, walk_length, has_seed, seed,
-                                     stream_skip, d_out, stats);
+    // The matrix leaves the device at the PCIe rate (RMAT-18: 17 ms for 0.86 GB against 13 ms of walks): large job arrays
+    // are walked in PARTS and the copy of part k (helper thread, copy stream, pinned staging) runs under the kernels of
+    // part k + 1.  Part k + 1's stream address = draws the earlier parts ACTUALLY consumed, so the walks are those of one
+    // call whatever the split (dead ends included).  Alias modes consume a variable number of words per step: one part.
+    const size_t row_bytes = sizeof(uint32_t) * ((size_t)walk_length + 2);
+    int n_parts = 1;
+    if (mode < PW_MODE_PRECOMP && (size_t)n_jobs * row_bytes >= ((size_t)128 << 20) && !getenv("PECANPY_AMD_NO_PARTS")) n_parts = 4;
+    if (const char *pe = getenv("PECANPY_AMD_PARTS")) { n_parts = atoi(pe); if (n_parts < 1 || mode >= PW_MODE_PRECOMP) n_parts = 1; }
+    if (!has_seed && n_parts > 1) { seed = os_seed(); has_seed = 1; }   // (every part walks the same stream)
+    pw_stats total;
+    memset(&total, 0, sizeof(total));
+    std::thread copier;
+    int copy_rc = 0;
+    std::string copy_err;
+    uint64_t skip = stream_skip;
+    for (int part = 0; part < n_parts && !rc; part++) {
+        const uint64_t lo = (uint64_t)part * n_jobs / n_parts, hi = (uint64_t)(part + 1) * n_jobs / n_parts;
+        pw_stats st;
+        memset(&st, 0, sizeof(st));
+        rc = pw_simulate_device(g, mode, p, q, extend, d_starts + lo, hi - lo, walk_length, has_seed, seed, skip,
+                                d_out + lo * ((size_t)walk_length + 2), &st);
+        if (rc) break;
+        skip += st.total_steps;
+        if (part == 0) total = st;
+        else {
+            total.total_steps += st.total_steps; total.overflow_reads += st.overflow_reads; total.clamped_reads += st.clamped_reads;
+            total.dead_end_walks += st.dead_end_walks; total.repair_rounds += st.repair_rounds; total.walk_kernel_ms += st.walk_kernel_ms;
+            total.rng_kernel_ms += st.rng_kernel_ms; total.walk_kernel_launches += st.walk_kernel_launches;
+            total.stream_addressing |= st.stream_addressing; total.lane_rounds += st.lane_rounds; total.redo_walks += st.redo_walks;
+            total.list_entries_read += st.list_entries_read; total.ambiguous_steps += st.ambiguous_steps;
+            total.lane_kernel_ms += st.lane_kernel_ms; total.wave_chain_steps += st.wave_chain_steps; total.param_index_ms += st.param_index_ms;
+            total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch; total.verify_dropped += st.verify_dropped;
+            total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
+        }
+        if (copier.joinable()) copier.join();          // (one copy at a time: they share the staging buffers and the PCIe link)
+        if (copy_rc) break;
+        copier = std::thread([&, lo, hi]() {
+            (void)hipSetDevice(g->device);
+            copy_rc = copy_out_staged(g, (char *)out + lo * row_bytes, (const char *)d_out + lo * row_bytes, (hi - lo) * row_bytes);
+            if (copy_rc) copy_err = g_err;             // (g_err is thread local: carried over below)
+        });
+    }
     const double t3 = now();
-    if (!rc) rc = copy_out_staged(g, out, d_out, sizeof(uint32_t) * out_elems);
+    if (copier.joinable()) copier.join();
+    if (!rc && copy_rc) rc = fail(copy_rc, copy_err);
+    if (!rc && stats) *stats = total;
     const double t4 = now();
     (void)hipFree(d_starts);
     (void)hipFree(d_out);

@@ -234,6 +234,26 @@ def test_device_stream_at_deep_offsets():
     assert np.array_equal(eng.stream_sample(11, 3_000_000, 4000), rs.random_sample(4000))
 
 
+@pytest.mark.parametrize("parts", [2, 3, 5])
+def test_host_call_walked_in_parts_equals_one_call(parts, monkeypatch):
+    """pw_simulate walks large job arrays in parts (the copy-out of one part under the kernels of the next); part k + 1
+    is addressed into the stream by the draws the earlier parts actually consumed -- undirected graph and a directed
+    one with dead ends, against the oracle."""
+    monkeypatch.setenv("PECANPY_AMD_PARTS", str(parts))
+    indptr, indices, data = rmat_csr(11, seed=7)
+    starts = orc.shuffled_starts(indptr.size - 1, 3, 1)
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 25, 1)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, 25, seed=1)
+    assert np.array_equal(got, want), _diff_report(got, want)
+    assert eng.last_stats["total_steps"] == int((want[:, -1].astype(np.int64) - 1).sum())
+    z = np.load(os.path.join(GOLDEN, "sink_SparseOTF_p0.5_q2.npz"))
+    eng = WalkEngine.from_csr(z["indptr"], z["indices"], z["data"])
+    got = eng.simulate("SparseOTF", 0.5, 2, False, z["starts"], int(z["walk_length"]), seed=int(z["seed"]))
+    assert np.array_equal(got, z["walks"]), _diff_report(got, z["walks"])
+    assert eng.last_stats["stream_addressing"] == 0
+
+
 def test_dense_bits_handle_ignores_padding_bits():
     """pw_dense_create_bits with garbage in the bits beyond column n - 1 of every row's last word: the handle
     clears them in its copy -- same walks as from clean rows, on the register-only kernel and on the complete one."""
