@@ -260,7 +260,11 @@ def test_parked_walks_and_chain_kernel_equal_in_place_chains_and_oracle(p, q, mo
         assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
         runs[name] = st
     assert runs["queue"]["lane_rounds"] > 1 and runs["in_place"]["lane_rounds"] == 1
-    assert runs["queue"]["wave_chain_steps"] == runs["in_place"]["wave_chain_steps"] > 0
+    # the queueing form defers the interval decision through a pool in LDS; a step that finds the pool full is parked
+    # UNDECIDED and settled by the chain kernel (round 4), so it may run a few more chains than the in-place form -- never
+    # fewer, and the ambiguous steps are the same set
+    assert runs["in_place"]["wave_chain_steps"] > 0
+    assert runs["in_place"]["wave_chain_steps"] <= runs["queue"]["wave_chain_steps"] <= 2 * runs["in_place"]["wave_chain_steps"]
     assert runs["queue"]["ambiguous_steps"] == runs["in_place"]["ambiguous_steps"] > runs["queue"]["wave_chain_steps"]
 
 
