@@ -291,7 +291,16 @@ int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, 
  * total / the thread's.  on_device: one GPU thread per target. */
 int pw_selftest_lane_floats(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev,
                             const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots);
-/* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
+/* The lane kernel's decision for WEIGHTED rows (csrc/seqscan.h: lane_decide_weighted: float64 prefix sums of the step's
+ * values with a rigorous bound on the float32 chain's drift), host only.  vals[k] = the step's value of neighbour k
+ * before normalisation (what get_normalized_probs holds at sparse_rw.py:87 / :126), base[k] = its value as a plain
+ * "out" neighbour, cls[k] = 0 other (vals == base) / 1 common neighbour of prev and cur / 2 prev.  chain[i] = the
+ * reference's position for draw r[i] (sequential float32 w.sum(), w / tot, cumsum, searchsorted; n: never reached),
+ * lane[i] = the decision: the same position, or 0xfffffffd when a partial sum lies within the bound of the draw (the
+ * step then takes the wave-per-walk scan). */
+int pw_selftest_lane_weighted(const float *vals, const float *base, const uint8_t *cls, uint32_t n, const double *r,
+                              uint32_t n_r, uint32_t *chain, uint32_t *lane);
+/* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). *//* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);
 

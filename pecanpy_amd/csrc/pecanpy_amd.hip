@@ -2400,6 +2400,58 @@ PW_EXPORT int pw_selftest_lane(int on_device, int device, const uint8_t *cls, ui
     return PW_OK;
 }
 
+// The weighted-row decision of the lane kernel (seqscan.h: lane_decide_weighted) on a host row, beside the reference's
+// sequential float32 chain.  vals[k] = the step's value of neighbour k before normalisation, base[k] = its base value
+// (what it would be as a plain "out" neighbour), cls[k] = 0 other (vals == base) / 1 common neighbour / 2 prev.
+PW_EXPORT int pw_selftest_lane_weighted(const float *vals, const float *base, const uint8_t *cls, uint32_t n, const double *r,
+                                        uint32_t n_r, uint32_t *chain, uint32_t *lane) {
+    if (!vals || !base || !cls || !r || !chain || !lane || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    float tot = 0.0f;
+    for (uint32_t k = 0; k < n; k++) tot = tot + vals[k];                     // sequential float32 w.sum()
+    std::vector<float> c(n);
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < n; k++) { acc = acc + vals[k] / tot; c[k] = acc; }   // cumsum of fl32(w / tot)
+    std::vector<double> pq(n), dl;
+    std::vector<uint16_t> cl16;
+    std::vector<uint32_t> cl32;
+    const uint32_t wide = n > 65536u ? 1u : 0u;
+    double run = 0.0, drun = 0.0, dprev = 0.0;
+    uint32_t pp = 0xffffffffu;
+    for (uint32_t k = 0; k < n; k++) {
+        run += (double)base[k];
+        pq[k] = run;
+        if (cls[k] == 1) {
+            drun += (double)vals[k] - (double)base[k];
+            dl.push_back(drun);
+            if (wide) cl32.push_back(k); else cl16.push_back((uint16_t)k);
+        } else if (cls[k] == 2) {
+            if (pp != 0xffffffffu) return fail(PW_ERR_INVALID, "at most one prev");
+            pp = k;
+            dprev = (double)vals[k] - (double)base[k];
+        } else if (cls[k] != 0 || vals[k] != base[k]) return fail(PW_ERR_INVALID, "class 0 elements carry their base value");
+    }
+    const uint32_t n_cl = (uint32_t)dl.size();
+    cl16.resize(cl16.size() + 8, 0xffffu);
+    cl32.resize(cl32.size() + 8, 0xffffffffu);
+    uint32_t piv_off = 0;
+    if (pw::list_has_pivots(wide, n_cl)) {
+        const uint32_t np = pw::list_pivot_count(wide), step = pw::list_pivot_step(wide, n_cl);
+        piv_off = (uint32_t)(wide ? cl32.size() : cl16.size());
+        for (uint32_t k = 0; k < np; k++) { if (wide) cl32.push_back(cl32[(size_t)(k + 1) * step]); else cl16.push_back(cl16[(size_t)(k + 1) * step]); }
+    }
+    dl.push_back(0.0);
+    const pw::ListView view = pw::list_view_of(wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide, n_cl, piv_off);
+    const pw::WeightedRow wr{pq.data(), dl.data(), dprev};
+    for (uint32_t i = 0; i < n_r; i++) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+        chain[i] = lo;
+        uint32_t probes = 0;
+        lane[i] = pw::lane_decide_weighted(n, n_cl, pp, r[i], tot, wr, view, probes);
+    }
+    return PW_OK;
+}
+
 // ---- node2vec+ thresholds (host only) -----------------------------------------------------------------
 PW_EXPORT int pw_noise_thresholds_csr(const uint32_t *indptr, const float *data, uint32_t n_nodes, double gamma, float *thr) {
     if (!indptr || !thr || (!data && indptr[n_nodes] != 0)) return fail(PW_ERR_INVALID, "null pointer");

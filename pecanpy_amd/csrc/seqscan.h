@@ -505,6 +505,77 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     return LANE_AMBIGUOUS;
 }
 
+// ---- WEIGHTED rows: the decision from float64 prefix sums, with a rigorous bound on the float32 chain (round 4) ------
+// Arbitrary float32 weights leave no exact integer form of the partial sums.  What one thread CAN have cheaply is the
+// real prefix sum of the step's values: the value of a neighbour that is neither a common neighbour nor prev (its BASE
+// value: fl32(f64(w) / q), node2vec+: fl32(f64(w) * alpha_0)) depends on cur alone, so its float64 prefix sums PQ are a
+// per-vertex array; the common neighbours of the arriving entry differ from their base value by deltas whose prefix
+// sums DL follow the entry's list; prev is one more delta.  S(k) = PQ[k] + DL[#commons <= k] + [pp <= k] dprev is then
+// the real sum of the first k + 1 values (float64 evaluation: relative 1e-13), and the reference's float32 chain
+//     v_i = fl32(w'_i / tot),  c_k = fl32(c_{k-1} + v_k)            (sparse_rw.py:89, pecanpy.py:556-557)
+// obeys | c_k - S(k) / tot | <= (S(k) / tot) * eps(k),  eps(k) = (k + 2) * 2^-24 * (1 + o(1)):  one relative rounding 2^-24
+// per division, one per addition applied to a partial sum that never exceeds the last one (the chain is monotone).
+// Candidate k1 = first k with S(k) / tot * (1 + eps) >= r (bisection over the list, then inside the run of non-common
+// positions that holds it); the chain is monotone, so c_{k1-1} < r <= c_{k1} -- i.e. hi(k1 - 1) < r and lo(k1) >= r --
+// makes k1 the reference's answer.  Otherwise LANE_AMBIGUOUS: the step goes to the wave-per-walk scan (RMAT-20 with
+// hashed weights: 10 % of the steps; the bound saturates on rows beyond a few thousand entries).
+struct WeightedRow {
+    const double *pq;   // [d] inclusive float64 prefix sums of the base values of cur's row
+    const double *dl;   // [n_in] inclusive prefix sums, in list order, of (step value - base value) of the common neighbours
+    double dprev;       // (step value - base value) of prev's element (0: prev is not in the row)
+};
+PW_HD double weighted_eps(uint32_t k) { return 1.05 * ((double)k + 3.0) * (1.0 / 16777216.0) + 1e-9; }
+
+struct WeightedEval {   // upper bound of the chain at the common neighbour i (position P), as order-preserving bits
+    const WeightedRow *wr;
+    uint32_t pp;
+    double inv;
+    PW_HD uint64_t operator()(uint32_t i, uint32_t P) const {
+        const double S = wr->pq[P] + wr->dl[i] + (pp < P ? wr->dprev : 0.0);
+        const double hi = S * inv * (1.0 + weighted_eps(P)) + 3e-45 * ((double)P + 1.0);
+        return FloatTraits<double>::bits(hi > 0.0 ? hi : 0.0);
+    }
+};
+
+PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
+                                    const ListView &cl, uint32_t &probes) {
+    if (!(tot > 0.0f) || d == 0u) return LANE_REDO;
+    const double inv = 1.0 / (double)tot;
+    const uint64_t tbits = FloatTraits<double>::bits(r > 0.0 ? r : 0.0);
+    uint32_t ks = 0, ke = d, f = 0;
+    if (n_in) {
+        const WeightedEval ev{&wr, pp, inv};
+        const SearchResult sr = list_search(cl, 0u, n_in, ev, tbits, probes);
+        f = sr.f;
+        if (sr.has_below) ks = sr.p_below + 1u;
+        if (sr.f < n_in) ke = sr.p_at;
+    }
+    const double dbase = f ? wr.dl[f - 1u] : 0.0;
+    auto sum_at = [&](uint32_t k, uint32_t commons) -> double {   // S(k) with `commons` common neighbours at positions <= k
+        return wr.pq[k] + (commons ? wr.dl[commons - 1u] : 0.0) + (pp <= k ? wr.dprev : 0.0);
+    };
+    auto hi_of = [&](uint32_t k, double S) { return S * inv * (1.0 + weighted_eps(k)) + 3e-45 * ((double)k + 1.0); };
+    auto lo_of = [&](uint32_t k, double S) { return S * inv * (1.0 - weighted_eps(k)) - 3e-45 * ((double)k + 1.0); };
+    // first position of the run [ks, ke) whose upper bound reaches r (none: ke -- the common neighbour there, or d)
+    uint32_t lo = ks, hi = ke;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const double S = wr.pq[mid] + dbase + (pp <= mid ? wr.dprev : 0.0);
+        probes++;
+        if (hi_of(mid, S) >= r) hi = mid; else lo = mid + 1u;
+    }
+    const uint32_t k1 = lo;
+    // the chain is monotone: c_{k1 - 1} < r <= c_{k1} settles it
+    if (k1 > 0u) {
+        const uint32_t kp = k1 - 1u;                       // (>= ks - 1: `f` common neighbours at positions <= kp)
+        if (!(hi_of(kp, sum_at(kp, f)) < r)) return LANE_AMBIGUOUS;
+    }
+    if (k1 >= d) return d;                                 // never reached: the mirrored overflow read (choice == degree)
+    const uint32_t commons = (k1 == ke && f < n_in) ? f + 1u : f;
+    if (!(lo_of(k1, sum_at(k1, commons)) >= r)) return LANE_AMBIGUOUS;
+    return k1;
+}
+
 // ---- the float32 chain itself, evaluated by ONE thread (lane kernel, ambiguous steps) ---------------------------
 // c_k = c_{k-1} + x_class(k), sequential float32 additions (np.cumsum), first k with (double)c_k >= r
 // (np.searchsorted, reference src/pecanpy/pecanpy.py:556-557).  Same arithmetic as the wavefront version

@@ -354,3 +354,60 @@ def test_float_chain_step_for_non_dyadic_biases(w_out, w_prev, device):
         declined += int(tie.sum())
         total += r.size
     assert declined / total < 0.05
+
+
+# ---- weighted rows: float64 prefix sums + a rigorous bound on the float32 chain (lane_decide_weighted) ------------------
+def _weighted_run(vals, base, cls, r):
+    vals = np.ascontiguousarray(vals, np.float32)
+    base = np.ascontiguousarray(base, np.float32)
+    cls = np.ascontiguousarray(cls, np.uint8)
+    r = np.ascontiguousarray(r, np.float64)
+    chain = np.zeros(r.size, np.uint32)
+    lane = np.zeros(r.size, np.uint32)
+    _lib.check(_lib.load().pw_selftest_lane_weighted(
+        vals.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p), cls.ctypes.data_as(C.c_void_p), vals.size,
+        r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p), lane.ctypes.data_as(C.c_void_p)))
+    return chain, lane
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 64, 300, 1000, 3000, 9000, 70000])
+def test_weighted_lane_decision_never_disagrees_with_the_float32_chain(n):
+    """Every target the decision SETTLES must be the position the reference's sequential float32 cumsum / searchsorted
+    gives -- random targets and targets placed exactly on, one ulp around and 1e-7 around partial sums of the chain --
+    for node2vec and node2vec+-like rows (commons with arbitrary deltas), dyadic and non-dyadic p, q; what it leaves
+    open is reported, not decided.  Rows beyond a few thousand entries are mostly ambiguous (the bound grows with k)."""
+    rs = np.random.RandomState(n)
+    for trial in range(6):
+        w = (rs.random_sample(n) * 0.999 + 0.001).astype(np.float32)
+        if trial == 5:
+            w = np.ldexp(np.float32(1.0), rs.randint(-6, 3, n)).astype(np.float32)      # dyadic weights: tie-heavy chains
+        q = float(rs.choice([2.0, 0.5, 1.7, 0.3, 4.0, 1.0]))
+        p = float(rs.choice([0.5, 2.0, 0.3, 1.0]))
+        cls = np.zeros(n, np.uint8)
+        cls[rs.choice(n, int(rs.randint(0, max(1, n // 3))), replace=False)] = 1
+        cand = np.flatnonzero(cls == 0)
+        if cand.size and rs.random_sample() < 0.8:
+            cls[rs.choice(cand)] = 2
+        base = (w.astype(np.float64) / q).astype(np.float32)
+        vals = base.copy()
+        com = cls == 1
+        if trial % 2:                      # node2vec+-like: a common neighbour is an in-edge (w) or an out-edge (w * alpha)
+            alpha = 1.0 / q + (1.0 - 1.0 / q) * rs.random_sample(n)
+            ext = (w.astype(np.float64) * alpha).astype(np.float32)
+            vals[com] = np.where(rs.random_sample(int(com.sum())) < 0.5, w[com], ext[com])
+        else:
+            vals[com] = w[com]
+        vals[cls == 2] = (w[cls == 2].astype(np.float64) / p).astype(np.float32)
+        t = np.float32(0)
+        for x in vals:
+            t = np.float32(t + x)
+        c = np.cumsum((vals / t).astype(np.float32), dtype=np.float32).astype(np.float64)
+        pick = rs.choice(n, min(n, 150), replace=False)
+        r = np.concatenate([rs.random_sample(300), c[pick], np.nextafter(c[pick], 0), np.nextafter(c[pick], 2),
+                            c[pick] * (1 - 1e-7), c[pick] * (1 + 1e-7), [0.0, 0.9999999999]])
+        r = np.clip(r, 0, 0.9999999999)
+        chain, lane = _weighted_run(vals, base, cls, r)
+        decided = lane != 0xFFFFFFFD
+        assert np.array_equal(lane[decided], chain[decided]), (n, p, q, trial)
+        if n <= 300:
+            assert decided[:300].mean() > 0.9          # short rows: the bound is far below the spacing of the partial sums
