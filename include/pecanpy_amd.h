@@ -66,7 +66,9 @@ typedef struct {
     uint32_t stream_addressing; /* 0: the reference's exact draw assignment; 1: nominal per-walk slots
                                    (fallback on sink-heavy directed graphs) */
     /* lane kernel (one walk per lane, csrc/walk_lanes.hip.h): unit-weight CSR graphs, 1/p and 1/q powers of two */
-    uint32_t lane_kernel;       /* 1: the call ran on the lane kernel; 2: on its float-chain form (1/p or 1/q not a power of two) */
+    uint32_t lane_kernel;       /* 1: the call ran on the lane kernel; 2: on its float-chain form (1/p or 1/q not a power of two);
+                                   3: on its weighted form (weighted CSR graphs: float64-bounded decision, eager_steps = the steps
+                                   the wave-per-walk scan decided) */
     uint32_t lane_rounds;       /* lane kernel launches of the call: walks whose step needs the float32 chain are parked,
                                    the chains of a whole queue run in one launch, the next round resumes the walks */
     uint64_t redo_walks;        /* walks a fast kernel handed to the complete one: lane kernel -> wave-per-walk kernel

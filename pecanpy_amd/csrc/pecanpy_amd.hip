@@ -100,6 +100,19 @@ struct pw_graph {
     bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
                                                         // built (the wave kernel's lazy step reads it) but the lane kernel is not used
     float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
+    // weighted lane form (walk_lanes.hip.h: WEIGHTED): base values, their per-row float64 prefix sums, per-entry delta prefix sums
+    float *d_wb = nullptr;
+    double *d_wpq = nullptr, *d_wdl = nullptr, *d_wl_dprev = nullptr;
+    unsigned long long *d_wl_off = nullptr;
+    uint32_t *d_wedge_row = nullptr;                    // ... source vertex of every CSR entry
+    unsigned long long *d_wck_off = nullptr;            // ... recorded chain values (wckpt_kernel): first record of entry e
+    float *d_wck = nullptr;
+    uint64_t wdl_cap = 0, wck_cap = 0;
+    double wl_p = 0, wl_q = 0;
+    int wl_extend = -1;
+    uint64_t wl_thr_version = 0;
+    bool wl_failed = false;
+    bool wl_active = false;                             // the current call runs the weighted lane form
     double tot_p = 0, tot_q = 0;                        // ... built for these parameters
     int tot_extend = -1;                                // -1: none yet
     uint64_t tot_thr_version = 0, thr_version = 0;      // thresholds uploaded since the table was built?
@@ -233,6 +246,9 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
+    for (void *q : {(void *)g->d_wb, (void *)g->d_wpq, (void *)g->d_wdl, (void *)g->d_wl_dprev, (void *)g->d_wl_off, (void *)g->d_wedge_row,
+                    (void *)g->d_wck_off, (void *)g->d_wck})
+        if (q) (void)hipFree(q);
     g->redo.release();
     g->susp[0].release();
     g->susp[1].release();
@@ -1117,6 +1133,106 @@ static int ensure_tot_table(pw_graph *g, pw::WalkArgs &wa, bool extend) {
     return 0;
 }
 
+// Tables of the WEIGHTED lane form (walk_lanes.hip.h), per (p, q, extend, thresholds), cached in the handle like the
+// normaliser table they go with: base values wb[nnz], their per-row float64 prefix sums wpq[nnz], one float64 per list
+// entry of the lane index (delta prefix sums) and the per-entry prev delta.  Returns with *ok = false (no error) when
+// the form does not apply: the wave-per-walk kernel then serves the call.
+static int ensure_wlane_tables(pw_graph *g, const pw::WalkArgs &wa, bool extend, bool *ok) {
+    *ok = false;
+    if (g->kind != 0 || g->unit || !g->nnz || !g->d_lines || g->lanes_off || !wa.tot_e || g->wl_failed) return 0;
+    if (getenv("PECANPY_AMD_NO_LANES") || getenv("PECANPY_AMD_NO_WLANES")) return 0;
+    if (extend && !g->d_thr) return 0;
+    // (the float64 evaluation of the prefix differences is part of the decision's error budget: moderate biases only)
+    if (!(wa.p >= 1.0 / 1024 && wa.p <= 1024.0 && wa.q >= 1.0 / 1024 && wa.q <= 1024.0)) return 0;
+    const bool fresh = g->wl_extend == (extend ? 1 : 0) && g->wl_p == wa.p && g->wl_q == wa.q &&
+                       (!extend || g->wl_thr_version == g->thr_version);
+    if (fresh) { *ok = true; return 0; }
+    const uint32_t nnz = g->nnz;
+    auto give_up = [&]() { g->wl_failed = true; (void)hipGetLastError(); return 0; };
+    if (!g->d_wb) {
+        hipError_t e = hipMalloc((void **)&g->d_wb, sizeof(float) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wpq, sizeof(double) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_dprev, sizeof(double) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_off, sizeof(unsigned long long) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wck_off, sizeof(unsigned long long) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wedge_row, sizeof(uint32_t) * (size_t)nnz);
+        if (e != hipSuccess) return give_up();
+        hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_wedge_row);
+    }
+    uint64_t *d_tiles = nullptr;
+    const uint64_t n_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
+    auto cleanup = [&]() { if (d_tiles) (void)hipFree(d_tiles); };
+    hipError_t e = hipMalloc((void **)&d_tiles, sizeof(uint64_t) * (n_tiles + 1));
+    if (e != hipSuccess) { cleanup(); return give_up(); }
+    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+    // offsets of the per-entry delta lists (one float64 per list entry) and of the recorded chain values
+    uint64_t entries = 0, records = 0;
+    hipLaunchKernelGGL(pw::entry_tile_sums_kernel<0>, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles);
+    hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
+    hipLaunchKernelGGL(pw::entry_offsets_kernel<0>, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles, g->d_wl_off);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&entries, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pw::entry_tile_sums_kernel<1>, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles);
+        hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, n_tiles);
+        hipLaunchKernelGGL(pw::entry_offsets_kernel<1>, dim3((unsigned)n_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, nnz, d_tiles, g->d_wck_off);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&records, d_tiles + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) { cleanup(); return fail(PW_ERR_HIP, std::string("weighted lane tables (offsets): ") + hipGetErrorString(e)); }
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (entries + 1 > g->wdl_cap) {
+        if (g->d_wdl) (void)hipFree(g->d_wdl);
+        g->d_wdl = nullptr;
+        g->wdl_cap = 0;
+        if ((entries + 1) * sizeof(double) > free_b / 2 || hipMalloc((void **)&g->d_wdl, sizeof(double) * (size_t)(entries + 1)) != hipSuccess) {
+            cleanup();
+            return give_up();
+        }
+        g->wdl_cap = entries + 1;
+    }
+    if (records + 1 > g->wck_cap) {
+        if (g->d_wck) (void)hipFree(g->d_wck);
+        g->d_wck = nullptr;
+        g->wck_cap = 0;
+        if ((records + 1) * sizeof(float) > free_b / 4 || hipMalloc((void **)&g->d_wck, sizeof(float) * (size_t)(records + 1)) != hipSuccess) {
+            cleanup();
+            return give_up();
+        }
+        g->wck_cap = records + 1;
+    }
+    const unsigned egrid = (unsigned)(((uint64_t)nnz + 255) / 256);
+    pw::CsrDev c = csr_dev(g);
+    if (extend) hipLaunchKernelGGL(pw::wbase_kernel<true>, dim3(egrid), dim3(256), 0, g->stream, (const float *)g->d_data, g->d_wedge_row, g->d_thr, wa.q, nnz, g->d_wb);
+    else hipLaunchKernelGGL(pw::wbase_kernel<false>, dim3(egrid), dim3(256), 0, g->stream, (const float *)g->d_data, g->d_wedge_row, (const float *)nullptr, wa.q, nnz, g->d_wb);
+    hipLaunchKernelGGL(pw::wprefix_kernel, dim3((unsigned)(((uint64_t)g->n_nodes * pw::WAVE + 255) / 256)), dim3(256), 0, g->stream, g->d_indptr, g->d_wb,
+                       g->n_nodes, g->d_wpq);
+    if (extend) hipLaunchKernelGGL(pw::wlist_kernel<true>, dim3(egrid), dim3(256), 0, g->stream, c, g->d_wedge_row, g->d_wb, wa.p, wa.q, g->d_wl_off, g->d_wdl, g->d_wl_dprev);
+    else hipLaunchKernelGGL(pw::wlist_kernel<false>, dim3(egrid), dim3(256), 0, g->stream, c, g->d_wedge_row, g->d_wb, wa.p, wa.q, g->d_wl_off, g->d_wdl, g->d_wl_dprev);
+    if (records) {   // the chain's value after every CHAIN_CKPT-th element of the rows longer than that, per arriving entry
+        const unsigned cgrid = (unsigned)(((uint64_t)nnz + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK);
+        if (extend) hipLaunchKernelGGL(pw::wckpt_kernel<true>, dim3(cgrid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa, g->d_wedge_row, g->d_wck_off, g->d_wck);
+        else hipLaunchKernelGGL(pw::wckpt_kernel<false>, dim3(cgrid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa, g->d_wedge_row, g->d_wck_off, g->d_wck);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(g->ev[5], g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("weighted lane tables: ") + hipGetErrorString(e));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[4], g->ev[5]));
+    g->param_ms_call += ms;
+    g->wl_extend = extend ? 1 : 0;
+    g->wl_p = wa.p;
+    g->wl_q = wa.q;
+    g->wl_thr_version = g->thr_version;
+    *ok = true;
+    return 0;
+}
+
 static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total = nullptr) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
@@ -1142,7 +1258,7 @@ static bool lanes_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
 
 // One lane per walk (walk_lanes.hip.h); the jobs it hands back (overflow reads, rows outside the exact range) are
 // walked again by the wave-per-walk kernel.  *n_redo receives their number.
-static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
+static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bool weighted = false, bool extend = false) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
     pw::LanesArgs la;
@@ -1166,18 +1282,25 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     la.redo_count = g->counters.p + 6;
     la.w_out = wa.w_out;
     la.w_prev = wa.w_prev;
+    la.wpq = g->d_wpq;
+    la.wdl = g->d_wdl;
+    la.wl_off = g->d_wl_off;
+    la.wl_dprev = g->d_wl_dprev;
+    la.tot_e = wa.tot_e;
     // TAILS form (the rest of the edge line staged in LDS): for graphs whose edge lines stay cache resident -- there the
     // probes of inline lists and pivots are L2 hits that LDS reads replace; beyond that the HBM probes of the long lists
     // set the pace and the plain form is as fast (PECANPY_AMD_LANE_TAILS = 0 / 1 overrides the size rule)
     bool tails = (uint64_t)g->nnz * sizeof(pw::ELine) <= (uint64_t)2 << 30;   // (RMAT-18 / -20: 15.0 -> 13.4 / 36.9 -> 34.1 ms; RMAT-22, 4.2 GB of lines: 138.8 -> 139.7)
     if (const char *te = getenv("PECANPY_AMD_LANE_TAILS")) tails = atoi(te) != 0;
-    if (getenv("PECANPY_AMD_VERIFY_TIGHT")) tails = false;
+    if (getenv("PECANPY_AMD_VERIFY_TIGHT") || weighted) tails = false;
     int occ = 0;
-    if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (weighted) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    else if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<false, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
     int occ_in = 0;
-    if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (weighted) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    else if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_in < 1) occ_in = 1;
     const uint64_t lanes_resident = (uint64_t)g->n_cu * (uint64_t)occ * pw::WAVES_PER_BLOCK * pw::WAVE;
@@ -1190,6 +1313,9 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     //  16 x -> 160.8: the chains of the last round run at a few lanes per wavefront)
     uint64_t tail = lanes_resident / 2;
     if (n_work / 16 > tail) tail = n_work / 16 < 4 * lanes_resident ? n_work / 16 : 4 * lanes_resident;
+    // (weighted form: every walk is parked about nine times -- first step, ambiguous steps -- and the in-place form can only
+    //  hand such walks to walk_kernel for good: rounds go on until few walks are left)
+    if (weighted) tail = 8192;
     if (tail_env) tail = (uint64_t)strtoull(tail_env, nullptr, 10);
     bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
@@ -1201,7 +1327,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
     // verification mode: every step the interval decision settles is recorded and decided again by the float chain
     const char *ver_env = getenv("PECANPY_AMD_VERIFY_TIGHT");
-    const bool verify = ver_env != nullptr;
+    const bool verify = ver_env != nullptr && !weighted;
     la.ver_poison = (verify && strcmp(ver_env, "poison") == 0) ? 1u : 0u;
     la.ver = nullptr;
     la.ver_count = g->counters.p + 40;
@@ -1224,7 +1350,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
-        const bool queue_out = use_queue && todo > tail && round < 64;
+        const bool queue_out = use_queue && todo > tail && round < (weighted ? 512 : 64);
         la.susp = queue_out ? g->susp[round & 1].p : nullptr;
         la.susp_count = g->counters.p + 32;
         la.susp_chunk = todo > 32 * lanes_resident ? 128u : 1u;   // (void slots: < 128 per wavefront)
@@ -1246,7 +1372,9 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         HIP_TRY(hipEventRecord(g->ev[4], g->stream));
         if (verify) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
         const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
-        if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
+        if (weighted && queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (weighted) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out && tails) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false>), lgrid, lblock, 0, g->stream, la);
         else if (verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, true>), lgrid, lblock, 0, g->stream, la);
@@ -1282,7 +1410,15 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
         }
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
-        if (parked) {   // settle the queue just filled
+        if (parked && weighted) {   // the parked steps of the weighted form: one wavefront each, the wave-per-walk scan
+            if (extend) hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<true>, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa,
+                                           g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
+                                           (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));
+            else hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<false>, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa,
+                                    g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
+                                    (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));
+            HIP_TRY(hipGetLastError());
+        } else if (parked) {   // settle the queue just filled
             hipLaunchKernelGGL(pw::lanes_chain_kernel, dim3((unsigned)((parked + 255) / 256)), dim3(256), 0, g->stream,
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
@@ -1407,9 +1543,11 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     const bool floats = lanes_float_eligible(g, wa);
-    if (!floats && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend, redo_total);
+    const bool wlanes = g->wl_active && !wa.job_list;   // (repair passes of a weighted directed graph: the wave kernel)
+    if (!floats && !wlanes && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend, redo_total);
     uint64_t n_redo = 0;
-    int rc = floats ? launch_lane_float_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo);
+    int rc = wlanes ? launch_lane_walks(g, wa, &n_redo, true, extend)
+                    : (floats ? launch_lane_float_walks(g, wa, &n_redo) : launch_lane_walks(g, wa, &n_redo));
     // Walks the lane kernel cannot step (overflow reads, rows outside the exact range, tie budget) go to walk_kernel,
     // which resumes them at that step and finishes them.  Measured and rejected: handing them BACK to the lane kernel
     // once they are on a CSR entry again -- as extra cycles after the rounds (198 vs 189 ms per RMAT-22 pass, round 2)
@@ -1617,8 +1755,16 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     g->param_ms_call = 0;
     rc = ensure_tot_table(g, wa, extend != 0);   // (before the timed walk region: a per-(p, q) index, reported apart)
     if (rc) return rc;
+    g->wl_active = false;
+    if (mode == PW_MODE_SPARSE_OTF) {
+        rc = ensure_wlane_tables(g, wa, extend != 0, &g->wl_active);   // (likewise; the weighted lane form needs both)
+        if (rc) return rc;
+        if (g->wl_active) {   // the lane kernel only writes the cells a walk fills (unit graphs: zero-filled on the side stream above)
+            HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
+        }
+    }
     uint64_t redo_total = 0;
-    const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa);
+    const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa) || g->wl_active;
     g->lane_ms = 0;
     g->lane_rounds = 0;
     g->ver_checked = g->ver_mismatch = g->ver_dropped = g->ver_ties = 0;
@@ -1707,7 +1853,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.overflow_reads = h[2];
     st.clamped_reads = h[3];
     st.dead_end_walks = dead;
-    st.lane_kernel = lanes ? (lanes_float_eligible(g, wa) ? 2u : 1u) : 0u;
+    st.lane_kernel = lanes ? (g->wl_active ? 3u : (lanes_float_eligible(g, wa) ? 2u : 1u)) : 0u;
     st.redo_walks = redo_total;
     st.list_entries_read = h[7];
     st.ambiguous_steps = h[8];
@@ -2446,8 +2592,9 @@ PW_EXPORT int pw_selftest_lane_weighted(const float *vals, const float *base, co
         uint32_t lo = 0, hi = n;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
         chain[i] = lo;
-        uint32_t probes = 0;
-        lane[i] = pw::lane_decide_weighted(n, n_cl, pp, r[i], tot, wr, view, probes);
+        uint32_t probes = 0, k_safe = 0;
+        lane[i] = pw::lane_decide_weighted(n, n_cl, pp, r[i], tot, wr, view, probes, k_safe);
+        if (k_safe > chain[i]) return fail(PW_ERR_INVALID, "lane_decide_weighted: k_safe beyond the chain's position");
     }
     return PW_OK;
 }

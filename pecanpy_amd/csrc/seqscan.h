@@ -537,8 +537,11 @@ struct WeightedEval {   // upper bound of the chain at the common neighbour i (p
     }
 };
 
+// k_safe (out): every partial sum before element k_safe is known to stay below r -- a step left open can start its exact
+// scan there (from the recorded chain value before it: walk_sparse.hip.h, CHAIN_CKPT) instead of at element 0.
 PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
-                                    const ListView &cl, uint32_t &probes) {
+                                    const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+    k_safe = 0;
     if (!(tot > 0.0f) || d == 0u) return LANE_REDO;
     const double inv = 1.0 / (double)tot;
     const uint64_t tbits = FloatTraits<double>::bits(r > 0.0 ? r : 0.0);
@@ -570,6 +573,7 @@ PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, doub
         const uint32_t kp = k1 - 1u;                       // (>= ks - 1: `f` common neighbours at positions <= kp)
         if (!(hi_of(kp, sum_at(kp, f)) < r)) return LANE_AMBIGUOUS;
     }
+    k_safe = k1;                                           // (c_j <= c_{k1 - 1} < r for every j < k1: the chain is monotone)
     if (k1 >= d) return d;                                 // never reached: the mirrored overflow read (choice == degree)
     const uint32_t commons = (k1 == ke && f < n_in) ? f + 1u : f;
     if (!(lo_of(k1, sum_at(k1, commons)) >= r)) return LANE_AMBIGUOUS;

@@ -107,6 +107,12 @@ struct LanesArgs {
     uint64_t ver_cap;
     uint32_t ver_poison;                      // PECANPY_AMD_VERIFY_TIGHT=poison: every 1024th RECORD (not the walk) gets a wrong
                                               // position, which the check must report -- proves the check is live
+    // WEIGHTED form (weighted CSR graphs; per (p, q, extend, thresholds) tables built by wbase / wprefix / wlist kernels)
+    const double *wpq;                        // [nnz] per-row inclusive float64 prefix sums of the base values
+    const double *wdl;                        // per-entry lists of delta prefix sums (entry e: wdl + wl_off[e], n_in values)
+    const unsigned long long *wl_off;         // [nnz] offset of entry e's deltas; ~0: no table for this entry (eager step)
+    const double *wl_dprev;                   // [nnz] (step value - base value) of prev's element when arriving by entry e
+    const float *tot_e;                       // [nnz] the step's normaliser (sequential float32 row total) by arriving entry
 };
 
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
@@ -267,10 +273,16 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // whose lines stay cache resident (RMAT-18: the probes it removes were L2 hits, 15.0 -> 13.4 ms per pass); at RMAT-22 the
 // dependent HBM probes of the long lists set the pace and it is neutral (139.7 vs 138.8 ms), so the plain form stays.
 // The LDS it takes comes out of the pool and the job window (32 slots / 32 jobs instead of 64 / 64: measured equal).
-template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false>
+// WEIGHTED (round 4): weighted CSR graphs, node2vec and node2vec+.  A step is decided by lane_decide_weighted (seqscan.h)
+// from the per-vertex float64 prefix sums of the base values + the arriving entry's delta prefix sums, with a rigorous
+// bound on the float32 chain; what the bound leaves open (RMAT-20 with hashed weights: 10 % of the steps), the first
+// step of every walk and arrivals without a table are parked for lanes_eager_kernel<true, ..> -- the wave-per-walk scan
+// with the normaliser from the per-entry table -- and resumed by the next round.  No pool, no interval decision, no
+// float chain per lane here; without a queue (small job lists, the last round) such a walk goes to walk_kernel for good.
+template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false, bool WEIGHTED = false>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q))
 walk_lanes_kernel(LanesArgs a) {
-    constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS;
+    constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS && !WEIGHTED;
     constexpr bool LINE_LDS = TAILS || PW_LANES_LINE_LDS;
     constexpr int POOL_N = TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL;
     constexpr int WIN_N = TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN;
@@ -619,13 +631,34 @@ walk_lanes_kernel(LanesArgs a) {
         // partial index: the list of the entry this walk arrived by was left out -- the step is parked for
         // lanes_eager_kernel (queueing form) or handed to walk_kernel with the rest of the walk (no queue)
         const bool nolist = runnable && A.n_in != 0u && !edge_list_stored(A.d, A.n_in, A.coff);
+        uint32_t wk_safe = 0;   // WEIGHTED: every partial sum before this element stays below the draw (parked with the step)
+        if (WEIGHTED) {
+            if (runnable) {
+                // (first step of a walk: no prev, plain weights -- the eager kernel has the per-vertex normaliser; arrivals by
+                //  an overflow line or an entry without tables likewise)
+                unsigned long long wo_ = ~0ull;
+                if (A.j >= 2u && A.e < a.nnz && !nolist) wo_ = a.wl_off[A.e];
+                if (wo_ != ~0ull) {
+                    const WeightedRow wr{a.wpq + A.s0, a.wdl + wo_, a.wl_dprev[A.e]};
+                    uint32_t probes_ = 0;
+                    choice = lane_decide_weighted(A.d, A.n_in, A.pp, r, a.tot_e[A.e], wr, lane_list(A.e, A.d, A.n_in, A.coff), probes_, wk_safe);
+                    n_probes += probes_;
+                    if (choice == LANE_REDO) choice = LANE_AMBIGUOUS;
+                }
+                if (choice == LANE_AMBIGUOUS) {
+                    wo = w_out;
+                    ls.kmax = LANE_EAGER_MARK;                               // parked for lanes_eager_kernel<true, ..>
+                    if (INPLACE && !a.susp) choice = LANE_NEEDS_WAVE;       // no queue: walk_kernel takes the walk over here
+                }
+            }
+        } else
         if (runnable && !nolist) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
             // (r = this step's draw: loaded when the previous step was applied / the walk was started)
             choice = lane_decide(A.d, A.n_in, A.pp, r, wo, w_prev, lane_list(A.e, A.d, A.n_in, A.coff), ls);
             n_probes += ls.probes;
         }
-        if (nolist) {
+        if (nolist && !WEIGHTED) {
             wo = w_out;
             ls.kmax = LANE_EAGER_MARK;
             if (INPLACE && !a.susp) choice = LANE_NEEDS_WAVE;
@@ -649,7 +682,7 @@ walk_lanes_kernel(LanesArgs a) {
 #endif
         LPROF_T(1);
         // the chain's drift bounded from the class counts (seqscan.h: lane_tight): arithmetic only, right away
-        const bool amb0 = runnable && choice == LANE_AMBIGUOUS && !nolist;
+        const bool amb0 = !WEIGHTED && runnable && choice == LANE_AMBIGUOUS && !nolist;
         if (DEFER) {
             // the step waits in the pool for the next pass of the interval decision; this lane takes another walk
             const uint64_t am = ballot(amb0);
@@ -710,7 +743,7 @@ walk_lanes_kernel(LanesArgs a) {
                     qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
                     qp[1] = make_uint4(A.n_in, A.pp, A.e, A.coff);
                     qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
-                    qp[3] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
+                    qp[3] = make_uint4(WEIGHTED ? wk_safe : __float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                        (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
                     const uint32_t slot = (A.j - 1u) & 3u;          // staged output cells: written out now
                     uint32_t *cell = a.out + (uint64_t)A.job * W + (A.j - slot);
@@ -887,7 +920,163 @@ lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsi
     }
 }
 
-// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------
+// ---- WEIGHTED form: eager steps and the per-(p, q, extend) tables ------------------------------------------------------------
+// A parked step of the weighted lane kernel: the wave-per-walk scan (walk_sparse.hip.h: sample_step_weighted -- membership
+// mask from the arriving entry's list, exact sequential float32 chain) with the normaliser from the per-entry table.
+// The scan does not start at element 0: the record carries k_safe (every partial sum before it stays below the draw --
+// lane_decide_weighted) and the chain's exact value after every CHAIN_CKPT-th element of (prev, cur)'s row was recorded
+// with the tables (wckpt_kernel), so it starts at the last recorded value at or before k_safe: at most CHAIN_CKPT + the
+// width of the ambiguity instead of half a hub row.  ck_off[e] = first record of entry e; edge_row[e] = its source vertex.
+template <bool EXTEND>
+__global__ void __launch_bounds__(WAVE)
+lanes_eager_weighted_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused,
+                            const uint32_t *edge_row_unused, const unsigned long long *ck_off_unused, const float *ck_unused) {
+    __shared__ uint32_t s_mask[MASK_WORDS];
+    __shared__ uint32_t s_in[EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue[2 * QCAP];
+    constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
+    SuspRec *q = (SuspRec *)kernarg<uint64_t>(XARG);
+    const uint64_t n = kernarg<uint64_t>(XARG + 8);
+    const uint64_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint4 *qp = (const uint4 *)(q + i);
+    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
+    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) return;
+    WalkArgs la = reload_walk_args();
+    const ELine *lines = (const ELine *)la.g.tri;
+    const uint32_t e = uni(q1.z), j = uni(q0.y);
+    const bool has_prev = j >= 2u;
+    uint32_t cur, prev = 0;
+    if (!has_prev) cur = as_scalar<uint32_t>(PW_KARG(uint64_t, starts))[uni(q0.x)];
+    else {
+        cur = uni(lines[e].nxt);
+        prev = e >= la.g.nnz ? e - la.g.nnz : uni(as_scalar<uint32_t>(kernarg<uint64_t>(XARG + 24))[e]);
+    }
+    const uint32_t s0 = uni(la.g.indptr[cur]), d = uni(la.g.indptr[cur + 1]) - s0;
+    const uint32_t t0 = has_prev ? uni(la.g.indptr[prev]) : 0u, dp = has_prev ? uni(la.g.indptr[prev + 1]) - t0 : 0u;
+    const double r = __longlong_as_double((long long)(((unsigned long long)uni(q3.w) << 32) | uni(q3.z)));
+    float ktot = 0.0f;
+    bool have_tot = false;
+    if (la.tot_e) {
+        if (!has_prev) { ktot = la.tot_v[cur]; have_tot = true; }
+        else if (e < la.g.nnz) { ktot = la.tot_e[e]; have_tot = true; }
+    }
+    ktot = __uint_as_float(uni(__float_as_uint(ktot)));
+    // where the scan starts: the last recorded chain value at or before k_safe (records exist for real entries only)
+    uint32_t k_start = 0;
+    float c_start = 0.0f;
+    if (has_prev && have_tot && e < la.g.nnz && kernarg<uint64_t>(XARG + 40) != 0ull) {
+        const uint32_t m = uni(q3.x) / CHAIN_CKPT;                     // (k_safe <= d; record m - 1 = value after element m * CKPT - 1)
+        if (m > 0u && m * CHAIN_CKPT < d) {
+            const unsigned long long off = as_scalar<unsigned long long>(kernarg<uint64_t>(XARG + 32))[e];
+            c_start = __uint_as_float(uni(__float_as_uint(((const float *)kernarg<uint64_t>(XARG + 40))[off + m - 1u])));
+            k_start = m * CHAIN_CKPT;
+        }
+    }
+    la.g.step_edge = (has_prev && e < la.g.nnz) ? e : NOT_FOUND;
+    uint32_t choice = sample_step_weighted<float, false>(la, s_mask, EXTEND ? s_in : nullptr, s_queue, cur, has_prev, prev, t0, dp, r, s0, d,
+                                                         have_tot ? &ktot : nullptr, nullptr, k_start, k_start ? &c_start : nullptr);
+    choice = uni(choice);
+    if (lane_id() == 0) {
+        q[i].choice = choice;
+        atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), 1ull);
+    }
+}
+
+// Base value of every CSR entry (v -> x): the value of x in v's row for a walker whose prev is neither x nor adjacent to x --
+// node2vec: fl32(f64(w) / q) (sparse_rw.py:86); node2vec+: fl32(f64(w) * alpha), alpha = 1/q, or min(1, 1/q) when the edge
+// (v, x) itself is noisy (w < thr[v]) (sparse_rw.py:119-125 with t = 0).  Depends on cur alone.
+template <bool EXTEND>
+__global__ void __launch_bounds__(256)
+wbase_kernel(const float *__restrict__ data, const uint32_t *__restrict__ edge_row, const float *__restrict__ thr, double q, uint32_t nnz,
+             float *wb) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const float w = data[e];
+    if (!EXTEND) { wb[e] = Arith<float>::bias_div(w, q); return; }
+    const double inv_q = 1.0 / q;
+    double alpha = inv_q + (1.0 - inv_q) * 0.0;
+    if (Arith<float>::noisy(w, thr[edge_row[e]])) alpha = inv_q < 1.0 ? inv_q : 1.0;
+    wb[e] = Arith<float>::bias_mul(w, alpha);
+}
+
+// Per-row inclusive float64 prefix sums of the base values (one wavefront per row)
+__global__ void __launch_bounds__(256)
+wprefix_kernel(const uint32_t *__restrict__ indptr, const float *__restrict__ wb, uint32_t n_nodes, double *pq) {
+    const uint32_t v = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+    if (v >= n_nodes) return;
+    const int lane = lane_id();
+    const uint32_t s0 = indptr[v], d = indptr[v + 1] - s0;
+    double carry = 0.0;
+    for (uint32_t c0 = 0; c0 < d; c0 += WAVE) {
+        const uint32_t k = c0 + (uint32_t)lane;
+        double x = k < d ? (double)wb[s0 + k] : 0.0;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const double y = __shfl_up(x, (unsigned)off, WAVE);
+            if (lane >= off) x += y;
+        }
+        if (k < d) pq[s0 + k] = carry + x;
+        carry += __shfl(x, WAVE - 1, WAVE);
+    }
+}
+
+// Per-entry delta prefix sums: entry e = (u -> v), list P_0 < P_1 < ... of positions in row v of the common neighbours of u
+// and v.  A walker that arrived by e (prev = u, cur = v) gives the common neighbour x = row_v[P_j] the value
+//   node2vec : w(v, x)                                                                       (sparse_rw.py:84-86: not an out edge)
+//   node2vec+: w(v, x) when w(u, x) >= thr[x] (in edge); else fl32(f64(w(v, x)) * alpha), alpha = 1/q + (1 - 1/q) * t,
+//              t = fl32(w(u, x) / thr[x]), overridden by min(1, 1/q) when w(v, x) < thr[v]      (sparse_rw.py:93-130)
+// -- the statements of RowVals::value / value_ext -- and dl[j] = sum_{i <= j} (f64(value_i) - f64(base_i)).  dprev[e] = the
+// same difference for prev's own element (fl32(f64(w) / p)).  One thread per entry; entries whose list is not stored
+// (partial index) or, for node2vec+, that have no reverse entry get offset ~0: their steps take the eager kernel.
+template <bool EXTEND>
+__global__ void __launch_bounds__(256)
+wlist_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const float *__restrict__ wb, double p, double q,
+             unsigned long long *wl_off, double *dl, double *dprev) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.nnz) return;
+    const ELine *lines = (const ELine *)g.tri;
+    const float *__restrict__ data = (const float *)g.data;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    const uint2 r1 = *((const uint2 *)(lines + e) + 2);
+    const uint32_t v = r0.x, n_in = r0.y, rev = r0.z, d_v = r0.w, s_v = r1.x, coff = r1.y;
+    const uint32_t u = edge_row[e];
+    dprev[e] = rev != NOT_FOUND ? (double)Arith<float>::bias_div(data[s_v + rev], p) - (double)wb[s_v + rev] : 0.0;
+    const unsigned long long off = wl_off[e];      // (in: exclusive prefix sum of n_in over the entries)
+    if (n_in == 0u) return;
+    if (!edge_list_stored(d_v, n_in, coff) || (EXTEND && rev == NOT_FOUND)) { wl_off[e] = ~0ull; return; }
+    const ListView P = edge_list(lines, g.clist, (uint32_t)e, d_v, n_in, coff);
+    ListView Q = P;
+    uint32_t t0 = 0;
+    if (EXTEND) {
+        const uint32_t e2 = s_v + rev;
+        const uint32_t d_u = g.indptr[u + 1] - g.indptr[u];
+        if (!edge_list_stored(d_u, lines[e2].n_in, lines[e2].coff)) { wl_off[e] = ~0ull; return; }
+        Q = edge_list(lines, g.clist, e2, d_u, lines[e2].n_in, lines[e2].coff);
+        t0 = g.indptr[u];
+    }
+    const double inv_q = 1.0 / q;
+    const float thr_cur = EXTEND ? g.thr[v] : 0.0f;
+    double run = 0.0;
+    for (uint32_t j = 0; j < n_in; j++) {
+        const uint32_t pos = P.at(j);
+        const float w = data[s_v + pos];
+        float val = w;
+        if (EXTEND) {
+            const uint32_t x = g.indices[s_v + pos];
+            const float wpx = data[t0 + Q.at(j)], tx = g.thr[x];
+            if (!Arith<float>::in_edge(wpx, tx)) {
+                double alpha = inv_q + (1.0 - inv_q) * Arith<float>::t_ratio(wpx, tx);
+                if (Arith<float>::noisy(w, thr_cur)) alpha = inv_q < 1.0 ? inv_q : 1.0;
+                val = Arith<float>::bias_mul(w, alpha);
+            }
+        }
+        run += (double)val - (double)wb[s_v + pos];
+        dl[off + j] = run;
+    }
+}
+
+// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------
 // counts: [0] records checked [1] MISMATCHES (lane_tight's position != the chain's) [2] chains that declined (tie budget)
 // bad: the first few mismatching records, for the error message
 __global__ void __launch_bounds__(256)
@@ -1316,6 +1505,87 @@ clist_offsets_kernel(ELine *lines, uint32_t nnz, const uint64_t *__restrict__ ti
         }
         run += loc[k];
     }
+}
+
+// Exclusive prefix sums over the CSR entries of a per-entry count (the weighted lane form's tables): MODE 0 = the list length
+// n_in (one float64 per list entry: wlist_kernel), MODE 1 = the recorded chain values of the entry's target row,
+// (degree - 1) / CHAIN_CKPT (wckpt_kernel).  Tile sums -> scan_tile_sums_kernel -> offsets.
+template <int MODE> __device__ __forceinline__ uint32_t entry_count(const ELine *lines, uint64_t e) {
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    return MODE == 0 ? r0.y : (r0.w ? (r0.w - 1u) / CHAIN_CKPT : 0u);
+}
+template <int MODE>
+__global__ void __launch_bounds__(CL_BLOCK)
+entry_tile_sums_kernel(const ELine *__restrict__ lines, uint32_t nnz, uint64_t *tile_sums) {
+    __shared__ uint64_t sh[CL_BLOCK];
+    const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)threadIdx.x * CL_ITEMS;
+    uint64_t s = 0;
+    for (int k = 0; k < CL_ITEMS; k++)
+        if (base + k < nnz) s += entry_count<MODE>(lines, base + k);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = CL_BLOCK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh[0];
+}
+template <int MODE>
+__global__ void __launch_bounds__(CL_BLOCK)
+entry_offsets_kernel(const ELine *__restrict__ lines, uint32_t nnz, const uint64_t *__restrict__ tile_sums, unsigned long long *off_out) {
+    __shared__ uint64_t sh[CL_BLOCK];
+    const int t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)t * CL_ITEMS;
+    uint32_t loc[CL_ITEMS];
+    uint64_t s = 0;
+    for (int k = 0; k < CL_ITEMS; k++) {
+        loc[k] = base + k < nnz ? entry_count<MODE>(lines, base + k) : 0u;
+        s += loc[k];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 1; off < CL_BLOCK; off <<= 1) {
+        const uint64_t add = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = tile_sums[blockIdx.x] + sh[t] - s;
+    for (int k = 0; k < CL_ITEMS; k++) {
+        if (base + k < nnz) off_out[base + k] = run;
+        run += loc[k];
+    }
+}
+
+// Recorded chain values: for every CSR entry e = (u -> v) whose target row has more than CHAIN_CKPT entries, the exact
+// float32 value of the reference's cumsum(w / tot) for a walker that arrived by e (prev = u, cur = v), after every
+// CHAIN_CKPT-th element -- computed by the walk step's own code (sample_step_weighted, normaliser from the per-entry
+// table) -- so that an exact scan can start in the middle of a hub row.  One wavefront per entry; Sigma_v d_v^2 element
+// visits, like the normaliser table.
+template <bool EXTEND>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, EXTEND ? PW_MIN_WAVES - 1 : PW_MIN_WAVES)
+wckpt_kernel(WalkArgs a_unused, const uint32_t *__restrict__ edge_row_unused, const unsigned long long *ck_off_unused, float *ck_unused) {
+    __shared__ uint32_t s_mask[WAVES_PER_BLOCK][MASK_WORDS];
+    __shared__ uint32_t s_in[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue[WAVES_PER_BLOCK][2 * QCAP];
+    const int wave = threadIdx.x / WAVE;
+    constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
+    const uint32_t nnz = PW_KARG(uint32_t, g.nnz);
+    const uint64_t e = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint64_t)wave;
+    if (e >= nnz) return;
+    const sptr<uint32_t> indptr = as_scalar<uint32_t>(PW_KARG(uint64_t, g.indptr));
+    const uint32_t cur = uni(as_scalar<uint32_t>(PW_KARG(uint64_t, g.indices))[e]);
+    const uint32_t s0 = indptr[cur], d = indptr[cur + 1] - s0;
+    if (d <= CHAIN_CKPT) return;
+    const uint32_t prev = uni(as_scalar<uint32_t>(kernarg<uint64_t>(XARG))[e]);
+    const uint32_t t0 = indptr[prev], dp = indptr[prev + 1] - t0;
+    WalkArgs la = reload_walk_args();
+    la.g.step_edge = (uint32_t)e;
+    float ktot = __uint_as_float(uni(__float_as_uint(la.tot_e[e])));
+    const unsigned long long off = as_scalar<unsigned long long>(kernarg<uint64_t>(XARG + 8))[e];
+    float *out = (float *)kernarg<uint64_t>(XARG + 16) + off;
+    (void)sample_step_weighted<float, false>(la, s_mask[wave], EXTEND ? s_in[EXTEND ? wave : 0] : nullptr, s_queue[wave], cur, true, prev, t0, dp,
+                                             0.0, s0, d, &ktot, nullptr, 0u, nullptr, out);
 }
 
 // test hook (pw_lane_index_export): the list of every entry, decoded to uint32, at off[e] of `out`

@@ -311,6 +311,7 @@ constexpr int WAVES_PER_BLOCK = 4;
 #endif
 constexpr int MASK_WORDS = PW_MASK_WORDS;        // per wave: 32*MASK_WORDS neighbours per segment
 constexpr uint32_t SEG = MASK_WORDS * 32;
+constexpr uint32_t CHAIN_CKPT = 1024;   // weighted lane form: spacing of the recorded chain values (divides SEG, multiple of the scan's 256-element trips)
 constexpr int EPL = 4;                           // elements per lane per generic scan pass
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
 __device__ __forceinline__ double uni(double v) {
@@ -1325,7 +1326,12 @@ template <typename T, bool DENSE>
 __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint32_t *mask, uint32_t *in_mask,
                                                          uint32_t *queue, uint32_t cur, bool has_prev, uint32_t prev,
                                                          uint32_t t0, uint32_t dp, double r, uint32_t s0,
-                                                         uint32_t d, const T *known_tot = nullptr, T *tot_out = nullptr) {
+                                                         uint32_t d, const T *known_tot = nullptr, T *tot_out = nullptr,
+                                                         uint32_t k_start = 0, const T *c_start = nullptr, T *ckpt_out = nullptr) {
+    // k_start / c_start (round 4, weighted lane form): the CDF search starts at element k_start (a multiple of CHAIN_CKPT)
+    // with the chain's exact value after element k_start - 1 -- every earlier partial sum is known to stay below r.
+    // ckpt_out: no search; the normalised chain is run over the whole row and its value after every CHAIN_CKPT elements is
+    // recorded (ckpt_out[m] = c after element (m + 1) * CHAIN_CKPT - 1, for (m + 1) * CHAIN_CKPT < d).
     const uint32_t *__restrict__ indices = a.g.indices;
     const T *__restrict__ data = (const T *)a.g.data;
     const bool extend = in_mask != nullptr;
@@ -1384,14 +1390,32 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     // pass 2: cdf search
     rv.normalize = true;
     rv.tot = tot;
-    T c = (T)0;
+    if (ckpt_out) {   // the whole normalised chain, recorded every CHAIN_CKPT elements (chunks never straddle a mask segment)
+        T c = (T)0;
+        for (uint32_t sa = 0; sa < d; sa += SEG) {
+            const uint32_t len = d - sa < SEG ? d - sa : SEG;
+            if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);
+            rv.seg_a = sa;
+            for (uint32_t kb = sa; kb < sa + len; kb += CHAIN_CKPT) {
+                const uint32_t ke = kb + CHAIN_CKPT < sa + len ? kb + CHAIN_CKPT : sa + len;
+                // (the scan works in 256-element trips that may reach past its end after a binade crossing: the VALUES beyond
+                //  the chunk have to read as zero, which is what rv.kend does -- not the scan's own end)
+                rv.kend = ke;
+                (void)seq_scan<T, false>(c, kb, ke, 0.0, rv, kb == 0 ? WAVE : 0);
+                if (ke < d && (ke % CHAIN_CKPT) == 0u && lane_id() == 0) ckpt_out[ke / CHAIN_CKPT - 1u] = c;
+            }
+        }
+        return 0;
+    }
+    T c = c_start ? *c_start : (T)0;
     uint32_t choice = NOT_FOUND;
-    for (uint32_t sa = 0; sa < d && choice == NOT_FOUND; sa += SEG) {
+    for (uint32_t sa = (k_start / SEG) * SEG; sa < d && choice == NOT_FOUND; sa += SEG) {
         uint32_t len = d - sa < SEG ? d - sa : SEG;
         if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
-        choice = seq_scan<T, true>(c, sa, sa + len, r, rv, sa == 0 ? WAVE : 0);
+        const uint32_t kbeg = k_start > sa ? k_start : sa;
+        choice = seq_scan<T, true>(c, kbeg, sa + len, r, rv, kbeg == 0 ? WAVE : 0);
     }
     return choice == NOT_FOUND ? d : choice;
 }

@@ -338,3 +338,39 @@ def test_overflow_reads_step_through_the_vertex_overflow_line(monkeypatch):
         assert np.array_equal(got2, want)
         assert plain.last_stats["redo_walks"] >= plain.last_stats["overflow_reads"] == ost.overflow_reads
     assert seen > 20
+
+
+@pytest.mark.parametrize("extend,gamma,p,q", [(False, 0, 0.5, 2), (False, 0, 0.3, 1.7), (True, 0, 0.5, 2), (True, 0.5, 1.5, 0.3),
+                                               (True, 0, 4, 0.25), (False, 0, 1, 1)])
+def test_weighted_lane_form_equals_the_oracle_and_the_wave_kernel(extend, gamma, p, q, monkeypatch):
+    """The WEIGHTED form of the lane kernel (round 4: float64 prefix sums + a rigorous bound on the float32 chain, the rest
+    parked for the wave-per-walk scan): weighted R-MAT graphs, node2vec and node2vec+ (gamma 0 / 0.5), dyadic and
+    non-dyadic p, q -- bit-exact against the oracle and against the wave-per-walk kernel, most steps decided by the lane."""
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, data = rmat_csr(12, seed=5, weighted=True)
+    n = indptr.size - 1
+    thr = None
+    if extend:
+        g = node2vec.SparseOTF.from_csr(indptr, indices, data, extend=True, gamma=gamma)
+        with np.errstate(all="ignore"):
+            thr = np.nan_to_num(g.get_noise_thresholds(), nan=0.0)
+    starts = orc.shuffled_starts(n, 10, 2)
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, 40, 2, thr=thr, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    if extend:
+        eng.set_thresholds(thr)
+    monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "0")          # queueing rounds whatever the size of the job array
+    got = eng.simulate("SparseOTF", p, q, extend, starts, 40, seed=2)
+    st = dict(eng.last_stats)
+    assert st["lane_kernel"] == 3, st
+    assert np.array_equal(got, want), (extend, p, q)
+    assert (st["total_steps"], st["overflow_reads"]) == (ost.total_steps, ost.overflow_reads)
+    assert 0 < st["eager_steps"] < 0.5 * st["total_steps"], st          # (first steps + what the bound leaves open)
+    monkeypatch.setenv("PECANPY_AMD_NO_WLANES", "1")
+    wave = eng.simulate("SparseOTF", p, q, extend, starts, 40, seed=2)
+    assert eng.last_stats["lane_kernel"] == 0 and np.array_equal(wave, got)
+    monkeypatch.delenv("PECANPY_AMD_NO_WLANES")
+    monkeypatch.delenv("PECANPY_AMD_CHAIN_TAIL")
+    small = eng.simulate("SparseOTF", p, q, extend, starts[:300], 40, seed=2)      # no queue: such walks go to walk_kernel
+    assert np.array_equal(small, want[:300])
