@@ -1411,10 +1411,13 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         HIP_TRY(hipMemcpyAsync(&parked, g->counters.p + 32, sizeof(parked), hipMemcpyDeviceToHost, g->stream));
         HIP_TRY(hipStreamSynchronize(g->stream));
         if (parked && weighted) {   // the parked steps of the weighted form: one wavefront each, the wave-per-walk scan
-            if (extend) hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<true>, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa,
+            HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, sizeof(unsigned long long), g->stream));   // (record counter of the persistent grid)
+            const uint64_t want_e = (parked + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
+            const unsigned egrid_e = (unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * 8);
+            if (extend) hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<true>, dim3(egrid_e), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa,
                                            g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
                                            (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));
-            else hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<false>, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa,
+            else hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<false>, dim3(egrid_e), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa,
                                     g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
                                     (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));
             HIP_TRY(hipGetLastError());
@@ -1423,8 +1426,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
                                g->susp[round & 1].p, (uint64_t)parked, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 1);
             HIP_TRY(hipGetLastError());
             if (g->list_max_len != 0xffffffffu) {   // partial index: the steps whose entry's list was left out (one wavefront each)
-                hipLaunchKernelGGL(pw::lanes_eager_kernel, dim3((unsigned)parked), dim3(pw::WAVE), 0, g->stream, wa, g->susp[round & 1].p,
-                                   (uint64_t)parked, g->counters.p + 12);
+                HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, sizeof(unsigned long long), g->stream));
+                const uint64_t want_e = (parked + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
+                hipLaunchKernelGGL(pw::lanes_eager_kernel, dim3((unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * 8)),
+                                   dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa, g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12);
                 HIP_TRY(hipGetLastError());
             }
         }

@@ -326,6 +326,25 @@ PW_HD ListView list_view_of(const void *cl, uint32_t wide, uint32_t n_cl, uint32
     return v;
 }
 
+// first index i in [0, n) with cl.at(i) >= x (n: none) -- the pivots first (entries (k + 1) * step: probes of the edge line),
+// then a bisection of what is left
+PW_HD uint32_t list_lower_bound_pos(const ListView &cl, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    if (cl.npiv) {
+        uint32_t klo = 0, khi = cl.npiv;
+        while (klo < khi) {
+            const uint32_t km = (klo + khi) >> 1;
+            if (cl.pivot(km) >= x) { khi = km; hi = (km + 1u) * cl.step; }
+            else { klo = km + 1u; lo = (km + 1u) * cl.step + 1u; }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cl.at(mid) < x) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
 // floor(a / b) for a, b < 2^52, b > 0, through one float64 division (a 64-bit integer division costs ~200
 // instructions on the GPU; this is ~35)
 PW_HD uint64_t div_floor_small(uint64_t a, uint64_t b) {

@@ -871,19 +871,24 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
 // is established the way walk_kernel does without lists (key stream -> filter -> adjacency index: sample_step_unit with
 // step_edge = none), the float32 chain decides, and the record's `choice` is what the next lane round applies.
 // n, q: kernel arguments behind WalkArgs (read from the kernarg segment like walk_kernel's)
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
 lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused) {
-    __shared__ uint32_t s_mask[MASK_WORDS];
-    __shared__ uint16_t s_rank[MASK_WORDS + 2];
-    __shared__ uint32_t s_queue[2 * QCAP];
+    // (persistent: the wavefronts of a fixed grid stride over the records -- one workgroup per record is bound by the dispatch
+    //  rate, see lanes_eager_weighted_kernel)
+    __shared__ uint32_t s_mask_all[WAVES_PER_BLOCK][MASK_WORDS];
+    __shared__ uint16_t s_rank_all[WAVES_PER_BLOCK][MASK_WORDS + 2];
+    __shared__ uint32_t s_queue_all[WAVES_PER_BLOCK][2 * QCAP];
+    const int wave = readfirst_u32(threadIdx.x / WAVE);
+    uint32_t *const s_mask = s_mask_all[wave], *const s_queue = s_queue_all[wave];
+    uint16_t *const s_rank = s_rank_all[wave];
     constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
     SuspRec *q = (SuspRec *)kernarg<uint64_t>(XARG);
     const uint64_t n = kernarg<uint64_t>(XARG + 8);
-    const uint64_t i = blockIdx.x;
-    if (i >= n) return;
+    unsigned long long n_done = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint64_t)wave; i < n; i += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
     const uint4 *qp = (const uint4 *)(q + i);
     const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) return;
+    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) continue;
     WalkArgs la = reload_walk_args();
     const ELine *lines = (const ELine *)la.g.tri;
     const uint32_t e = uni(q1.z);
@@ -914,10 +919,11 @@ lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsi
         choice = sample_step_unit<float, false>(la, s_mask, s_rank, s_queue, cur, true, prev, t0, dp, r, s0, d);
     }
     choice = uni(choice);
-    if (lane_id() == 0) {
-        q[i].choice = choice;      // (>= d: the mirrored overflow read -- the lane kernel's apply handles it like any other)
-        atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), 1ull);
+    if (lane_id() == 0) q[i].choice = choice;      // (>= d: the mirrored overflow read -- the lane kernel's apply handles it like any other)
+    n_done++;
+    wave_lds_fence();
     }
+    if (lane_id() == 0 && n_done) atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), n_done);
 }
 
 // ---- WEIGHTED form: eager steps and the per-(p, q, extend) tables ------------------------------------------------------------
@@ -928,20 +934,26 @@ lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsi
 // with the tables (wckpt_kernel), so it starts at the last recorded value at or before k_safe: at most CHAIN_CKPT + the
 // width of the ambiguity instead of half a hub row.  ck_off[e] = first record of entry e; edge_row[e] = its source vertex.
 template <bool EXTEND>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, EXTEND ? PW_MIN_WAVES - 1 : PW_MIN_WAVES)
 lanes_eager_weighted_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused,
                             const uint32_t *edge_row_unused, const unsigned long long *ck_off_unused, const float *ck_unused) {
-    __shared__ uint32_t s_mask[MASK_WORDS];
-    __shared__ uint32_t s_in[EXTEND ? MASK_WORDS : 1];
-    __shared__ uint32_t s_queue[2 * QCAP];
+    // PERSISTENT: one workgroup per record (a single wavefront each) was bound by the workgroup dispatch rate -- 81 M launches/s,
+    // 1.1 resident wavefronts per SIMD for a kernel whose records take 14 us each (590 ms per C5 pass); the wavefronts of a
+    // fixed grid stride over the records instead.
+    __shared__ uint32_t s_mask_all[WAVES_PER_BLOCK][MASK_WORDS];
+    __shared__ uint32_t s_in_all[EXTEND ? WAVES_PER_BLOCK : 1][EXTEND ? MASK_WORDS : 1];
+    __shared__ uint32_t s_queue_all[WAVES_PER_BLOCK][2 * QCAP];
+    const int wave = readfirst_u32(threadIdx.x / WAVE);
+    uint32_t *const s_mask = s_mask_all[wave], *const s_in = s_in_all[EXTEND ? wave : 0], *const s_queue = s_queue_all[wave];
     constexpr size_t XARG = (sizeof(WalkArgs) + 7) & ~(size_t)7;
     SuspRec *q = (SuspRec *)kernarg<uint64_t>(XARG);
     const uint64_t n = kernarg<uint64_t>(XARG + 8);
-    const uint64_t i = blockIdx.x;
-    if (i >= n) return;
+    // (records by a fixed stride: a shared counter would serialise 5 M atomics per launch on one L2 channel -- 40 M/s)
+    unsigned long long n_done = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint64_t)wave; i < n; i += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
     const uint4 *qp = (const uint4 *)(q + i);
     const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];
-    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) return;
+    if (uni(q0.x) == NOT_FOUND || uni(q2.x) != LANE_EAGER_MARK) continue;
     WalkArgs la = reload_walk_args();
     const ELine *lines = (const ELine *)la.g.tri;
     const uint32_t e = uni(q1.z), j = uni(q0.y);
@@ -952,7 +964,7 @@ lanes_eager_weighted_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unu
         cur = uni(lines[e].nxt);
         prev = e >= la.g.nnz ? e - la.g.nnz : uni(as_scalar<uint32_t>(kernarg<uint64_t>(XARG + 24))[e]);
     }
-    const uint32_t s0 = uni(la.g.indptr[cur]), d = uni(la.g.indptr[cur + 1]) - s0;
+    const uint32_t s0 = uni(q0.z), d = uni(q0.w);               // (cur's row: the record carries it)
     const uint32_t t0 = has_prev ? uni(la.g.indptr[prev]) : 0u, dp = has_prev ? uni(la.g.indptr[prev + 1]) - t0 : 0u;
     const double r = __longlong_as_double((long long)(((unsigned long long)uni(q3.w) << 32) | uni(q3.z)));
     float ktot = 0.0f;
@@ -975,12 +987,14 @@ lanes_eager_weighted_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unu
     }
     la.g.step_edge = (has_prev && e < la.g.nnz) ? e : NOT_FOUND;
     uint32_t choice = sample_step_weighted<float, false>(la, s_mask, EXTEND ? s_in : nullptr, s_queue, cur, has_prev, prev, t0, dp, r, s0, d,
-                                                         have_tot ? &ktot : nullptr, nullptr, k_start, k_start ? &c_start : nullptr);
+                                                         have_tot ? &ktot : nullptr, nullptr, k_start, k_start ? &c_start : nullptr, nullptr,
+                                                         2u * CHAIN_CKPT, uni(q1.y), has_prev);   // (q1.y: prev's position in cur's row)
     choice = uni(choice);
-    if (lane_id() == 0) {
-        q[i].choice = choice;
-        atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), 1ull);
+    if (lane_id() == 0) q[i].choice = choice;
+    n_done++;          // (counted per wavefront: one atomic per RECORD on a single address runs at ~80 M/s -- it was the kernel's pace)
+    wave_lds_fence();
     }
+    if (lane_id() == 0 && n_done) atomicAdd((unsigned long long *)kernarg<uint64_t>(XARG + 16), n_done);
 }
 
 // Base value of every CSR entry (v -> x): the value of x in v's row for a walker whose prev is neither x nor adjacent to x --

@@ -894,13 +894,9 @@ __device__ __forceinline__ uint32_t build_mask_list(const CsrDev &g, uint32_t *m
     const ListView P = edge_list(lines, g.clist, e, d, n_in, lines[e].coff);
     // list entries whose position lies in [a, a + len) (the list is ascending; one segment: all of them)
     uint32_t lo_i = 0, hi_i = n_in;
-    if (a != 0 || len < d) {
-        uint32_t lo = 0, hi = n_in;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P.at(mid) < a) lo = mid + 1; else hi = mid; }
-        lo_i = lo;
-        hi = n_in;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P.at(mid) < a + len) lo = mid + 1; else hi = mid; }
-        hi_i = lo;
+    if (a != 0 || len < d) {   // (the list's pivots, in the entry's own line, resolve the upper levels of both searches)
+        lo_i = a ? list_lower_bound_pos(P, n_in, a) : 0u;
+        hi_i = a + len < d ? list_lower_bound_pos(P, n_in, a + len) : n_in;
     }
     ListView Q = P;
     if (in_mask) {
@@ -1327,11 +1323,15 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
                                                          uint32_t *queue, uint32_t cur, bool has_prev, uint32_t prev,
                                                          uint32_t t0, uint32_t dp, double r, uint32_t s0,
                                                          uint32_t d, const T *known_tot = nullptr, T *tot_out = nullptr,
-                                                         uint32_t k_start = 0, const T *c_start = nullptr, T *ckpt_out = nullptr) {
+                                                         uint32_t k_start = 0, const T *c_start = nullptr, T *ckpt_out = nullptr,
+                                                         uint32_t window = 0, uint32_t known_prev_pos = NOT_FOUND, bool prev_pos_known = false) {
     // k_start / c_start (round 4, weighted lane form): the CDF search starts at element k_start (a multiple of CHAIN_CKPT)
     // with the chain's exact value after element k_start - 1 -- every earlier partial sum is known to stay below r.
     // ckpt_out: no search; the normalised chain is run over the whole row and its value after every CHAIN_CKPT elements is
     // recorded (ckpt_out[m] = c after element (m + 1) * CHAIN_CKPT - 1, for (m + 1) * CHAIN_CKPT < d).
+    // window (with a known normaliser): the search works on windows of that many elements instead of whole mask segments --
+    // the membership mask is scattered from the arriving entry's list for the window only (a hub-to-hub entry's list has
+    // thousands of entries; the scan of a parked step ends within a window or two of where it starts).
     const uint32_t *__restrict__ indices = a.g.indices;
     const T *__restrict__ data = (const T *)a.g.data;
     const bool extend = in_mask != nullptr;
@@ -1360,11 +1360,15 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
         rv.thr_cur = __uint_as_float(uni(__float_as_uint(a.g.thr[cur])));
     }
 
-    const bool multi = has_prev && d > SEG;
+    const uint32_t seg = (window && known_tot && !ckpt_out) ? window : SEG;
+    const bool multi = has_prev && (d > SEG || (seg < SEG && d > seg));
     // prev's position is needed by every segment: find it once when the row is segmented
     if (multi) {
-        uint32_t pos = uni(lower_bound_u32(indices + s0, d, prev));
-        if (pos < d && uni(indices[s0 + pos]) == prev) rv.prev_pos = pos;
+        if (prev_pos_known) rv.prev_pos = known_prev_pos;   // (the caller has it from the arriving entry's record)
+        else {
+            uint32_t pos = uni(lower_bound_u32(indices + s0, d, prev));
+            if (pos < d && uni(indices[s0 + pos]) == prev) rv.prev_pos = pos;
+        }
     }
 
     // pass 1: tot
@@ -1409,8 +1413,8 @@ __device__ __forceinline__ uint32_t sample_step_weighted(const WalkArgs &a, uint
     }
     T c = c_start ? *c_start : (T)0;
     uint32_t choice = NOT_FOUND;
-    for (uint32_t sa = (k_start / SEG) * SEG; sa < d && choice == NOT_FOUND; sa += SEG) {
-        uint32_t len = d - sa < SEG ? d - sa : SEG;
+    for (uint32_t sa = (k_start / seg) * seg; sa < d && choice == NOT_FOUND; sa += seg) {
+        uint32_t len = d - sa < seg ? d - sa : seg;
         if (multi) (void)segment_mask<T, DENSE>(a.g, mask, in_mask, queue, cur, s0, sa, len, t0, dp, prev);  // single segment: still valid
         rv.seg_a = sa;
         rv.kend = sa + len;
