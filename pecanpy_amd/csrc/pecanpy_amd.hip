@@ -112,7 +112,8 @@ struct pw_graph {
     int wl_extend = -1;
     uint64_t wl_thr_version = 0;
     bool wl_failed = false;
-    bool wl_active = false;                             // the current call runs the weighted lane form
+    bool wl_active = false;                             // the current call may run the weighted lane form (tables are there)
+    bool wl_used = false;                               // ... and did
     double tot_p = 0, tot_q = 0;                        // ... built for these parameters
     int tot_extend = -1;                                // -1: none yet
     uint64_t tot_thr_version = 0, thr_version = 0;      // thresholds uploaded since the table was built?
@@ -1548,7 +1549,16 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
 
 static int launch_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
     const bool floats = lanes_float_eligible(g, wa);
-    const bool wlanes = g->wl_active && !wa.job_list;   // (repair passes of a weighted directed graph: the wave kernel)
+    // weighted lane form: whole job arrays only (repair passes of a directed graph run on job lists: the wave kernel), and
+    // only when the rounds have a queue -- the in-place form can do nothing with a step it cannot decide (first steps
+    // included) but hand the walk to walk_kernel
+    bool wlanes = g->wl_active && !wa.job_list;
+    if (wlanes) {
+        const char *tail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
+        const uint64_t wtail = tail_env ? (uint64_t)strtoull(tail_env, nullptr, 10) : 8192ull;
+        if (wa.n_jobs <= wtail || getenv("PECANPY_AMD_NO_CHAIN_QUEUE")) wlanes = false;
+    }
+    if (wlanes) g->wl_used = true;
     if (!floats && !wlanes && !lanes_eligible(g, wa)) return launch_wave_walks(g, wa, extend, redo_total);
     uint64_t n_redo = 0;
     int rc = wlanes ? launch_lane_walks(g, wa, &n_redo, true, extend)
@@ -1761,7 +1771,10 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     rc = ensure_tot_table(g, wa, extend != 0);   // (before the timed walk region: a per-(p, q) index, reported apart)
     if (rc) return rc;
     g->wl_active = false;
-    if (mode == PW_MODE_SPARSE_OTF) {
+    g->wl_used = false;
+    const char *wtail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
+    const uint64_t wtail = wtail_env ? (uint64_t)strtoull(wtail_env, nullptr, 10) : 8192ull;
+    if (mode == PW_MODE_SPARSE_OTF && n_jobs > wtail && !getenv("PECANPY_AMD_NO_CHAIN_QUEUE")) {   // (the rule of launch_walks)
         rc = ensure_wlane_tables(g, wa, extend != 0, &g->wl_active);   // (likewise; the weighted lane form needs both)
         if (rc) return rc;
         if (g->wl_active) {   // the lane kernel only writes the cells a walk fills (unit graphs: zero-filled on the side stream above)
@@ -1769,7 +1782,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         }
     }
     uint64_t redo_total = 0;
-    const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa) || g->wl_active;
+    const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa);
     g->lane_ms = 0;
     g->lane_rounds = 0;
     g->ver_checked = g->ver_mismatch = g->ver_dropped = g->ver_ties = 0;
@@ -1858,7 +1871,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.overflow_reads = h[2];
     st.clamped_reads = h[3];
     st.dead_end_walks = dead;
-    st.lane_kernel = lanes ? (g->wl_active ? 3u : (lanes_float_eligible(g, wa) ? 2u : 1u)) : 0u;
+    st.lane_kernel = g->wl_used ? 3u : (lanes ? (lanes_float_eligible(g, wa) ? 2u : 1u) : 0u);
     st.redo_walks = redo_total;
     st.list_entries_read = h[7];
     st.ambiguous_steps = h[8];

@@ -374,3 +374,39 @@ def test_weighted_lane_form_equals_the_oracle_and_the_wave_kernel(extend, gamma,
     monkeypatch.delenv("PECANPY_AMD_CHAIN_TAIL")
     small = eng.simulate("SparseOTF", p, q, extend, starts[:300], 40, seed=2)      # no queue: such walks go to walk_kernel
     assert np.array_equal(small, want[:300])
+
+
+def test_weighted_lane_form_on_a_directed_graph_with_dead_ends(monkeypatch):
+    """Weighted DIRECTED graphs through the weighted lane form: entries without a reverse edge (prev is not in cur's row),
+    dead ends that shorten walks and shift the stream addresses (repair passes: job lists, wave kernel).  A graph with a
+    single rarely-reached sink: the oracle's walks, draw for draw; a sink-heavy one (the engine may fall back to nominal
+    stream addressing, reported): equal to the wave-per-walk kernel."""
+    rng = np.random.default_rng(21)
+    m = 4000
+    monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "0")
+    monkeypatch.setenv("PECANPY_AMD_FORCE_TOT", "1")
+    for sinks in ("one", "many"):
+        src, dst = rng.integers(0, m, 90000), rng.integers(0, m, 90000)
+        keep = (src != dst) & ((src != 1234) if sinks == "one" else (src % 97 != 0))
+        if sinks == "one":
+            keep &= ~((dst == 1234) & (rng.random(dst.size) < 0.8))      # ... with few in-edges
+        indptr, indices, _ = csr_from_edges(src[keep], dst[keep], m)
+        data = (rng.random(indices.size) * 0.999 + 0.001).astype(np.float32)
+        starts = orc.shuffled_starts(m, 6, 5)
+        L = 10 if sinks == "one" else 30
+        eng = WalkEngine.from_csr(indptr, indices, data)
+        for p, q in ((0.5, 2.0), (1.3, 0.7)):
+            want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts, L, 5, return_stats=True)
+            got = eng.simulate("SparseOTF", p, q, False, starts, L, seed=5)
+            st = dict(eng.last_stats)
+            assert st["lane_kernel"] == 3 and st["dead_end_walks"] > 0, st
+            if st["stream_addressing"] == 0:
+                assert np.array_equal(got, want), (sinks, p, q)
+                assert st["total_steps"] == ost.total_steps
+            else:
+                assert sinks == "many"
+            monkeypatch.setenv("PECANPY_AMD_NO_WLANES", "1")
+            wave = eng.simulate("SparseOTF", p, q, False, starts, L, seed=5)
+            assert eng.last_stats["lane_kernel"] == 0 and eng.last_stats["stream_addressing"] == st["stream_addressing"]
+            monkeypatch.delenv("PECANPY_AMD_NO_WLANES")
+            assert np.array_equal(got, wave), (sinks, p, q)
