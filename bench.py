@@ -359,8 +359,9 @@ def main():
         print("bench.py: gathered shards verified against a whole-array run", file=sys.stderr)
 
     # ---- roofline of the dominant kernel (rank 0's shard) ------------------------------------------------------
-    lane = bool(st["lane_kernel"])
-    k_ms = float(np.mean(acc["lane_kernel_ms"] if lane else acc["walk_kernel_ms"]))
+    lane = int(st["lane_kernel"]) in (1, 2)          # (3 = the weighted lane form: its own accounting below)
+    wlane = int(st["lane_kernel"]) == 3
+    k_ms = float(np.mean(acc["lane_kernel_ms"] if (lane or wlane) else acc["walk_kernel_ms"]))
     steps0 = int(acc["total_steps"][-1])
     walks0 = int(has_nbr[starts[lo:hi]].sum())
     ref_bytes = None
@@ -415,11 +416,26 @@ def main():
         # figure in the reference's element sizes is its declared format
         declared = ref_bytes
         kernel = "walk_kernel<float,false,%s,%s>" % ("true" if not cfg["weighted"] else "false", "true" if extend else "false")
-        fmt = ("SURVEY 8(d): 8*d_cur + 4*d_prev + 28 per step" +
+        if wlane:
+            kernel = ("walk_lanes_kernel<WEIGHTED> (float64-bounded decision per lane) + lanes_eager_weighted_kernel (wave scan of the "
+                      "steps the bound leaves open, from recorded chain values), every round of a pass")
+            # declared format of the weighted lane form: per step the 64-byte edge line, the draw and the
+            # output cell; per search probe a list entry and two float64 table values (18 B: an upper bound, probes inside a run
+            # read one value); per parked step its 64-byte queue record out and back and the scan window of the wave scan
+            # (at most 2 x 1024 elements from the last recorded chain value: 4-byte weights + 4-byte neighbour ids); 36 B per walk
+            probes = int(acc["list_entries_read"][-1])
+            eager = int(st["eager_steps"])
+            declared = (steps0 * (64 + 8 + 4) + probes * 18 + eager * (128 + 2048 * 8) + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
+                        (hi - lo - walks0) * 8)
+            fmt = ("64 B edge line + 8 B draw + 4 B output per step, 18 B per search probe (list entry + two float64 prefix values), "
+                   "per parked step 128 B of queue record + a scan window of at most 2048 elements x 8 B; 36 B per walk")
+        fmt_ref = ("SURVEY 8(d): 8*d_cur + 4*d_prev + 28 per step" +
                (" + 4*d_prev + 4*|N(cur)&N(prev)| + 4 (node2vec+)" if extend else "") +
                " -- the REFERENCE's row traffic, which this kernel's rows mostly take from L2 / Infinity Cache: `frac` here is an "
                "algorithmic-byte rate, NOT an HBM utilisation (that is traffic_frac_of_peak, from the PMC passes); the kernel is "
                "instruction bound (issue_bound)")
+        if not wlane:
+            fmt = fmt_ref
     achieved = declared / (k_ms * 1e-3) / 1e9
     key = f"{key_graph}_{mode}_p{p:g}_q{q:g}{'_ext' if extend else ''}_w{W}_l{L}_seed{args.seed}"
     pmc = load_pmc(key) if world == 1 else None
@@ -448,6 +464,9 @@ def main():
         roofline["traffic_frac_of_random_sector_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / RANDOM_SECTOR_GBS, 4)
     if pmc and "issue" in pmc:
         roofline["issue_bound"] = pmc["issue"]
+    if wlane:
+        roofline["eager_step_frac"] = round(st["eager_steps"] / max(steps0, 1), 5)
+        roofline["lane_rounds"] = int(st["lane_rounds"])
     if lane:
         roofline["ambiguous_step_frac"] = round(acc["ambiguous_steps"][-1] / max(steps0, 1), 5)
         roofline["float_chain_step_frac"] = round(acc["wave_chain_steps"][-1] / max(steps0, 1), 5)

@@ -11,7 +11,7 @@ for c in $CFGS; do
     headline) ARGS="--steps 1 --warmup 0"; KERN="walk_lanes_kernel+lanes_chain_kernel"; KEY="rmat22_SparseOTF_p0.5_q2_w10_l80_seed0";;
     C2) ARGS="--config C2 --steps 1 --warmup 0"; KERN="walk_lanes_kernel+lanes_chain_kernel"; KEY="rmat18_SparseOTF_p0.5_q2_w10_l80_seed0";;
     C3) ARGS="--config C3 --steps 1 --warmup 0"; KERN="walk_lanes_kernel+lanes_chain_kernel"; KEY="rmat22_SparseOTF_p0.25_q4_w10_l80_seed0";;
-    C5) ARGS="--config C5 --steps 1 --warmup 0"; KERN="walk_kernel<float, false, false, true>"; KEY="rmat20w_SparseOTF_p0.5_q2_ext_w10_l80_seed0";;
+    C5) ARGS="--config C5 --steps 1 --warmup 0"; KERN="walk_lanes_kernel+lanes_eager_weighted_kernel"; KEY="rmat20w_SparseOTF_p0.5_q2_ext_w10_l80_seed0";;
     C4) ARGS="--config C4 --steps 1 --warmup 0"; KERN="walk_dense_fast_kernel"; KEY="er100000_DenseOTF_p0.5_q2_w10_l80_seed0";;
   esac
   tools/pmc_run.sh $OUT/$c $ARGS > /dev/null 2>&1
