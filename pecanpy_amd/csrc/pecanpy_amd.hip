@@ -105,6 +105,7 @@ struct pw_graph {
     double *d_wpq = nullptr, *d_wdl = nullptr, *d_wl_dprev = nullptr;
     unsigned long long *d_wl_off = nullptr;
     uint32_t *d_wedge_row = nullptr;                    // ... source vertex of every CSR entry
+    double *d_wp1 = nullptr;                            // ... per-row prefix sums of the raw weights (first steps; graph-static)
     unsigned long long *d_wck_off = nullptr;            // ... recorded chain values (wckpt_kernel): first record of entry e
     float *d_wck = nullptr;
     uint64_t wdl_cap = 0, wck_cap = 0;
@@ -247,7 +248,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
-    for (void *q : {(void *)g->d_wb, (void *)g->d_wpq, (void *)g->d_wdl, (void *)g->d_wl_dprev, (void *)g->d_wl_off, (void *)g->d_wedge_row,
+    for (void *q : {(void *)g->d_wb, (void *)g->d_wpq, (void *)g->d_wdl, (void *)g->d_wl_dprev, (void *)g->d_wl_off, (void *)g->d_wedge_row, (void *)g->d_wp1,
                     (void *)g->d_wck_off, (void *)g->d_wck})
         if (q) (void)hipFree(q);
     g->redo.release();
@@ -1157,8 +1158,11 @@ static int ensure_wlane_tables(pw_graph *g, const pw::WalkArgs &wa, bool extend,
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_off, sizeof(unsigned long long) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wck_off, sizeof(unsigned long long) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wedge_row, sizeof(uint32_t) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wp1, sizeof(double) * (size_t)nnz);
         if (e != hipSuccess) return give_up();
         hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_wedge_row);
+        hipLaunchKernelGGL(pw::wprefix_kernel, dim3((unsigned)(((uint64_t)g->n_nodes * pw::WAVE + 255) / 256)), dim3(256), 0, g->stream, g->d_indptr,
+                           (const float *)g->d_data, g->n_nodes, g->d_wp1);
     }
     uint64_t *d_tiles = nullptr;
     const uint64_t n_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
@@ -1288,6 +1292,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     la.wl_off = g->d_wl_off;
     la.wl_dprev = g->d_wl_dprev;
     la.tot_e = wa.tot_e;
+    la.wp1 = getenv("PECANPY_AMD_NO_WFIRST") ? nullptr : g->d_wp1;
+    la.tot_v = wa.tot_v;
     // TAILS form (the rest of the edge line staged in LDS): for graphs whose edge lines stay cache resident -- there the
     // probes of inline lists and pivots are L2 hits that LDS reads replace; beyond that the HBM probes of the long lists
     // set the pace and the plain form is as fast (PECANPY_AMD_LANE_TAILS = 0 / 1 overrides the size rule)

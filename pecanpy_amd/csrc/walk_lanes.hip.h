@@ -113,6 +113,8 @@ struct LanesArgs {
     const unsigned long long *wl_off;         // [nnz] offset of entry e's deltas; ~0: no table for this entry (eager step)
     const double *wl_dprev;                   // [nnz] (step value - base value) of prev's element when arriving by entry e
     const float *tot_e;                       // [nnz] the step's normaliser (sequential float32 row total) by arriving entry
+    const double *wp1;                        // [nnz] per-row inclusive float64 prefix sums of the RAW weights (first step of a walk)
+    const float *tot_v;                       // [n_nodes] ... and its normaliser, by vertex
 };
 
 // (per-lane exact decision: lane_decide / LaneStep in seqscan.h, shared with the host self test)
@@ -578,7 +580,7 @@ walk_lanes_kernel(LanesArgs a) {
                             for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                     } else {
                         A.soff = ((uint64_t)j1.y << 32) | j1.x;
-                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = 0; A.coff = 0; A.j = 1;
+                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = WEIGHTED ? start : 0u; A.coff = 0; A.j = 1;
                         if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff); }
                         else r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
                         A.flags = F_ACTIVE;
@@ -638,6 +640,15 @@ walk_lanes_kernel(LanesArgs a) {
                 //  an overflow line or an entry without tables likewise)
                 unsigned long long wo_ = ~0ull;
                 if (A.j >= 2u && A.e < a.nnz && !nolist) wo_ = a.wl_off[A.e];
+                if (A.j == 1u && a.wp1) {
+                    // first step: no prev, the raw weights over their sequential float32 total (sparse_rw.py:66-67 / 89) -- the
+                    // same decision on the prefix sums of the raw row (A.e holds the start vertex until the step is applied)
+                    const WeightedRow wr{a.wp1 + A.s0, nullptr, 0.0};
+                    uint32_t probes_ = 0;
+                    choice = lane_decide_weighted(A.d, 0u, NOT_FOUND, r, a.tot_v[A.e], wr, ListView{nullptr, 0u}, probes_, wk_safe);
+                    n_probes += probes_;
+                    if (choice == LANE_REDO) choice = LANE_AMBIGUOUS;
+                }
                 if (wo_ != ~0ull) {
                     const WeightedRow wr{a.wpq + A.s0, a.wdl + wo_, a.wl_dprev[A.e]};
                     uint32_t probes_ = 0;
