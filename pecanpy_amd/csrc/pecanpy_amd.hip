@@ -13,6 +13,8 @@
 #include <random>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <string>
 #include <thread>
@@ -130,10 +132,14 @@ struct pw_graph {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: the zero-fill of the walk matrix runs under the stream expansion
     hipEvent_t ev_side = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // pw_simulate() walks a large job array in parts: the stream of the WHOLE array is expanded once, and while this is
+    // set expand_stream() serves the parts' sub-ranges from g->rng as it stands (never kept across API calls)
+    struct { bool valid = false; uint32_t seed = 0; uint64_t first_block = 0, n_blocks = 0; } rng_hold;
     hipStream_t copy_stream = nullptr;     // pw_simulate: the D2H of one part of the walk matrix runs here, under the walks of the next
-    hipEvent_t ev_copy[2] = {nullptr, nullptr};
-    void *stage[2] = {nullptr, nullptr};   // pinned staging buffers of pw_simulate's copy out
+    static constexpr int N_STAGE = 12;
+    hipEvent_t ev_copy[N_STAGE] = {};
+    void *stage[N_STAGE] = {};             // pinned staging buffers of pw_simulate's copy out
     uint32_t *seed_state = nullptr;        // pinned: the seed's MT19937 state on its way to the device
     double lane_ms = 0;              // lane kernel time of the current call
     int n_cu = 0;
@@ -1325,6 +1331,13 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     if (weighted) tail = 8192;
     if (tail_env) tail = (uint64_t)strtoull(tail_env, nullptr, 10);
     bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
+    // Short job lists (a few jobs per resident lane) run in ONE in-place launch: with so few walks per lane the launch
+    // lasts as long as its slowest walks, and a walk is slower in the queueing form (its deferred steps wait for a full
+    // pass of the wavefront's pool, its chains for the next round) -- that form pays off through throughput only.
+    // (RMAT-16 / -17 / -18, 0.66 / 1.3 / 2.6 M jobs: 5.1 -> 3.4, 9.7 -> 5.8, 13.0 -> 10.7 ms per pass; RMAT-19, 5.2 M jobs:
+    //  18.4 with the queue, 22.1 in place.  PECANPY_AMD_CHAIN_TAIL set: the queue rule alone decides.)
+    // (not with a partial index: without a queue the steps whose list was left out hand their walks to walk_kernel for good)
+    if (!weighted && !tail_env && g->list_max_len == 0xffffffffu && n_work <= 10 * lanes_resident) use_queue = false;
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
     const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;
     if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
@@ -1596,6 +1609,13 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
     const uint64_t first_block = stream_skip / 312;
     const uint64_t end_block = (stream_skip + total + 311) / 312;
     const uint64_t n_blocks = end_block > first_block ? end_block - first_block : 1;
+    if (g->rng_hold.valid && g->rng_hold.seed == seed && first_block >= g->rng_hold.first_block &&
+        first_block + n_blocks <= g->rng_hold.first_block + g->rng_hold.n_blocks) {
+        HIP_TRY(hipEventRecord(g->ev[0], g->stream));   // (nothing to do: the callers still read the pair of events)
+        HIP_TRY(hipEventRecord(g->ev[1], g->stream));
+        *rng_base = g->rng_hold.first_block * 312;
+        return 0;
+    }
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
     uint64_t per_gen = 1;
     int per_gen_log = 0;
@@ -1895,58 +1915,114 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     return PW_OK;
 }
 
-// Device -> pageable host copy through two pinned staging buffers: the DMA of chunk c + 1 runs while chunk c is copied
-// out of its staging buffer by a few host threads (a plain hipMemcpy to pageable memory does both serially at ~1/5 of
-// the PCIe rate; the walk matrix is 13.8 GB at RMAT-22).  The buffers live in the handle.
-static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t bytes) {
-    const size_t CH = (size_t)64 << 20;
-    if (bytes < CH / 2) {
+// Device -> pageable host copy through a ring of pinned staging buffers (a plain hipMemcpy to pageable memory runs at
+// ~1/5 of the PCIe rate; the walk matrix is 13.8 GB at RMAT-22): the calling thread issues the chunk DMAs as buffers
+// come free, a few worker threads each take the next chunk that has landed and copy it to its place (the destination
+// is usually fresh pageable memory -- first-touch page faults set the pace of a thread, so several work side by side,
+// each on a chunk of its own, with no barrier between chunks).  The buffers live in the handle.  `feed` (pw_simulate's
+// parts): the bytes [0, feed->ready) of the source are final -- a chunk's DMA is issued once the producer has
+// announced it, so ONE copy runs through all parts and the link never idles between them.
+struct CopyFeed {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t ready = 0;
+    bool abort = false;
+    void announce(size_t r) { { std::lock_guard<std::mutex> l(m); ready = r; } cv.notify_all(); }
+    void stop() { { std::lock_guard<std::mutex> l(m); abort = true; } cv.notify_all(); }
+    // true once [0, upto) is final (block: wait for it); false: not yet / the producer gave up
+    bool have(size_t upto, bool block) {
+        std::unique_lock<std::mutex> l(m);
+        if (block) cv.wait(l, [&]() { return abort || ready >= upto; });
+        return !abort && ready >= upto;
+    }
+    bool stopped() { std::lock_guard<std::mutex> l(m); return abort; }
+};
+
+static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t bytes, CopyFeed *feed) {
+    const size_t CH = (size_t)8 << 20;
+    constexpr size_t NBUF = pw_graph::N_STAGE;
+    bool pinned = bytes >= 2 * CH;
+    if (pinned)
+        for (auto &b : g->stage)
+            if (!b && hipHostMalloc(&b, CH, hipHostMallocDefault) != hipSuccess) {
+                b = nullptr;
+                (void)hipGetLastError();
+                pinned = false;   // no pinned memory: plain copy
+            }
+    if (!pinned) {
+        if (feed && !feed->have(bytes, true)) return 0;   // (the producer failed: its error is the call's)
         HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g->copy_stream));
         HIP_TRY(hipStreamSynchronize(g->copy_stream));
         return 0;
     }
-    for (auto &b : g->stage)
-        if (!b && hipHostMalloc(&b, CH, hipHostMallocDefault) != hipSuccess) {
-            b = nullptr;
-            (void)hipGetLastError();
-            HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g->copy_stream));   // no pinned memory: plain copy
-            HIP_TRY(hipStreamSynchronize(g->copy_stream));
-            return 0;
-        }
-    // (the destination is usually fresh pageable memory: the copy is bound by first-touch page faults per thread)
     static const int T_env = getenv("PECANPY_AMD_COPY_THREADS") ? atoi(getenv("PECANPY_AMD_COPY_THREADS")) : 0;
     const int T_use = T_env > 0 ? (T_env > 32 ? 32 : T_env) : 8;
-    auto fan_out = [T_use](char *to, const char *from, size_t n) {
-        const int T = T_use;
-        std::thread th[32];
-        const size_t part = (n / T + 4095) & ~(size_t)4095;
-        for (int t = 0; t < T; t++) {
-            const size_t lo = (size_t)t * part, hi = lo + part < n ? lo + part : n;
-            th[t] = std::thread([=]() { if (lo < hi) memcpy(to + lo, from + lo, hi - lo); });
-        }
-        for (int t = 0; t < T; t++) th[t].join();
-    };
     const size_t n_ch = (bytes + CH - 1) / CH;
     const bool dbg = getenv("PECANPY_AMD_COPY_DEBUG") != nullptr;
-    double t_wait = 0, t_copy = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (size_t c = 0; c <= n_ch; c++) {
-        if (c < n_ch) {
-            const size_t off = c * CH, len = off + CH < bytes ? CH : bytes - off;
-            HIP_TRY(hipMemcpyAsync(g->stage[c & 1], (const char *)d_src + off, len, hipMemcpyDeviceToHost, g->copy_stream));
-            HIP_TRY(hipEventRecord(g->ev_copy[c & 1], g->copy_stream));
+    auto chunk_len = [&](size_t c) { return c * CH + CH < bytes ? CH : bytes - c * CH; };
+    struct Ring {
+        std::mutex m;
+        std::condition_variable cv;
+        size_t issued = 0, next = 0;        // chunks whose DMA + event are on the copy stream / handed to a worker
+        size_t drained[NBUF] = {};          // buffer b: 1 + the last chunk copied out of it
+        bool stop = false;
+        hipError_t err = hipSuccess;
+    } ring;
+    auto worker = [&]() {
+        (void)hipSetDevice(g->device);
+        for (;;) {
+            size_t c;
+            {
+                std::unique_lock<std::mutex> l(ring.m);
+                c = ring.next;
+                if (c >= n_ch || ring.stop) return;
+                ring.next++;
+                ring.cv.wait(l, [&]() { return ring.stop || ring.issued > c; });
+                if (ring.stop) return;
+            }
+            const hipError_t e = hipEventSynchronize(g->ev_copy[c % NBUF]);
+            if (e == hipSuccess) memcpy((char *)dst + c * CH, g->stage[c % NBUF], chunk_len(c));
+            {
+                std::lock_guard<std::mutex> l(ring.m);
+                if (e != hipSuccess) { ring.err = e; ring.stop = true; }
+                ring.drained[c % NBUF] = c + 1;
+            }
+            ring.cv.notify_all();
         }
-        if (c > 0) {
-            const size_t off = (c - 1) * CH, len = off + CH < bytes ? CH : bytes - off;
-            const double t0 = now();
-            HIP_TRY(hipEventSynchronize(g->ev_copy[(c - 1) & 1]));
-            const double t1 = now();
-            fan_out((char *)dst + off, (const char *)g->stage[(c - 1) & 1], len);
-            t_wait += t1 - t0;
-            t_copy += now() - t1;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T_use; t++) pool.emplace_back(worker);
+    double t_feed = 0, t_ring = 0;
+    hipError_t issue_err = hipSuccess;
+    bool gave_up = false;
+    for (size_t c = 0; c < n_ch; c++) {
+        const double t0 = now();
+        if (feed && !feed->have(c * CH + chunk_len(c), true)) { gave_up = true; break; }   // (the producer failed: its error is the call's)
+        const double t1 = now();
+        {   // the buffer's previous chunk has been copied out
+            std::unique_lock<std::mutex> l(ring.m);
+            ring.cv.wait(l, [&]() { return ring.stop || c < NBUF || ring.drained[c % NBUF] == c - NBUF + 1; });
+            if (ring.stop) break;
         }
+        t_feed += t1 - t0;
+        t_ring += now() - t1;
+        issue_err = hipMemcpyAsync(g->stage[c % NBUF], (const char *)d_src + c * CH, chunk_len(c), hipMemcpyDeviceToHost, g->copy_stream);
+        if (issue_err == hipSuccess) issue_err = hipEventRecord(g->ev_copy[c % NBUF], g->copy_stream);
+        if (issue_err != hipSuccess) break;
+        { std::lock_guard<std::mutex> l(ring.m); ring.issued = c + 1; }
+        ring.cv.notify_all();
     }
-    if (dbg) fprintf(stderr, "[copy_out] %.2f GB: waiting for DMA %.1f ms, host copies %.1f ms (%d threads)\n", bytes / 1e9, t_wait * 1e3, t_copy * 1e3, T_use);
+    {
+        std::lock_guard<std::mutex> l(ring.m);
+        if (gave_up || issue_err != hipSuccess) ring.stop = true;   // (workers still waiting for a chunk that will not come)
+    }
+    ring.cv.notify_all();
+    for (auto &th : pool) th.join();
+    if (issue_err != hipSuccess) return fail(PW_ERR_HIP, hipGetErrorString(issue_err));
+    if (ring.err != hipSuccess) return fail(PW_ERR_HIP, hipGetErrorString(ring.err));
+    if (dbg) fprintf(stderr, "[copy_out] %.2f GB in %zu chunks: issuer waited %.1f ms for the walks, %.1f ms for a free buffer (%d copy threads)\n",
+                     bytes / 1e9, n_ch, t_feed * 1e3, t_ring * 1e3, T_use);
     return 0;
 }
 
@@ -1970,19 +2046,44 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     const double t2 = now();
     // The matrix leaves the device at the PCIe rate (RMAT-18: 17 ms for 0.86 GB against 13 ms of walks): large job arrays
     // are walked in PARTS and the copy of part k (helper thread, copy stream, pinned staging) runs under the kernels of
-    // part k + 1.  Part k + 1's stream address = draws the earlier parts ACTUALLY consumed, so the walks are those of one
+    // part k + 1 (the copy is the longer of the two: one chunked copy follows the parts, the link stays busy throughout).  Part k + 1's stream address = draws the earlier parts ACTUALLY consumed, so the walks are those of one
     // call whatever the split (dead ends included).  Alias modes consume a variable number of words per step: one part.
     const size_t row_bytes = sizeof(uint32_t) * ((size_t)walk_length + 2);
     int n_parts = 1;
-    if (mode < PW_MODE_PRECOMP && (size_t)n_jobs * row_bytes >= ((size_t)128 << 20) && !getenv("PECANPY_AMD_NO_PARTS")) n_parts = 4;
+    // (the first part's walks are the only ones the copy does not hide: more parts while a part stays a launch worth making --
+    //  RMAT-18, 0.86 GB: 4 / 8 / 16 parts -> 22.7 / 21.5 / 29.0 ms per call)
+    if (mode < PW_MODE_PRECOMP && (size_t)n_jobs * row_bytes >= ((size_t)128 << 20) && !getenv("PECANPY_AMD_NO_PARTS"))
+        n_parts = (size_t)n_jobs * row_bytes >= ((size_t)800 << 20) ? 8 : 4;
     if (const char *pe = getenv("PECANPY_AMD_PARTS")) { n_parts = atoi(pe); if (n_parts < 1 || mode >= PW_MODE_PRECOMP) n_parts = 1; }
     if (!has_seed && n_parts > 1) { seed = os_seed(); has_seed = 1; }   // (every part walks the same stream)
     pw_stats total;
     memset(&total, 0, sizeof(total));
+    CopyFeed feed;
     std::thread copier;
     int copy_rc = 0;
     std::string copy_err;
     uint64_t skip = stream_skip;
+    // the draws of the whole array, expanded once (a part's range -- offset by what the earlier parts consumed, never more
+    // than their nominal share -- lies inside): one jump tree instead of one per part
+    struct HoldGuard {
+        pw_graph *g;
+        ~HoldGuard() { g->rng_hold.valid = false; }
+    } hold_guard{g};
+    if (!rc && n_parts > 1) {
+        if (g->counters.ensure(N_COUNTERS)) rc = PW_ERR_NOMEM;
+        if (!rc) rc = check_starts(g, d_starts, n_jobs);
+        uint64_t nominal = 0, base = 0;
+        if (!rc) rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, false, &nominal, nullptr);
+        if (!rc) (void)hipEventRecord(g->ev[7], g->stream);
+        if (!rc) rc = expand_stream(g, seed, true, stream_skip, nominal, &base);
+        if (!rc) {
+            (void)hipEventRecord(g->ev[6], g->stream);   // (ev[0] / ev[1] are recorded again by every part)
+            g->rng_hold.valid = true;
+            g->rng_hold.seed = seed;
+            g->rng_hold.first_block = base / 312;
+            g->rng_hold.n_blocks = (stream_skip + nominal + 311) / 312 > base / 312 ? (stream_skip + nominal + 311) / 312 - base / 312 : 1;
+        }
+    }
     for (int part = 0; part < n_parts && !rc; part++) {
         const uint64_t lo = (uint64_t)part * n_jobs / n_parts, hi = (uint64_t)(part + 1) * n_jobs / n_parts;
         pw_stats st;
@@ -2002,17 +2103,22 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
             total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch; total.verify_dropped += st.verify_dropped;
             total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
         }
-        if (copier.joinable()) copier.join();          // (one copy at a time: they share the staging buffers and the PCIe link)
-        if (copy_rc) break;
-        copier = std::thread([&, lo, hi]() {
-            (void)hipSetDevice(g->device);
-            copy_rc = copy_out_staged(g, (char *)out + lo * row_bytes, (const char *)d_out + lo * row_bytes, (hi - lo) * row_bytes);
-            if (copy_rc) copy_err = g_err;             // (g_err is thread local: carried over below)
-        });
+        if (!copier.joinable())                        // (ONE copy for all parts: it follows the rows announced below)
+            copier = std::thread([&]() {
+                (void)hipSetDevice(g->device);
+                copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
+                if (copy_rc) copy_err = g_err;         // (g_err is thread local: carried over below)
+            });
+        feed.announce((size_t)hi * row_bytes);
     }
+    if (rc) feed.stop();
     const double t3 = now();
     if (copier.joinable()) copier.join();
     if (!rc && copy_rc) rc = fail(copy_rc, copy_err);
+    if (!rc && g->rng_hold.valid) {   // (the parts found their draws in place: the one expansion is the call's generator time)
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g->ev[7], g->ev[6]) == hipSuccess) total.rng_kernel_ms += ms;
+    }
     if (!rc && stats) *stats = total;
     const double t4 = now();
     (void)hipFree(d_starts);

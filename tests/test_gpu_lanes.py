@@ -144,6 +144,13 @@ def test_lane_kernel_equals_wave_kernel_at_rmat18(monkeypatch):
         assert torch.equal(a, b)
         assert sa["total_steps"] == wave.last_stats["total_steps"]
         assert sa["overflow_reads"] == wave.last_stats["overflow_reads"]
+        # a job array of a few jobs per resident lane runs in one in-place launch; with the queue rule forced the same
+        # call takes rounds (parked walks, lanes_chain_kernel) and returns the same matrix
+        assert sa["lane_rounds"] == 1
+        monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "100000")
+        c = lanes.simulate_device("SparseOTF", p, q, False, d_starts, 80, seed=2)
+        monkeypatch.delenv("PECANPY_AMD_CHAIN_TAIL")
+        assert lanes.last_stats["lane_rounds"] > 1 and torch.equal(a, c)
 
 
 # ---- input validation at the C ABI --------------------------------------------------------------
