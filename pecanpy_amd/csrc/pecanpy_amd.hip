@@ -1331,13 +1331,14 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     if (weighted) tail = 8192;
     if (tail_env) tail = (uint64_t)strtoull(tail_env, nullptr, 10);
     bool use_queue = getenv("PECANPY_AMD_NO_CHAIN_QUEUE") == nullptr && n_work > tail;
-    // Short job lists (a few jobs per resident lane) run in ONE in-place launch: with so few walks per lane the launch
+    // Short job lists (at most nine jobs per resident lane) run in ONE in-place launch: with so few walks per lane the launch
     // lasts as long as its slowest walks, and a walk is slower in the queueing form (its deferred steps wait for a full
     // pass of the wavefront's pool, its chains for the next round) -- that form pays off through throughput only.
     // (RMAT-16 / -17 / -18, 0.66 / 1.3 / 2.6 M jobs: 5.1 -> 3.4, 9.7 -> 5.8, 13.0 -> 10.7 ms per pass; RMAT-19, 5.2 M jobs:
-    //  18.4 with the queue, 22.1 in place.  PECANPY_AMD_CHAIN_TAIL set: the queue rule alone decides.)
+    //  18.4 with the queue, 22.1 in place.  On the RMAT-22 graph, 1.3 / 2.6 / 3.2 M jobs: 12.9 -> 10.3, 18.5 -> 17.5,
+    //  19.1-20.5 -> 21.0: nine jobs per resident lane is the crossover.  PECANPY_AMD_CHAIN_TAIL set: the queue rule alone decides.)
     // (not with a partial index: without a queue the steps whose list was left out hand their walks to walk_kernel for good)
-    if (!weighted && !tail_env && g->list_max_len == 0xffffffffu && n_work <= 10 * lanes_resident) use_queue = false;
+    if (!weighted && !tail_env && g->list_max_len == 0xffffffffu && n_work <= 9 * lanes_resident) use_queue = false;
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
     const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;
     if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
