@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--extend", action="store_true", help="node2vec+ (weighted graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--gather-chunks", type=int, default=4,
-                    help="N > 1: chunks per shard whose gathers overlap the next chunk's walk kernel")
+    ap.add_argument("--gather-chunks", default="auto",
+                    help="N > 1: chunks per shard whose gathers overlap the next chunk's walk kernel; 'auto' = 2 / 3 / 4 for "
+                         "shards below 8 M / below 16 M / from 16 M jobs (a call costs ~10 ms + 3 ms per million jobs: "
+                         "DESIGN.md section 6, profiles/r04_shard_chunks_two_engines.txt)")
     ap.add_argument("--rank0-share", default="auto",
                     help="rank 0's shard as a fraction of a uniform one (it also assembles the matrix); 'auto' = the model of "
                          "DESIGN.md section 6 (0.5 at 8 GPUs), 1 = uniform")
@@ -240,7 +242,10 @@ def main():
     skip = int(has_nbr[starts[:lo]].sum()) * L
     # N > 1 with gather: the shard is walked in a few chunks and the gather of chunk c (async, on RCCL's
     # stream) overlaps the walk kernel of chunk c + 1; --gather-chunks 1 = one blocking gather at the end
-    n_chunks = max(1, args.gather_chunks) if do_gather else 1
+    if args.gather_chunks == "auto":   # (the same on every rank: from the LARGEST shard)
+        largest = max(b - a for a, b in all_bounds)
+        auto_chunks = 2 if largest < 8_000_000 else 3 if largest < 16_000_000 else 4
+    n_chunks = (auto_chunks if args.gather_chunks == "auto" else max(1, int(args.gather_chunks))) if do_gather else 1
     chunk_bounds = tapered_bounds(hi - lo, n_chunks)   # decreasing sizes: the exposed tail is the smallest chunk's transfer
     csum = np.concatenate([[0], np.cumsum(has_nbr[starts[lo:hi]], dtype=np.int64)])
     chunk_skip = [skip + int(csum[a]) * L for a, _ in chunk_bounds]
