@@ -1993,7 +1993,11 @@ static int copy_out_staged(pw_graph *g, void *dst, const void *d_src, size_t byt
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < T_use; t++) pool.emplace_back(worker);
+    try {
+        for (int t = 0; t < T_use; t++) pool.emplace_back(worker);
+    } catch (const std::exception &) {   // (thread limit of the process: go on with the workers there are, or give up)
+        if (pool.empty()) return fail(PW_ERR_NOMEM, "no thread for the copy out");
+    }
     double t_feed = 0, t_ring = 0;
     hipError_t issue_err = hipSuccess;
     bool gave_up = false;
