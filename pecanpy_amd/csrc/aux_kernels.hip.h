@@ -283,13 +283,15 @@ scan_tile_sums_kernel(uint64_t *tile_sums, uint64_t n_tiles) {
     if (t == 0) tile_sums[n_tiles] = carry;
 }
 
-// stream_off[i] = skip + exclusive prefix of draws.  If prev_off != nullptr, jobs whose offset
-// changed are appended to changed_list (repair passes re-run exactly those).
+// stream_off[i] = skip + exclusive prefix of draws.  If changed_list != nullptr, jobs whose offset
+// changed are appended to it (repair passes re-run exactly those).  Block-wise repair (pw_simulate_device, sink-heavy
+// directed graphs): only jobs below `limit` are re-addressed and reported -- the others keep the offset they were last
+// walked with -- and *first_mismatch receives the smallest job index, over ALL jobs, whose offset differs.
 __global__ void __launch_bounds__(SCAN_BLOCK)
 draws_offsets_kernel(const uint32_t *indptr, const uint32_t *starts, const uint32_t *walks,
                      uint32_t L, uint64_t n_jobs, const uint64_t *tile_sums, uint64_t skip,
                      uint64_t *stream_off, uint32_t *changed_list,
-                     unsigned long long *changed_count) {
+                     unsigned long long *changed_count, uint64_t limit, unsigned long long *first_mismatch) {
     __shared__ uint64_t sh[SCAN_BLOCK];
     const int t = threadIdx.x;
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)t * SCAN_ITEMS;
@@ -308,18 +310,32 @@ draws_offsets_kernel(const uint32_t *indptr, const uint32_t *starts, const uint3
         __syncthreads();
     }
     uint64_t run = skip + tile_sums[blockIdx.x] + sh[t] - s;
+    uint64_t first = ~0ull;
     for (int k = 0; k < SCAN_ITEMS; k++) {
         uint64_t i = base + k;
         if (i < n_jobs) {
             if (changed_list) {
                 if (stream_off[i] != run && loc[k] != 0) {
-                    unsigned long long slot = atomicAdd(changed_count, 1ull);
-                    changed_list[slot] = (uint32_t)i;
+                    if (i < first) first = i;
+                    if (i < limit) {
+                        unsigned long long slot = atomicAdd(changed_count, 1ull);
+                        changed_list[slot] = (uint32_t)i;
+                    }
                 }
             }
-            stream_off[i] = run;
+            if (i < limit) stream_off[i] = run;
         }
         run += loc[k];
+    }
+    if (first_mismatch) {   // (one atomic per tile at most)
+        __syncthreads();
+        sh[t] = first;
+        __syncthreads();
+        for (int s2 = SCAN_BLOCK / 2; s2 > 0; s2 >>= 1) {
+            if (t < s2 && sh[t + s2] < sh[t]) sh[t] = sh[t + s2];
+            __syncthreads();
+        }
+        if (t == 0 && sh[0] != ~0ull) atomicMin(first_mismatch, (unsigned long long)sh[0]);
     }
 }
 

@@ -814,29 +814,35 @@ PW_EXPORT int pw_graph_set_thresholds(pw_graph *g, const float *thr) {
 }
 
 // exclusive prefix of per-job draw counts -> g->stream_off; returns total through *total
+// (block-wise repair: only jobs below `limit` are re-addressed / reported; *first_mismatch = smallest job index of ANY job
+//  whose offset differs from the one it was last walked with, ~0 when the addressing is consistent)
 static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t *d_walks, uint32_t L,
                            uint64_t n_jobs, uint64_t skip, bool track_changes, uint64_t *total,
-                           uint64_t *n_changed) {
+                           uint64_t *n_changed, uint64_t limit = ~0ull, uint64_t *first_mismatch = nullptr) {
     uint64_t n_tiles = (n_jobs + pw::SCAN_TILE - 1) / pw::SCAN_TILE;
     if (g->stream_off.ensure(n_jobs + 1)) return PW_ERR_NOMEM;
     if (g->tile_sums.ensure(n_tiles + 1)) return PW_ERR_NOMEM;
     if (track_changes && g->changed.ensure(n_jobs)) return PW_ERR_NOMEM;
     unsigned long long *cc = g->counters.p + 5;
     if (track_changes) HIP_TRY(hipMemsetAsync(cc, 0, sizeof(unsigned long long), g->stream));
+    unsigned long long *fm = first_mismatch ? g->counters.p + 14 : nullptr;
+    if (fm) HIP_TRY(hipMemsetAsync(fm, 0xff, sizeof(unsigned long long), g->stream));
     hipLaunchKernelGGL(pw::draws_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
                        g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p);
     hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, g->tile_sums.p, n_tiles);
     hipLaunchKernelGGL(pw::draws_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
                        g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p,
-                       track_changes ? g->changed.p : nullptr, cc);
+                       track_changes ? g->changed.p : nullptr, cc, limit < n_jobs ? limit : n_jobs, fm);
     HIP_TRY(hipGetLastError());
     uint64_t tot = 0;
     HIP_TRY(hipMemcpyAsync(&tot, g->tile_sums.p + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
-    unsigned long long nc = 0;
+    unsigned long long nc = 0, fmv = ~0ull;
     if (track_changes) HIP_TRY(hipMemcpyAsync(&nc, cc, sizeof(nc), hipMemcpyDeviceToHost, g->stream));
+    if (fm) HIP_TRY(hipMemcpyAsync(&fmv, fm, sizeof(fmv), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     *total = tot;
     if (n_changed) *n_changed = nc;
+    if (first_mismatch) *first_mismatch = fmv;
     return 0;
 }
 
@@ -1316,6 +1322,11 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     else if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_in < 1) occ_in = 1;
+    if (const char *oe = getenv("PECANPY_AMD_LANE_OCC")) {   // (experiments: fewer resident workgroups per CU than fit)
+        const int cap = atoi(oe);
+        if (cap >= 1 && cap < occ) occ = cap;
+        if (cap >= 1 && cap < occ_in) occ_in = cap;
+    }
     const uint64_t lanes_resident = (uint64_t)g->n_cu * (uint64_t)occ * pw::WAVES_PER_BLOCK * pw::WAVE;
     // Steps that need the float32 chain (~1 % on RMAT-22 after lane_tight) are not run in place -- a chain with a few
     // of the wavefront's 64 lanes enabled costs the other lanes ~300 us -- their walks are PARKED in a queue, a
@@ -1848,22 +1859,39 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
 
     // 4. dead ends shift the stream addresses of every later walk: re-address and re-run the
     //    affected walks until the addressing is self-consistent (directed graphs only).
+    //    Each round makes a longer prefix of the job array final.  With few dead ends that converges in a handful of
+    //    rounds over the whole array; on sink-heavy directed graphs the single-stream semantics (pecanpy.py:198-206)
+    //    is inherently sequential -- a re-addressed walk draws new numbers, may end elsewhere and shifts everything
+    //    behind it again -- so after max_rounds the repair goes on BLOCK-WISE and stays exact: only the jobs of a
+    //    window of `blk` jobs behind the first inconsistent one are re-addressed and re-walked per round (the jobs
+    //    behind the window keep the offsets they were last walked with and are not touched until the window reaches
+    //    them), O(dead-end walks) small launches instead of O(dead-end walks) passes over the whole array.  Slow but
+    //    exact; pw_stats.repair_rounds counts the rounds.  NOMINAL addressing -- every walk owns a fixed slot of
+    //    walk_length draws: reproducible under the seed and statistically equivalent, but not the reference's
+    //    draw-for-draw assignment -- is an explicit opt-in (PECANPY_AMD_NOMINAL_STREAM=1), reported through
+    //    pw_stats.stream_addressing = 1.
     uint64_t dead = h[4];
     const uint64_t max_rounds = 32;
+    const bool nominal_ok = getenv("PECANPY_AMD_NOMINAL_STREAM") != nullptr;
+    const uint64_t blk = getenv("PECANPY_AMD_REPAIR_BLOCK") ? (uint64_t)strtoull(getenv("PECANPY_AMD_REPAIR_BLOCK"), nullptr, 10) : 4096ull;
+    uint64_t limit = ~0ull;          // block-wise phase: jobs below are being settled
     while (dead > 0) {
-        uint64_t tot2 = 0, n_changed = 0;
-        const bool give_up = st.repair_rounds >= max_rounds;
-        // Each round makes a longer prefix of the job array final; on sink-heavy directed graphs that
-        // takes O(n_jobs) rounds (the single-stream semantics is inherently sequential there).  After
-        // max_rounds fall back to NOMINAL addressing: every walk owns a fixed slot of walk_length draws
-        // (reproducible under the seed and statistically equivalent, but no longer the reference's exact
-        // draw-for-draw assignment); reported through pw_stats.stream_addressing = 1.
+        uint64_t tot2 = 0, n_changed = 0, first = ~0ull;
+        const bool over = st.repair_rounds >= max_rounds;
+        const bool give_up = over && nominal_ok;
+        const bool blockwise = over && !nominal_ok;
+        if (blockwise && limit == ~0ull) limit = 0;     // (the first block-wise round only locates the first inconsistent job)
         rc = compute_offsets(g, d_starts, give_up ? nullptr : d_out, walk_length, n_jobs, stream_skip, true, &tot2,
-                             &n_changed);
+                             &n_changed, blockwise ? limit : ~0ull, blockwise ? &first : nullptr);
         if (rc) return rc;
         if (give_up) st.stream_addressing = 1;
-        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu: %llu jobs re-addressed%s\n", (unsigned long long)st.repair_rounds, (unsigned long long)n_changed, give_up ? " (nominal slots)" : "");
-        if (n_changed == 0) break;
+        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu: %llu jobs re-addressed%s\n", (unsigned long long)st.repair_rounds, (unsigned long long)n_changed, give_up ? " (nominal slots)" : (blockwise ? " (block-wise)" : ""));
+        if (blockwise) {
+            if (first == ~0ull) break;                                   // consistent from the first job to the last
+            const uint64_t want = first + (blk ? blk : 1) < n_jobs ? first + (blk ? blk : 1) : n_jobs;
+            if (n_changed == 0) { limit = want; continue; }              // (nothing inside the window: move it, look again)
+            if (want > limit) limit = want;
+        } else if (n_changed == 0) break;
         st.repair_rounds++;
         wa.job_list = g->changed.p;
         wa.n_list = n_changed;
@@ -2051,8 +2079,9 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     const double t2 = now();
     // The matrix leaves the device at the PCIe rate (RMAT-18: 17 ms for 0.86 GB against 13 ms of walks): large job arrays
     // are walked in PARTS and the copy of part k (helper thread, copy stream, pinned staging) runs under the kernels of
-    // part k + 1 (the copy is the longer of the two: one chunked copy follows the parts, the link stays busy throughout).  Part k + 1's stream address = draws the earlier parts ACTUALLY consumed, so the walks are those of one
-    // call whatever the split (dead ends included).  Alias modes consume a variable number of words per step: one part.
+    // part k + 1 (the copy is the longer of the two: one chunked copy follows the parts, the link stays busy throughout).  Part k + 1's
+    // stream address = draws the earlier parts ACTUALLY consumed; every part's addressing is exact (the block-wise repair of
+    // pw_simulate_device), so the walks are those of one call whatever the split (dead ends included).  Alias modes consume a variable number of words per step: one part.
     const size_t row_bytes = sizeof(uint32_t) * ((size_t)walk_length + 2);
     int n_parts = 1;
     // (the first part's walks are the only ones the copy does not hide: more parts while a part stays a launch worth making --
@@ -2060,6 +2089,10 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     if (mode < PW_MODE_PRECOMP && (size_t)n_jobs * row_bytes >= ((size_t)128 << 20) && !getenv("PECANPY_AMD_NO_PARTS"))
         n_parts = (size_t)n_jobs * row_bytes >= ((size_t)800 << 20) ? 8 : 4;
     if (const char *pe = getenv("PECANPY_AMD_PARTS")) { n_parts = atoi(pe); if (n_parts < 1 || mode >= PW_MODE_PRECOMP) n_parts = 1; }
+    // (nominal addressing -- the opt-in fallback of the dead-end repair -- must be decided ONCE for the whole array: a part that
+    //  fell back would own slots up to skip + nominal while the next part started at skip + actual; exact addressing, the
+    //  default, makes the walks those of one call whatever the split)
+    if (getenv("PECANPY_AMD_NOMINAL_STREAM")) n_parts = 1;
     if (!has_seed && n_parts > 1) { seed = os_seed(); has_seed = 1; }   // (every part walks the same stream)
     pw_stats total;
     memset(&total, 0, sizeof(total));

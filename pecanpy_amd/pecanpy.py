@@ -169,9 +169,10 @@ class Base(BaseGraph):
             import warnings
 
             warnings.warn(
-                "walks on this sink-heavy directed graph were generated with NOMINAL stream addressing (one fixed "
-                "slot of walk_length draws per walk) after 32 re-addressing passes: reproducible under the seed, "
-                "but not the reference's draw-for-draw assignment (see DESIGN.md section 3)", RuntimeWarning, stacklevel=3)
+                "PECANPY_AMD_NOMINAL_STREAM is set: walks on this sink-heavy directed graph were generated with NOMINAL "
+                "stream addressing (one fixed slot of walk_length draws per walk) after 32 re-addressing passes: "
+                "reproducible under the seed, but not the reference's draw-for-draw assignment (unset it for the exact, "
+                "block-wise repair; see DESIGN.md section 3)", RuntimeWarning, stacklevel=3)
 
     def _random_walks(self, starts, walk_length, gather=True):
         """GPU replacement of the reference's njit ``_random_walks`` (pecanpy.py:164-210)."""

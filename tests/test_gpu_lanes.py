@@ -116,10 +116,9 @@ def test_lane_kernel_directed_graph_with_dead_ends(monkeypatch):
     eng = WalkEngine.from_csr(indptr, indices, data)
     got = eng.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
     st = eng.last_stats
-    assert st["lane_kernel"] == 1 and st["dead_end_walks"] > 0
-    if st["stream_addressing"] == 0:
-        assert np.array_equal(got, want)
-        assert st["total_steps"] == ost.total_steps
+    assert st["lane_kernel"] == 1 and st["dead_end_walks"] > 0 and st["stream_addressing"] == 0
+    assert np.array_equal(got, want)
+    assert st["total_steps"] == ost.total_steps
     wave = _wave_engine(indptr, indices, data, monkeypatch)
     got_w = wave.simulate("SparseOTF", 0.25, 4, False, starts, 12, seed=3)
     assert wave.last_stats["stream_addressing"] == st["stream_addressing"]
@@ -293,9 +292,9 @@ def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
     monkeypatch.delenv("PECANPY_AMD_CHAIN_TAIL")
     assert np.array_equal(got, ref)
     assert eng.last_stats["total_steps"] == st0["total_steps"] and eng.last_stats["repair_rounds"] == st0["repair_rounds"]
-    if st0["stream_addressing"] == 0:
-        want = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3)
-        assert np.array_equal(got, want)
+    assert st0["stream_addressing"] == 0
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3)
+    assert np.array_equal(got, want)
 
 
 def test_graph_handle_releases_its_device_memory(monkeypatch):
@@ -386,8 +385,8 @@ def test_weighted_lane_form_equals_the_oracle_and_the_wave_kernel(extend, gamma,
 def test_weighted_lane_form_on_a_directed_graph_with_dead_ends(monkeypatch):
     """Weighted DIRECTED graphs through the weighted lane form: entries without a reverse edge (prev is not in cur's row),
     dead ends that shorten walks and shift the stream addresses (repair passes: job lists, wave kernel).  A graph with a
-    single rarely-reached sink: the oracle's walks, draw for draw; a sink-heavy one (the engine may fall back to nominal
-    stream addressing, reported): equal to the wave-per-walk kernel."""
+    single rarely-reached sink and a sink-heavy one (block-wise repair): the oracle's walks, draw for draw, and equal to the
+    wave-per-walk kernel."""
     rng = np.random.default_rng(21)
     m = 4000
     monkeypatch.setenv("PECANPY_AMD_CHAIN_TAIL", "0")
@@ -407,11 +406,9 @@ def test_weighted_lane_form_on_a_directed_graph_with_dead_ends(monkeypatch):
             got = eng.simulate("SparseOTF", p, q, False, starts, L, seed=5)
             st = dict(eng.last_stats)
             assert st["lane_kernel"] == 3 and st["dead_end_walks"] > 0, st
-            if st["stream_addressing"] == 0:
-                assert np.array_equal(got, want), (sinks, p, q)
-                assert st["total_steps"] == ost.total_steps
-            else:
-                assert sinks == "many"
+            assert st["stream_addressing"] == 0, st          # (exact whatever the number of sinks: block-wise repair)
+            assert np.array_equal(got, want), (sinks, p, q)
+            assert st["total_steps"] == ost.total_steps
             monkeypatch.setenv("PECANPY_AMD_NO_WLANES", "1")
             wave = eng.simulate("SparseOTF", p, q, False, starts, L, seed=5)
             assert eng.last_stats["lane_kernel"] == 0 and eng.last_stats["stream_addressing"] == st["stream_addressing"]

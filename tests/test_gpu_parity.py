@@ -428,10 +428,7 @@ def test_precomp_tables_match_oracle_bitwise():
         assert np.array_equal(got, want), _diff_report(got, want)
 
 
-def test_sink_heavy_directed_graph_falls_back_to_nominal_slots():
-    """Many mid-walk dead ends: exact single-stream addressing would need O(n_jobs) passes, so the engine
-    switches to one fixed slot of walk_length draws per walk (reported in the stats) -- still
-    deterministic, and every walk equals the oracle run of that walk alone at its slot."""
+def _sink_heavy_graph():
     rng = np.random.default_rng(5)
     n = 400
     adj = rng.random((n, n)) < 0.02
@@ -441,8 +438,44 @@ def test_sink_heavy_directed_graph_falls_back_to_nominal_slots():
     indptr[1:] = np.cumsum(adj.sum(1))
     indices = np.nonzero(adj)[1].astype(np.uint32)
     data = np.ones(indices.size, dtype=np.float32)
+    return rng, n, indptr, indices, data
+
+
+def test_sink_heavy_directed_graph_is_exact_by_default(monkeypatch):
+    """Many mid-walk dead ends (40 % sinks): the single-stream semantics of the reference (pecanpy.py:198-206) is
+    inherently sequential here -- after 32 whole-array re-addressing passes the engine goes on BLOCK-WISE, still exact:
+    the walks are the oracle's, draw for draw, and stream_addressing stays 0.  Also through pw_simulate's parts."""
+    rng, n, indptr, indices, data = _sink_heavy_graph()
     L, seed = 30, 2
     starts = orc.shuffled_starts(n, 8, seed)
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, L, seed, return_stats=True)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    st = dict(eng.last_stats)
+    assert st["stream_addressing"] == 0 and st["dead_end_walks"] > 0 and st["repair_rounds"] > 32, st
+    assert np.array_equal(got, want), _diff_report(got, want)
+    assert st["total_steps"] == ost.total_steps
+    for blk in ("1", "64"):                                    # (window sizes of the block-wise phase: same walks)
+        monkeypatch.setenv("PECANPY_AMD_REPAIR_BLOCK", blk)
+        assert np.array_equal(eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed), want), blk
+    monkeypatch.delenv("PECANPY_AMD_REPAIR_BLOCK")
+    monkeypatch.setenv("PECANPY_AMD_PARTS", "3")              # every part's addressing is exact: the split does not matter
+    parts = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    assert eng.last_stats["stream_addressing"] == 0
+    assert np.array_equal(parts, want)
+    # non-dyadic p, q and the wave-per-walk kernel take the same repair path
+    want2 = orc.walks_sparse_otf(indptr, indices, data, 0.3, 1.7, starts, L, seed)
+    assert np.array_equal(eng.simulate("SparseOTF", 0.3, 1.7, False, starts, L, seed=seed), want2)
+
+
+def test_sink_heavy_directed_graph_nominal_slots_are_an_opt_in(monkeypatch):
+    """PECANPY_AMD_NOMINAL_STREAM=1: after 32 passes one fixed slot of walk_length draws per walk (reported in the stats) --
+    deterministic, every walk equals the oracle run of that walk alone at its slot; decided once for the whole array
+    (pw_simulate does not split such a call into parts)."""
+    rng, n, indptr, indices, data = _sink_heavy_graph()
+    L, seed = 30, 2
+    starts = orc.shuffled_starts(n, 8, seed)
+    monkeypatch.setenv("PECANPY_AMD_NOMINAL_STREAM", "1")
     eng = WalkEngine.from_csr(indptr, indices, data)
     got = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
     st = eng.last_stats
@@ -455,6 +488,8 @@ def test_sink_heavy_directed_graph_falls_back_to_nominal_slots():
         assert np.array_equal(got[i], want[0]), i
     again = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
     assert np.array_equal(again, got)
+    monkeypatch.setenv("PECANPY_AMD_PARTS", "3")
+    assert np.array_equal(eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed), got)
 
 
 def _sharded_worker(rank, world, port, ret):

@@ -138,6 +138,40 @@ def test_full_size_oracle_prefix(run, p, q):
     assert st["total_steps"] == ost.total_steps and st["overflow_reads"] == ost.overflow_reads
     if (p, q) == (0.5, 2.0):
         assert np.array_equal(run["out"][:n].cpu().numpy().view(np.uint32), want)
+    else:
+        # BASELINE C3 as it is run: the WHOLE 41.9 M-job array (the queueing / deferred form with its rounds -- the 20 000-job
+        # call above is one in-place launch, a different instantiation of the kernel) laid against the same oracle prefix
+        whole = run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"], L, seed=SEED)
+        ws = dict(run["eng"].last_stats)
+        assert ws["lane_kernel"] == 1 and ws["lane_rounds"] > 1, ws
+        assert np.array_equal(whole[:n].cpu().numpy().view(np.uint32), want)
+        del whole
+
+
+def test_c2_full_size_oracle_prefix():
+    """BASELINE C2 as named (RMAT-18, 10 x 80, p = 0.5, q = 2): the whole job array in the form the engine picks for it -- ONE
+    in-place launch of the TAILS instantiation (edge-line tails staged in LDS) -- against the oracle on its first 20 000 jobs."""
+    import torch
+
+    from oracle import pyoracle as orc
+
+    indptr, indices, data = rmat_csr(18, seed=1)
+    n_nodes = indptr.size - 1
+    starts = np.concatenate([np.arange(n_nodes, dtype=np.uint32)] * W)
+    np.random.RandomState(SEED).shuffle(starts)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    out = eng.simulate_device("SparseOTF", 0.5, 2, False, torch.from_numpy(starts.view(np.int32)).cuda(), L, seed=SEED)
+    st = dict(eng.last_stats)
+    assert st["lane_kernel"] == 1 and st["lane_rounds"] == 1 and st["redo_walks"] == 0, st
+    assert indices.size * 64 <= 2 << 30 and "PECANPY_AMD_LANE_TAILS" not in os.environ   # (launch_lane_walks' rule for the TAILS form)
+    n = 20000
+    want, ost = orc.walks_sparse_otf(indptr, indices, np.ones(indices.size, dtype=np.float32), 0.5, 2, starts[:n], L, SEED,
+                                     return_stats=True)
+    assert np.array_equal(out[:n].cpu().numpy().view(np.uint32), want)
+    head = eng.simulate_device("SparseOTF", 0.5, 2, False, torch.from_numpy(starts[:n].view(np.int32)).cuda(), L, seed=SEED)
+    hs = dict(eng.last_stats)
+    assert np.array_equal(head.cpu().numpy().view(np.uint32), want)
+    assert (hs["total_steps"], hs["overflow_reads"]) == (ost.total_steps, ost.overflow_reads)
 
 
 @pytest.mark.parametrize("p,q", [(0.3, 1.7), (3.0, 0.37)])
