@@ -267,10 +267,12 @@ struct ListView {
     // lane's piece 0; what lives in the line is then read from there instead of from global memory.
     uint32_t tail = 0xffffffffu; // 0xffffffff: not staged
     uint32_t inl = 0;            // the list itself lives in the line (p points into it)
+    uint32_t tshift = 10;        // log2 of the distance of the 16-byte pieces in LDS: 10 (LDS-DMA by the lane itself: piece c of lane t
+                                 // at base + 1024 c + 16 t) or 4 (QUAD fetch, round 5: the 64 bytes of a line are contiguous)
 #if defined(__HIP_DEVICE_COMPILE__)
     __device__ __forceinline__ uint32_t tail_entry(uint32_t i) const {
         const uint32_t o = 8u + (wide ? i << 2 : i << 1);             // (line offset 24 = tail offset 8)
-        const uint32_t addr = tail + ((o >> 4) << 10) + (o & 15u);
+        const uint32_t addr = tail + ((o >> 4) << tshift) + (o & 15u);
         return wide ? *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr
                     : (uint32_t) * (const __attribute__((address_space(3))) uint16_t *)(uintptr_t)addr;
     }
@@ -295,7 +297,7 @@ struct ListView {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (tail != 0xffffffffu && inl) {   // (inline lists are uint16: four entries = one aligned 8-byte LDS read inside a piece)
             const uint32_t o = 8u + (w0 << 1);
-            const uint32_t addr = tail + ((o >> 4) << 10) + (o & 15u);
+            const uint32_t addr = tail + ((o >> 4) << tshift) + (o & 15u);
             struct __attribute__((aligned(8))) Raw2 { uint32_t x, y; };
             const Raw2 raw = *(const __attribute__((address_space(3))) Raw2 *)(uintptr_t)addr;
             w.v[0] = raw.x & 0xffffu; w.v[1] = raw.x >> 16; w.v[2] = raw.y & 0xffffu; w.v[3] = raw.y >> 16;
@@ -475,8 +477,16 @@ PW_HD double lane_row_total(uint32_t d, uint32_t n_in, uint32_t pp, float w_out,
     return (double)n_in + (double)n_out * (double)w_out + (double)n_pv * (double)w_prev;
 }
 
-PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
-                           const ListView &cl, LaneStep &ls) {
+// lane_decide in three parts -- thresholds / the search over the list / the verdict -- so that the lane kernel can run the
+// search its own way (round 5: whole 64-byte sectors of the list fetched by quads of lanes, walk_lanes.hip.h); the search's
+// result (first entry whose mass reaches lo_th, its neighbours' positions and masses) does not depend on the probe order.
+struct DecideCtx {
+    uint32_t lo_th, hi_th;
+    uint32_t sh_in, sh_out, sh_prev;
+    uint32_t n_pv;
+};
+// returns LANE_REDO (row outside the exact range) or 0: go on with the search (n_in > 0) and lane_decide_end
+PW_HD uint32_t lane_decide_begin(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev, LaneStep &ls, DecideCtx &c) {
     const uint32_t n_pv = pp != 0xffffffffu ? 1u : 0u;
     ls.probes = 0;
     if (n_in + n_pv > d) return LANE_REDO;
@@ -488,30 +498,29 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     if (!(td <= 16777216.0 * (double)u)) return LANE_REDO;   // every partial sum exact: tot = exact sum
     ls.tot = (float)td;
     const uint32_t sh_u = (FloatTraits<float>::bits(u) >> 23) & 0xffu;
-    const uint32_t sh_in = (127u - sh_u) & 31u,   // classes that do not occur in the row get shift 0
-                   sh_out = n_out ? (((FloatTraits<float>::bits(w_out) >> 23) & 0xffu) - sh_u) & 31u : 0u,
-                   sh_prev = n_pv ? (((FloatTraits<float>::bits(w_prev) >> 23) & 0xffu) - sh_u) & 31u : 0u;
+    c.sh_in = (127u - sh_u) & 31u;   // classes that do not occur in the row get shift 0
+    c.sh_out = n_out ? (((FloatTraits<float>::bits(w_out) >> 23) & 0xffu) - sh_u) & 31u : 0u;
+    c.sh_prev = n_pv ? (((FloatTraits<float>::bits(w_prev) >> 23) & 0xffu) - sh_u) & 31u : 0u;
+    c.n_pv = n_pv;
     const double units = ldexp(td, (int)(127u - sh_u));   // td / u, exact
-    uint32_t sh_max = sh_in > sh_out ? sh_in : sh_out;
-    if (sh_prev > sh_max) sh_max = sh_prev;
+    uint32_t sh_max = c.sh_in > c.sh_out ? c.sh_in : c.sh_out;
+    if (c.sh_prev > sh_max) sh_max = c.sh_prev;
     const ExactThresholds th = exact_thresholds_f32(r * units, d, 1u << sh_max);
-    const uint32_t lo_th = th.lo, hi_th = th.hi;
-    const uint32_t wp = 1u << sh_prev;
-    // first common neighbour whose exact mass reaches lo_th
+    c.lo_th = th.lo; c.hi_th = th.hi;
+    return 0u;
+}
+// sr: the search for the first common neighbour whose exact mass reaches c.lo_th (nullptr when n_in == 0)
+PW_HD uint32_t lane_decide_end(uint32_t d, uint32_t n_in, uint32_t pp, const DecideCtx &c, const SearchResult *sr, LaneStep &ls) {
+    const uint32_t lo_th = c.lo_th, hi_th = c.hi_th;
+    const uint32_t wp = 1u << c.sh_prev;
     uint32_t s_run = 0, base = 0, p_f = 0xffffffffu, e_f = 0, f_below = 0;
     if (n_in) {
-        const MassEval ev{pp, sh_in, sh_out, sh_prev};
-#if defined(PW_LANES_WIDE_DECIDE) && PW_LANES_WIDE_DECIDE
-        const SearchResult sr = list_search_wide(cl, 0u, n_in, ev, (uint64_t)lo_th, ls.probes);   // (same result, field by field)
-#else
-        const SearchResult sr = list_search(cl, 0u, n_in, ev, (uint64_t)lo_th, ls.probes);
-#endif
-        if (sr.has_below) { s_run = sr.p_below + 1u; base = (uint32_t)sr.v_below; }
-        if (sr.f < n_in) { p_f = sr.p_at; e_f = (uint32_t)sr.v_at; }
-        f_below = sr.f;   // entries whose mass stays below lo_th: exactly the common neighbours before k1
+        if (sr->has_below) { s_run = sr->p_below + 1u; base = (uint32_t)sr->v_below; }
+        if (sr->f < n_in) { p_f = sr->p_at; e_f = (uint32_t)sr->v_at; }
+        f_below = sr->f;   // entries whose mass stays below lo_th: exactly the common neighbours before k1
     }
     uint32_t e1;
-    uint32_t k1 = solve_out_run(s_run, base, lo_th, (n_pv && pp >= s_run) ? pp : 0xffffffffu, sh_out, wp, e1);
+    uint32_t k1 = solve_out_run(s_run, base, lo_th, (c.n_pv && pp >= s_run) ? pp : 0xffffffffu, c.sh_out, wp, e1);
     if (p_f != 0xffffffffu && k1 >= p_f) { k1 = p_f; e1 = e_f; }
     if (k1 < d && e1 >= hi_th) return k1;
     // every j < k1 has c_j < r; the chain reaches r at the latest where E >= hi_th, and E grows by >= 1 per element
@@ -519,9 +528,24 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
     ls.kmax = km < d ? (uint32_t)km : d;
     ls.k1 = k1;
     ls.f = f_below;
-    ls.shifts = sh_in | (sh_out << 8) | (sh_prev << 16);
+    ls.shifts = c.sh_in | (c.sh_out << 8) | (c.sh_prev << 16);
     ls.p_next = p_f;
     return LANE_AMBIGUOUS;
+}
+
+PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, float w_out, float w_prev,
+                           const ListView &cl, LaneStep &ls) {
+    DecideCtx c;
+    if (lane_decide_begin(d, n_in, pp, r, w_out, w_prev, ls, c) == LANE_REDO) return LANE_REDO;
+    if (!n_in) return lane_decide_end(d, n_in, pp, c, nullptr, ls);
+    // first common neighbour whose exact mass reaches lo_th
+    const MassEval ev{pp, c.sh_in, c.sh_out, c.sh_prev};
+#if defined(PW_LANES_WIDE_DECIDE) && PW_LANES_WIDE_DECIDE
+    const SearchResult sr = list_search_wide(cl, 0u, n_in, ev, (uint64_t)c.lo_th, ls.probes);   // (same result, field by field)
+#else
+    const SearchResult sr = list_search(cl, 0u, n_in, ev, (uint64_t)c.lo_th, ls.probes);
+#endif
+    return lane_decide_end(d, n_in, pp, c, &sr, ls);
 }
 
 // ---- WEIGHTED rows: the decision from float64 prefix sums, with a rigorous bound on the float32 chain (round 4) ------

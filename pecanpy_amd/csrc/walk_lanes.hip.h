@@ -177,6 +177,25 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_LINE_LDS
 #define PW_LANES_LINE_LDS 0      // 1: the rest of the edge line a step enters (inline list / pivots) is copied to LDS with the record
 #endif
+#ifndef PW_LANES_QUAD
+#define PW_LANES_QUAD 1          // round 5: edge lines and list sectors are fetched WHOLE (64 bytes) by quads of lanes, straight into LDS
+#endif
+#ifndef PW_LANES_QPOOL
+#define PW_LANES_QPOOL 48        // ... pool slots / window jobs of that form (LDS: 4 KB of lines per wavefront on top)
+#endif
+#ifndef PW_LANES_QWIN
+#define PW_LANES_QWIN 32
+#endif
+#ifndef PW_LANES_MIN_WAVES_QD
+#define PW_LANES_MIN_WAVES_QD 4  // ... its occupancy: 35 KB of LDS per workgroup = 4 per CU; the memory path, not the wave count, sets its pace
+#endif
+#ifndef PW_LANES_QPIPE
+#define PW_LANES_QPIPE 0         // 1: the line requested when a step is taken is applied at the top of the NEXT iteration, behind the pool's pass
+                                 // (measured: 122 vs 118 ms per RMAT-22 pass -- the wait then also covers the stores the pass has just issued)
+#endif
+#ifndef PW_LANES_QDRAW_EARLY
+#define PW_LANES_QDRAW_EARLY 1   // the next step's draw is requested together with the line, not after the record has arrived
+#endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
                               // its share of the work at most)
@@ -187,7 +206,10 @@ __device__ unsigned long long g_lprof[16];
 
 // Takes the sampled edge of walk A: choice >= d hands the job to walk_kernel (overflow read / precondition / tie),
 // otherwise the record of the sampled entry's 64-byte line names the next vertex and everything the next step needs.
-#define PW_LANE_APPLY()                                                                         \
+// HEAD: the entry the walk moves to (A.e; fetch_ = its line is wanted) or the hand-over; TAIL: the record (r0_: first 16
+// bytes of the line, r1_: the next 8) applied to the walk.  Between the two the line is loaded -- by the lane itself, or by
+// its quad into LDS (QUAD form).
+#define PW_LANE_APPLY_HEAD(fetch_)                                                              \
     do {                                                                                        \
         uint32_t oe_ = NOT_FOUND;                                                               \
         if (choice == A.d && a.vlines) {                                                        \
@@ -212,10 +234,11 @@ __device__ unsigned long long g_lprof[16];
             if (oe_ != NOT_FOUND) {   /* (~1e-5 of the steps: counted where it happens; a sampled transition too) */ \
                 atomicAdd(a.stats + 1, 1ull); atomicAdd(a.stats + 0, 1ull);                     \
             }                                                                                   \
-            const uint4 *rp_ = (const uint4 *)(a.lines + A.e);                                  \
-            const uint4 r0_ = rp_[0];                                                           \
-            const uint2 r1_ = *(const uint2 *)(rp_ + 1);                                        \
-            if (LINE_LDS) { PW_LINE_STAGE(rp_); }                                      \
+            fetch_ = true;                                                                      \
+        }                                                                                       \
+    } while (0)
+#define PW_LANE_APPLY_TAIL(r0_, r1_, draw_prefetched_)                                          \
+    do {                                                                                        \
             {   /* output cells are staged four steps at a time: one 16-byte store instead of four 4-byte ones */ \
                 const uint32_t slot_ = (A.j - 1u) & 3u;                                         \
                 ob.v[0] = slot_ == 0u ? r0_.x : ob.v[0];                                        \
@@ -243,8 +266,7 @@ __device__ unsigned long long g_lprof[16];
                 }                                                                               \
                 A.flags = 0;                                                                    \
             } else if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff + (A.j - 1)); }                \
-            else r = a.rng[A.soff + (A.j - 1)];     /* the next step's draw, asked for now */   \
-        }                                                                                       \
+            else if (!(draw_prefetched_)) r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */ \
     } while (0)
 
 struct __attribute__((packed, aligned(4))) OutCells {   // four staged output cells: one 16-byte store, 4-byte aligned
@@ -282,12 +304,27 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // with the normaliser from the per-entry table -- and resumed by the next round.  No pool, no interval decision, no
 // float chain per lane here; without a queue (small job lists, the last round) such a walk goes to walk_kernel for good.
 template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false, bool WEIGHTED = false>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q))
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES
+                                      : ((PW_LANES_QUAD && PW_LANES_DEFER && !FLOATS && !WEIGHTED) ? PW_LANES_MIN_WAVES_QD
+                                         : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q)))
 walk_lanes_kernel(LanesArgs a) {
     constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS && !WEIGHTED;
-    constexpr bool LINE_LDS = TAILS || PW_LANES_LINE_LDS;
-    constexpr int POOL_N = TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL;
-    constexpr int WIN_N = TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN;
+    // QUAD (round 5; the dyadic forms): what a step reads of the graph comes in WHOLE 64-byte sectors, fetched by quads of
+    // lanes straight into LDS (global_load_lds, 16 bytes per lane: lane l moves piece l & 3 of the sector wanted by lane
+    // 16 k + (l >> 2), k = 0..3 -- the 64 bytes of lane w's sector land contiguously at byte 64 w of the wavefront's buffer):
+    // the edge line a step enters (record + inline list or pivots), and every sector of an overflow list a search looks
+    // into.  The memory path charges per (instruction, line) REQUEST, not per byte (tools/lane_mem_bench.hip,
+    // profiles/r05_lane_mem_bench.txt: whole lines by quads 52.9 G lines/s; the 16 + 8-byte record load of rounds 2-4
+    // 29.1 G/s; three dependent 2-byte probes of the same line on top of the record 15.7 G/s), so the record load, the
+    // probes of the inline list / the pivots and the last five levels of every overflow-list bisection -- 5.7 requests per
+    // step in round 4 -- become one request per line entered plus one per list sector visited.
+    constexpr bool QUAD = PW_LANES_QUAD && !FLOATS && !WEIGHTED && !TAILS;
+    constexpr bool LINE_LDS = (TAILS || PW_LANES_LINE_LDS) && !QUAD;
+    static_assert(!(QUAD && PW_LANES_DRAW_LDS), "the QUAD form fetches its draws with the lines");
+    constexpr int POOL_N = QUAD ? (PW_LANES_POOL < PW_LANES_QPOOL ? PW_LANES_POOL : PW_LANES_QPOOL)
+                                : (TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL);
+    constexpr int WIN_N = QUAD ? (PW_LANES_WIN < PW_LANES_QWIN ? PW_LANES_WIN : PW_LANES_QWIN)
+                               : (TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN);
     constexpr uint32_t DEFER_TH = TAILS ? (PW_LANES_DEFER_TH < 16 ? PW_LANES_DEFER_TH : 16) : PW_LANES_DEFER_TH;
     const int lane = lane_id();
     const uint32_t L = a.L;
@@ -403,6 +440,33 @@ walk_lanes_kernel(LanesArgs a) {
         if (LINE_LDS) { v.tail = tail_addr; v.inl = (d_ <= 65536u && n_in_ <= EL_INLINE) ? 1u : 0u; }
         return v;
     };
+    // QUAD: one 64-byte slot per lane -- the edge line the walk entered, later the list sector its search looks into
+    __shared__ uint4 s_quad[QUAD ? WAVES_PER_BLOCK : 1][4][WAVE];
+    uint4 (*const qbuf)[WAVE] = s_quad[QUAD ? readfirst_u32(threadIdx.x / WAVE) : 0];
+    const uint32_t qslot = QUAD ? (uint32_t)(uintptr_t)(lds_ptr_t)&qbuf[0][0] + (uint32_t)lane * 64u : 0u;   // LDS address of this lane's slot
+    // sector `sec` (64-byte units from `base`) of every lane with `want` set -> that lane's slot.  Converged code only.
+    // (0xffffffff names no sector: the lines array has fewer than 2^32 - 1 entries, the overflow array fewer sectors still)
+    const int q_src4 = (lane >> 2) << 2;                                   // byte index of this lane's source lane, instruction 0
+    const uint32_t q_piece = (uint32_t)(lane & 3) * 16u;
+    auto quad_issue = [&](bool want, const uint8_t *base, uint32_t sec) {
+        const uint32_t ws = want ? sec : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t osec = (uint32_t)__builtin_amdgcn_ds_bpermute(q_src4 + k * 64, (int)ws);
+            if (osec != 0xffffffffu)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (uint64_t)osec * 64u + q_piece), (lds_ptr_t)&qbuf[k][0], 16, 0, 0);
+        }
+    };
+    // (the compiler does not order an LDS read behind the LDS-DMA that fills it: the wait is explicit)
+    auto quad_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto quad_fetch = [&](bool want, const uint8_t *base, uint32_t sec) {
+        if (!ballot(want)) return;
+        quad_issue(want, base, sec);
+        quad_wait();
+    };
+    bool pending = false;   // QUAD: this lane's walk has taken an edge whose line is on its way (requested at the end of the last iteration)
+    auto q_u32 = [&](uint32_t off) -> uint32_t { return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(qslot + off); };
+    auto q_u16 = [&](uint32_t off) -> uint32_t { return (uint32_t) * (const __attribute__((address_space(3))) uint16_t *)(uintptr_t)(qslot + off); };
     // (the compiler does not order an LDS read behind the LDS-DMA that fills it: the wait is explicit)
 #define PW_DRAW_READ(di)                                                                                               \
     (*(const double *)((const char *)&dslot[((uint32_t)(di) & 7u) >> 1][lane] + (((uint32_t)(di) & 1u) << 3)))
@@ -497,6 +561,20 @@ walk_lanes_kernel(LanesArgs a) {
                 }
                 m_set &= ~ballot(give);
                 wave_lds_fence();
+            }
+        }
+        // ---- QUAD: the lines requested when the last iteration's steps were taken have had the pool's work to arrive in ----
+        if (QUAD && PW_LANES_QPIPE && ballot(pending)) {
+            quad_wait();
+            if (pending) {
+                typedef uint32_t __attribute__((ext_vector_type(4))) lds_u4;
+                typedef uint32_t __attribute__((ext_vector_type(2))) lds_u2;
+                const lds_u4 t0_ = *(const __attribute__((address_space(3))) lds_u4 *)(uintptr_t)qslot;
+                const lds_u2 t1_ = *(const __attribute__((address_space(3))) lds_u2 *)(uintptr_t)(qslot + 16u);
+                const uint4 r0_ = make_uint4(t0_.x, t0_.y, t0_.z, t0_.w);
+                const uint2 r1_ = make_uint2(t1_.x, t1_.y);
+                PW_LANE_APPLY_TAIL(r0_, r1_, PW_LANES_QDRAW_EARLY != 0);
+                pending = false;
             }
         }
         // ---- refill idle lanes from the job counter -------------------------------------------------------
@@ -662,6 +740,100 @@ walk_lanes_kernel(LanesArgs a) {
                     if (INPLACE && !a.susp) choice = LANE_NEEDS_WAVE;       // no queue: walk_kernel takes the walk over here
                 }
             }
+        } else if (QUAD) {
+            // lane_decide with the search run here: the line the walk entered waits in this lane's LDS slot (record, inline list
+            // or pivots); an overflow list is searched SECTOR by sector -- every lane that still needs one names it, the quads
+            // fetch them all (one request per sector), and the lane looks at the sector's first and last entry of its range:
+            // the answer lies inside (a bisection in LDS finishes it) or the range shrinks to one side.  The sector is chosen
+            // by INTERPOLATION between the masses at the two ends of the range (the pivots give them; the masses grow almost
+            // linearly with the index): lists of thousands of entries are settled in one or two sectors where the bisection
+            // of rounds 2-4 took log2(n / 21 / 32) + 1 dependent trips to memory and five more probes inside the last sector.
+            DecideCtx dc;
+            SearchResult sr;
+            sr.f = 0; sr.p_below = 0; sr.v_below = 0; sr.has_below = false; sr.p_at = 0xffffffffu; sr.v_at = 0;
+            uint32_t s_lo = 0, s_hi = 0;
+            bool need = false, go = false;
+            const bool narrow = A.d <= 65536u;
+            if (runnable && !nolist) {
+                wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
+                // (r = this step's draw: loaded when the previous step was applied / the walk was started)
+                choice = lane_decide_begin(A.d, A.n_in, A.pp, r, wo, w_prev, ls, dc);
+                go = choice != LANE_REDO;
+                if (go && A.n_in) {
+                    const MassEval ev{A.pp, dc.sh_in, dc.sh_out, dc.sh_prev};
+                    ListView v{nullptr, narrow ? 0u : 1u};
+                    v.tail = qslot + 16u; v.tshift = 4u;
+                    if (narrow && A.n_in <= EL_INLINE) {          // the list itself is in the line
+                        v.inl = 1u;
+                        sr = list_search(v, 0u, A.n_in, ev, (uint64_t)dc.lo_th, ls.probes);
+                        ls.probes = 0;                            // (LDS reads: no list bytes left the memory)
+                    } else {
+                        s_hi = A.n_in;
+                        if (list_has_pivots(v.wide, A.n_in)) {
+                            v.npiv = list_pivot_count(v.wide);
+                            v.step = list_pivot_step(v.wide, A.n_in);
+                            list_search_pivots(v, ev, (uint64_t)dc.lo_th, s_lo, s_hi, sr);
+                        }
+                        need = s_lo < s_hi;
+                        sr.f = s_lo;
+                    }
+                }
+            }
+            for (uint32_t trip = 0; ballot(need); trip++) {
+                const uint32_t esh = narrow ? 1u : 2u;
+                const uint64_t lbase = (uint64_t)A.coff * 16u;               // the list's byte offset in the overflow array
+                uint32_t g = s_lo + ((s_hi - s_lo) >> 1);
+                if (need && trip < 2u && sr.has_below && sr.p_at != 0xffffffffu && sr.v_at > sr.v_below) {
+                    // entry s_lo - 1 weighs v_below < target, entry s_hi weighs v_at >= target: where a straight line crosses
+                    // (every mass of a row lane_decide_begin accepts is below 2^24 units: 32-bit arithmetic)
+                    const float t = (float)(dc.lo_th - (uint32_t)sr.v_below) / (float)((uint32_t)sr.v_at - (uint32_t)sr.v_below);
+                    const float fe = (float)s_lo - 1.0f + t * (float)(s_hi - s_lo + 1u);
+                    const uint32_t gi = fe > 0.0f ? (uint32_t)fe : 0u;
+                    g = gi < s_lo ? s_lo : (gi >= s_hi ? s_hi - 1u : gi);
+                }
+                const uint32_t sec = (uint32_t)((lbase + ((uint64_t)g << esh)) >> 6);
+                quad_fetch(need, a.clist, sec);
+                if (need) {
+                    const MassEval ev64{A.pp, dc.sh_in, dc.sh_out, dc.sh_prev};
+                    auto ev = [&](uint32_t i, uint32_t P) -> uint32_t { return (uint32_t)ev64(i, P); };   // (below 2^24 units, as above)
+                    const uint64_t sb = (uint64_t)sec << 6;
+                    const uint32_t w_lo = sb > lbase ? (uint32_t)((sb - lbase) >> esh) : 0u;
+                    uint32_t w_hi = (uint32_t)((sb + 64u - lbase) >> esh);
+                    if (w_hi > A.n_in) w_hi = A.n_in;
+                    const uint32_t c_lo = w_lo > s_lo ? w_lo : s_lo, c_hi = w_hi < s_hi ? w_hi : s_hi;   // (g lies in both: not empty)
+                    const uint32_t eoff = (uint32_t)(lbase - sb);                                    // (mod 2^32: may be "negative")
+                    auto ent = [&](uint32_t i) -> uint32_t { const uint32_t o = eoff + (i << esh); return narrow ? q_u16(o) : q_u32(o); };
+                    const uint32_t P0 = ent(c_lo);
+                    const uint32_t v0 = ev(c_lo, P0);
+                    if (v0 >= dc.lo_th) { s_hi = c_lo; sr.p_at = P0; sr.v_at = v0; }
+                    else {
+                        sr.p_below = P0; sr.v_below = v0; sr.has_below = true;
+                        s_lo = c_lo + 1u;
+                        if (s_lo < c_hi) {
+                            const uint32_t P1 = ent(c_hi - 1u);
+                            const uint32_t v1 = ev(c_hi - 1u, P1);
+                            if (v1 < dc.lo_th) { s_lo = c_hi; sr.p_below = P1; sr.v_below = v1; }
+                            else {                                   // inside this sector: a bisection in LDS
+                                uint32_t l2 = s_lo, h2 = c_hi - 1u;
+                                sr.p_at = P1; sr.v_at = v1;
+                                while (l2 < h2) {
+                                    const uint32_t mid = (l2 + h2) >> 1;
+                                    const uint32_t P = ent(mid);
+                                    const uint32_t vm = ev(mid, P);
+                                    if (vm >= dc.lo_th) { h2 = mid; sr.p_at = P; sr.v_at = vm; }
+                                    else { l2 = mid + 1u; sr.p_below = P; sr.v_below = vm; }
+                                }
+                                s_lo = s_hi = l2;
+                            }
+                        }
+                    }
+                    ls.probes += 32u;                             // (one 64-byte sector = 32 two-byte entries' worth of list bytes)
+                    sr.f = s_lo;
+                    need = s_lo < s_hi;
+                }
+            }
+            if (go) choice = lane_decide_end(A.d, A.n_in, A.pp, dc, &sr, ls);
+            n_probes += ls.probes;
         } else
         if (runnable && !nolist) {
             wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
@@ -791,15 +963,46 @@ walk_lanes_kernel(LanesArgs a) {
         }
         }
         n_steps += (unsigned long long)__popcll(ballot(A.flags == F_ACTIVE && choice < A.d));   // (LANE_* codes are >= any degree)
-        if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {
-            PW_LANE_APPLY();
+        if (QUAD) {
+            // the lines of all lanes that move on: ONE request each, by the quads, into the lanes' slots -- and the next step's
+            // draw with them.  Nothing waits here: the record is applied at the top of the next iteration, behind the pool's
+            // pass (PW_LANE_APPLY_TAIL above), so the round trip runs under the interval decisions of the deferred steps.
+            bool fetch = false;
+            if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) PW_LANE_APPLY_HEAD(fetch);
+            if (PW_LANES_QDRAW_EARLY && fetch && A.j < L) r = a.rng[A.soff + A.j];   // (step A.j + 1 samples with double #(soff + A.j); unused if the walk ends)
+            quad_issue(fetch, (const uint8_t *)a.lines, A.e);
+            pending = fetch;
+            if (!PW_LANES_QPIPE && ballot(pending)) {
+                quad_wait();
+                if (pending) {
+                    typedef uint32_t __attribute__((ext_vector_type(4))) lds_u4;
+                    typedef uint32_t __attribute__((ext_vector_type(2))) lds_u2;
+                    const lds_u4 t0_ = *(const __attribute__((address_space(3))) lds_u4 *)(uintptr_t)qslot;
+                    const lds_u2 t1_ = *(const __attribute__((address_space(3))) lds_u2 *)(uintptr_t)(qslot + 16u);
+                    const uint4 r0_ = make_uint4(t0_.x, t0_.y, t0_.z, t0_.w);
+                    const uint2 r1_ = make_uint2(t1_.x, t1_.y);
+                    PW_LANE_APPLY_TAIL(r0_, r1_, PW_LANES_QDRAW_EARLY != 0);
+                    pending = false;
+                }
+            }
+        } else if (A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) {
+            bool fetch = false;
+            PW_LANE_APPLY_HEAD(fetch);
+            if (fetch) {
+                const uint4 *rp_ = (const uint4 *)(a.lines + A.e);
+                const uint4 r0_ = rp_[0];
+                const uint2 r1_ = *(const uint2 *)(rp_ + 1);
+                if (LINE_LDS) { PW_LINE_STAGE(rp_); }
+                PW_LANE_APPLY_TAIL(r0_, r1_, false);
+            }
         }
 #ifdef PW_LANES_WATCHDOG
         choice_wd = choice;
 #endif
         LPROF_T(3);
     }
-#undef PW_LANE_APPLY
+#undef PW_LANE_APPLY_HEAD
+#undef PW_LANE_APPLY_TAIL
 #undef PW_DRAW_STAGE
 #undef PW_DRAW_READ
 #undef PW_LINE_STAGE
