@@ -293,6 +293,12 @@ int pw_selftest_lane(int on_device, int device, const uint8_t *cls, uint32_t n, 
  * total / the thread's.  on_device: one GPU thread per target. */
 int pw_selftest_lane_floats(int on_device, int device, const uint8_t *cls, uint32_t n, float w_out, float w_prev,
                             const double *r, uint32_t n_r, uint32_t *chain, uint32_t *lane, float *tots);
+/* The bounded decision of that step alone (csrc/seqscan.h: lane_decide_unit_bounded, round 5 -- the real prefix sums of the
+ * three row values in closed form + a rigorous bound on the float32 chain's drift), host only, given the row's sequential
+ * float32 total: lane[i] = the position, n (never reached) or 0xfffffffd (left open: the chain decides); chain[i] = the
+ * reference's position (n: never reached).  Fails when a k_safe lies beyond the reference's position. */
+int pw_selftest_lane_unit_bounded(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                                  uint32_t *chain, uint32_t *lane);
 /* The lane kernel's decision for WEIGHTED rows (csrc/seqscan.h: lane_decide_weighted: float64 prefix sums of the step's
  * values with a rigorous bound on the float32 chain's drift), host only.  vals[k] = the step's value of neighbour k
  * before normalisation (what get_normalized_probs holds at sparse_rw.py:87 / :126), base[k] = its value as a plain

@@ -102,6 +102,9 @@ struct pw_graph {
     bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
                                                         // built (the wave kernel's lazy step reads it) but the lane kernel is not used
     float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
+    float *d_utot = nullptr;                            // unit graphs, 1/p or 1/q not a power of two: row total per arriving line
+    float utot_wo = 0, utot_wp = 0;                     // ... built for these biases (0: none)
+    bool utot_failed = false;
     // weighted lane form (walk_lanes.hip.h: WEIGHTED): base values, their per-row float64 prefix sums, per-entry delta prefix sums
     float *d_wb = nullptr;
     double *d_wpq = nullptr, *d_wdl = nullptr, *d_wl_dprev = nullptr;
@@ -253,6 +256,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_lines) (void)hipFree(g->d_lines);
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
+    if (g->d_utot) (void)hipFree(g->d_utot);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     for (void *q : {(void *)g->d_wb, (void *)g->d_wpq, (void *)g->d_wdl, (void *)g->d_wl_dprev, (void *)g->d_wl_off, (void *)g->d_wedge_row, (void *)g->d_wp1,
                     (void *)g->d_wck_off, (void *)g->d_wck})
@@ -1520,6 +1524,35 @@ static bool lanes_float_eligible(const pw_graph *g, const pw::WalkArgs &wa) {
     return g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && !wa.lazy_ok && !getenv("PECANPY_AMD_NO_LANES");
 }
 
+// FLOATS form: the row totals of all arriving lines, once per (1/q, 1/p) (walk_lanes.hip.h: unit_tot_kernel; cached in the
+// handle, reported as param_index_ms): the step then is ONE bounded decision instead of two float chains.  A call that
+// samples fewer steps than the graph has lines runs the two-chain step (an existing table is used whatever the call's size).
+static int ensure_unit_tot(pw_graph *g, const pw::WalkArgs &wa) {
+    if (g->utot_failed || getenv("PECANPY_AMD_NO_UTOT")) return 0;
+    const uint64_t n_lines = (uint64_t)g->nnz + (g->vlines ? g->n_nodes : 0);
+    const bool fresh = g->d_utot && g->utot_wo == wa.w_out && g->utot_wp == wa.w_prev;
+    if (fresh || !(wa.n_jobs * (uint64_t)wa.L >= n_lines || getenv("PECANPY_AMD_FORCE_TOT"))) return 0;
+    if (!g->d_utot && hipMalloc((void **)&g->d_utot, sizeof(float) * (size_t)(n_lines ? n_lines : 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        g->d_utot = nullptr;
+        g->utot_failed = true;
+        return 0;
+    }
+    g->utot_wo = g->utot_wp = 0;
+    HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+    hipLaunchKernelGGL(pw::unit_tot_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines, g->d_clist, n_lines,
+                       wa.w_out, wa.w_prev, g->d_utot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    float tms = 0;
+    HIP_TRY(hipEventElapsedTime(&tms, g->ev[4], g->ev[5]));
+    g->param_ms_call += tms;
+    g->utot_wo = wa.w_out;
+    g->utot_wp = wa.w_prev;
+    return 0;
+}
+
 static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo) {
     const uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
     if (g->redo.ensure(n_work ? n_work : 1)) return PW_ERR_NOMEM;
@@ -1548,6 +1581,7 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
     la.susp_count = g->counters.p + 32;
     la.ver_count = g->counters.p + 40;
     la.susp_chunk = 1;
+    if (g->d_utot && g->utot_wo == wa.w_out && g->utot_wp == wa.w_prev && !getenv("PECANPY_AMD_NO_UTOT")) la.tot_e = g->d_utot;   // (ensure_unit_tot)
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<true, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
@@ -1808,6 +1842,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     g->param_ms_call = 0;
     rc = ensure_tot_table(g, wa, extend != 0);   // (before the timed walk region: a per-(p, q) index, reported apart)
     if (rc) return rc;
+    if (mode == PW_MODE_SPARSE_OTF && lanes_float_eligible(g, wa)) { rc = ensure_unit_tot(g, wa); if (rc) return rc; }
     g->wl_active = false;
     g->wl_used = false;
     const char *wtail_env = getenv("PECANPY_AMD_CHAIN_TAIL");
@@ -2547,6 +2582,11 @@ PW_HD void lane_floats_one(uint32_t n, const ListView &cl, uint32_t n_cl, uint32
     uint32_t res = lane_chain<true>(n, n_cl, pp, inf, 1.0f, w_out, w_prev, cl, reads, &rowsum);
     *tot = rowsum;
     if (res != LANE_CHAIN_END) { *choice = res; return; }   // (LANE_TIE)
+    // round 5: the float64-bounded decision first (what the kernel does with the total from its table), the chain over
+    // w / tot only where that leaves the step open
+    uint32_t probes = 0, ks = 0;
+    const uint32_t b = lane_decide_unit_bounded(n, n_cl, pp, r, rowsum, w_out, w_prev, cl, probes, ks);
+    if (b <= n) { *choice = b == n ? LANE_CHAIN_END : b; return; }
     *choice = lane_chain<true>(n, n_cl, pp, r, 1.0f / rowsum, w_out / rowsum, w_prev / rowsum, cl, reads);
 }
 
@@ -2638,6 +2678,33 @@ PW_EXPORT int pw_selftest_lane_floats(int on_device, int device, const uint8_t *
     }
     cleanup();
     if (e != hipSuccess) return fail(PW_ERR_HIP, std::string("pw_selftest_lane_floats: ") + hipGetErrorString(e));
+    return PW_OK;
+}
+
+// The bounded decision of the FLOATS form alone (host): lane[i] = lane_decide_unit_bounded's verdict for draw r[i] given the
+// row's sequential float32 total -- the position, n (never reached) or 0xfffffffd (left open) -- and chain[i] = the
+// reference's position (sequential float32 w.sum(), w / tot, cumsum, searchsorted; n: never reached).
+PW_EXPORT int pw_selftest_lane_unit_bounded(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                                            uint32_t *chain, uint32_t *lane) {
+    if (!cls || !r || !chain || !lane || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    LaneRow row;
+    int rc = lane_row_setup(cls, n, w_out, w_prev, row, false);
+    if (rc) return rc;
+    float tot = 0.0f;
+    for (uint32_t k = 0; k < n; k++) tot = tot + (cls[k] == 1 ? 1.0f : (cls[k] == 0 ? w_out : w_prev));
+    const float x_in = 1.0f / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    std::vector<float> c(n);
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < n; k++) { acc = acc + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev)); c[k] = acc; }
+    for (uint32_t i = 0; i < n_r; i++) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+        chain[i] = lo;
+        uint32_t probes = 0, ks = 0;
+        lane[i] = pw::lane_decide_unit_bounded(n, row.n_cl, row.pp, r[i], tot, w_out, w_prev, row.view(), probes, ks);
+        if (lane[i] > n && lane[i] != pw::LANE_AMBIGUOUS) return fail(PW_ERR_INVALID, "unexpected verdict");
+        if (ks > lo) return fail(PW_ERR_INVALID, "k_safe beyond the reference's position");
+    }
     return PW_OK;
 }
 

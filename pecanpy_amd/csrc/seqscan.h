@@ -566,39 +566,62 @@ struct WeightedRow {
     const double *pq;   // [d] inclusive float64 prefix sums of the base values of cur's row
     const double *dl;   // [n_in] inclusive prefix sums, in list order, of (step value - base value) of the common neighbours
     double dprev;       // (step value - base value) of prev's element (0: prev is not in the row)
+    PW_HD double pq_at(uint32_t k) const { return pq[k]; }
+    PW_HD double dl_at(uint32_t i) const { return dl[i]; }   // (through the common neighbour of index i: i + 1 of them)
 };
-PW_HD double weighted_eps(uint32_t k) { return 1.05 * ((double)k + 3.0) * (1.0 / 16777216.0) + 1e-9; }
+// The same row description in CLOSED FORM for unit weights (round 5: unit graphs whose 1/p or 1/q is not a power of two):
+// every neighbour weighs b = fl32(1/q) (1 on the first step of a walk) unless it is a common neighbour (1) or prev (fl32(1/p)),
+// so the prefix sums need no tables: PQ[k] = (k + 1) b, DL[i] = (i + 1)(1 - b), dprev = fl32(1/p) - b -- products of a
+// float32 by an integer below 2^24, exact in float64.
+struct UnitPrefixRow {
+    double b, db;       // base value, (1 - base value)
+    double dprev;
+    PW_HD double pq_at(uint32_t k) const { return ((double)k + 1.0) * b; }
+    PW_HD double dl_at(uint32_t i) const { return ((double)i + 1.0) * db; }
+};
+// Relative drift of the float32 chain after element k: v_i = fl32(w'_i / tot) and k float32 additions of non-negative terms
+// give |c_k - S(k) / tot| <= ((1 + u)^(k + 1) - 1) S(k) / tot, u = 2^-24, and (1 + u)^n - 1 <= n u / (1 - n u) for n u < 1
+// (valid for EVERY k -- round 4's 1.05 (k + 3) u covered the second-order term only up to k ~ 800 000); n = k + 3 and the
+// 1e-9 leave room for the float64 evaluation of S and of the bound itself.  Rows beyond 2^22 elements: no bound (the step is
+// left to the exact scan).
+PW_HD double weighted_eps(uint32_t k) {
+    const double nu = ((double)k + 3.0) * (1.0 / 16777216.0);
+    return nu < 0.25 ? nu / (1.0 - nu) * 1.000001 + 1e-9 : 1e300;
+}
 
-struct WeightedEval {   // upper bound of the chain at the common neighbour i (position P), as order-preserving bits
-    const WeightedRow *wr;
+template <class Row>
+struct BoundedEval {   // upper bound of the chain at the common neighbour i (position P), as order-preserving bits
+    const Row *wr;
     uint32_t pp;
     double inv;
     PW_HD uint64_t operator()(uint32_t i, uint32_t P) const {
-        const double S = wr->pq[P] + wr->dl[i] + (pp < P ? wr->dprev : 0.0);
+        const double S = wr->pq_at(P) + wr->dl_at(i) + (pp < P ? wr->dprev : 0.0);
         const double hi = S * inv * (1.0 + weighted_eps(P)) + 3e-45 * ((double)P + 1.0);
         return FloatTraits<double>::bits(hi > 0.0 ? hi : 0.0);
     }
 };
+typedef BoundedEval<WeightedRow> WeightedEval;
 
 // k_safe (out): every partial sum before element k_safe is known to stay below r -- a step left open can start its exact
 // scan there (from the recorded chain value before it: walk_sparse.hip.h, CHAIN_CKPT) instead of at element 0.
-PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
-                                    const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+template <class Row>
+PW_HD uint32_t lane_decide_bounded(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const Row &wr,
+                                   const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
     k_safe = 0;
     if (!(tot > 0.0f) || d == 0u) return LANE_REDO;
     const double inv = 1.0 / (double)tot;
     const uint64_t tbits = FloatTraits<double>::bits(r > 0.0 ? r : 0.0);
     uint32_t ks = 0, ke = d, f = 0;
     if (n_in) {
-        const WeightedEval ev{&wr, pp, inv};
+        const BoundedEval<Row> ev{&wr, pp, inv};
         const SearchResult sr = list_search(cl, 0u, n_in, ev, tbits, probes);
         f = sr.f;
         if (sr.has_below) ks = sr.p_below + 1u;
         if (sr.f < n_in) ke = sr.p_at;
     }
-    const double dbase = f ? wr.dl[f - 1u] : 0.0;
+    const double dbase = f ? wr.dl_at(f - 1u) : 0.0;
     auto sum_at = [&](uint32_t k, uint32_t commons) -> double {   // S(k) with `commons` common neighbours at positions <= k
-        return wr.pq[k] + (commons ? wr.dl[commons - 1u] : 0.0) + (pp <= k ? wr.dprev : 0.0);
+        return wr.pq_at(k) + (commons ? wr.dl_at(commons - 1u) : 0.0) + (pp <= k ? wr.dprev : 0.0);
     };
     auto hi_of = [&](uint32_t k, double S) { return S * inv * (1.0 + weighted_eps(k)) + 3e-45 * ((double)k + 1.0); };
     auto lo_of = [&](uint32_t k, double S) { return S * inv * (1.0 - weighted_eps(k)) - 3e-45 * ((double)k + 1.0); };
@@ -606,7 +629,7 @@ PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, doub
     uint32_t lo = ks, hi = ke;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        const double S = wr.pq[mid] + dbase + (pp <= mid ? wr.dprev : 0.0);
+        const double S = wr.pq_at(mid) + dbase + (pp <= mid ? wr.dprev : 0.0);
         probes++;
         if (hi_of(mid, S) >= r) hi = mid; else lo = mid + 1u;
     }
@@ -621,6 +644,17 @@ PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, doub
     const uint32_t commons = (k1 == ke && f < n_in) ? f + 1u : f;
     if (!(lo_of(k1, sum_at(k1, commons)) >= r)) return LANE_AMBIGUOUS;
     return k1;
+}
+PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
+                                    const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+    return lane_decide_bounded(d, n_in, pp, r, tot, wr, cl, probes, k_safe);
+}
+// ... for a unit-weight row: w_out = fl32(1/q) (1.0f on the first step of a walk), w_prev = fl32(1/p), tot = the reference's
+// sequential float32 row total (w.sum(), sparse_rw.py:89)
+PW_HD uint32_t lane_decide_unit_bounded(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, float w_out, float w_prev,
+                                        const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+    const UnitPrefixRow row{(double)w_out, 1.0 - (double)w_out, pp != 0xffffffffu ? (double)w_prev - (double)w_out : 0.0};
+    return lane_decide_bounded(d, n_in, pp, r, tot, row, cl, probes, k_safe);
 }
 
 // ---- the float32 chain itself, evaluated by ONE thread (lane kernel, ambiguous steps) ---------------------------

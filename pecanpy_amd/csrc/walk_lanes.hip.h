@@ -196,6 +196,9 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_QDRAW_EARLY
 #define PW_LANES_QDRAW_EARLY 1   // the next step's draw is requested together with the line, not after the record has arrived
 #endif
+#ifndef PW_LANES_FWAIT
+#define PW_LANES_FWAIT 40        // FLOATS form: steps the float64 bound leaves open gather before their float chains run together
+#endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
                               // its share of the work at most)
@@ -685,7 +688,24 @@ walk_lanes_kernel(LanesArgs a) {
         }
         if (FLOATS) {
             if (runnable && A.n_in != 0u && !edge_list_stored(A.d, A.n_in, A.coff)) choice = LANE_NEEDS_WAVE;   // (partial index)
-            else if (runnable) {
+            else if (runnable && a.tot_e) {
+                // Round 5: the row total of every arriving entry (the reference's sequential float32 w.sum(), sparse_rw.py:89) was
+                // computed once per (p, q) by the chain itself (unit_tot_kernel), and the step is decided from the REAL prefix
+                // sums of the three row values -- closed form: n_in(k) + n_out(k) fl32(1/q) + [pp <= k] fl32(1/p) -- with a
+                // rigorous bound on the float32 chain's drift (seqscan.h: lane_decide_unit_bounded): one list search instead of
+                // two chains of ~17 binades x a search each.  What the bound leaves open waits (F_WAIT2) until a few lanes have
+                // gathered and is decided by the chain over w / tot, as before.
+                wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66), total = degree exactly
+                const float t = A.j >= 2 ? a.tot_e[A.e] : (float)A.d;
+                if (!(t > 0.0f)) choice = LANE_NEEDS_WAVE;          // (NaN: the total's chain met a tie binade beyond the budget)
+                else {
+                    uint32_t probes_ = 0, ks_ = 0;
+                    choice = lane_decide_unit_bounded(A.d, A.n_in, A.pp, r, t, wo, w_prev, lane_list(A.e, A.d, A.n_in, A.coff), probes_, ks_);
+                    n_probes += probes_;
+                    if (choice == LANE_REDO) choice = LANE_NEEDS_WAVE;
+                    if (choice == LANE_AMBIGUOUS) { A.flags = F_ACTIVE | F_WAIT2; tot = t; }
+                }
+            } else if (runnable) {
                 wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
                 const ListView cl = lane_list(A.e, A.d, A.n_in, A.coff);
                 float xi = 1.0f, xo = wo, xp = w_prev, rowsum = 0.0f;
@@ -705,6 +725,21 @@ walk_lanes_kernel(LanesArgs a) {
                 // LANE_CHAIN_END after the search: the CDF never reached r (mirrored overflow read); LANE_TIE: a tie binade
                 // beyond the budget -- both: walk_kernel takes the walk over at this step
                 choice = res < A.d ? res : (res == LANE_CHAIN_END ? A.d : LANE_NEEDS_WAVE);
+            }
+            if (a.tot_e) n_amb += (unsigned long long)__popcll(ballot(runnable && (A.flags & F_WAIT2) != 0));   // (left open just now)
+            {   // the steps the bound left open: their chains together, once enough lanes wait or nothing else can run
+                const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
+                if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_FWAIT || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0)) {
+                    n_wave += (unsigned long long)__popcll(w2);
+                    if (A.flags & F_WAIT2) {
+                        uint32_t reads = 0;
+                        const uint32_t res = lane_chain<true>(A.d, A.n_in, A.pp, r, 1.0f / tot, wo / tot, w_prev / tot,
+                                                              lane_list(A.e, A.d, A.n_in, A.coff), reads);
+                        n_probes += reads;
+                        choice = res < A.d ? res : (res == LANE_CHAIN_END ? A.d : LANE_NEEDS_WAVE);
+                        A.flags = F_ACTIVE;
+                    }
+                }
             }
         } else {
         LaneStep ls{1.0f, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -1078,6 +1113,31 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
         atomicAdd(stats + 6, reads_l);
         atomicAdd(stats + 9, done);
     }
+}
+
+// ---- FLOATS form: the row total of every arriving entry, once per (p, q) --------------------------------------------------
+// tot[e] = the reference's sequential float32 sum of the biased row of lines[e].nxt for a walker that arrived by entry e
+// (w.sum(), sparse_rw.py:89: common neighbours 1, prev fl32(1/p), the others fl32(1/q)) -- lane_chain<true> with r = +inf,
+// the first of the two chains the FLOATS step used to run every time.  NaN: the chain declined (a rounding-tie binade
+// beyond the budget, or the entry's list is not in a partial index): steps arriving by that entry go to walk_kernel.
+// One lane per line (CSR entries, then the overflow lines of the vertices).
+__global__ void __launch_bounds__(256)
+unit_tot_kernel(const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, uint64_t n_lines, float w_out, float w_prev, float *tot) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_lines) return;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    const uint32_t coff = *((const uint32_t *)(lines + e) + 5);
+    const uint32_t n_in = r0.y, pp = r0.z, d = r0.w;
+    float t = __uint_as_float(0x7fc00000u);
+    if (r0.x == NOT_FOUND || d == 0u) t = 0.0f;                       // (an overflow line without a target / a dead end: never stepped from)
+    else if (n_in == 0u || edge_list_stored(d, n_in, coff)) {
+        uint32_t reads = 0;
+        float rowsum = 0.0f;
+        const uint32_t res = lane_chain<true>(d, n_in, pp, __longlong_as_double(0x7ff0000000000000ll), 1.0f, w_out, w_prev,
+                                              edge_list(lines, clist, (uint32_t)e, d, n_in, coff), reads, &rowsum);
+        if (res == LANE_CHAIN_END) t = rowsum;
+    }
+    tot[e] = t;
 }
 
 // ---- steps whose entry's list is not in the (partial) index: walk_kernel's eager step, one wavefront per parked record ----

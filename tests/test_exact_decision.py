@@ -356,6 +356,45 @@ def test_float_chain_step_for_non_dyadic_biases(w_out, w_prev, device):
     assert declined / total < 0.05
 
 
+@pytest.mark.parametrize("w_out,w_prev", FLOAT_BIASES + [(1.0, 1.0)])
+def test_bounded_decision_of_the_float_step(w_out, w_prev):
+    """Round 5: the FLOATS step decides from the closed-form real prefix sums of the three row values with a rigorous bound on
+    the float32 chain (lane_decide_unit_bounded).  Every verdict it gives -- uniform draws, draws exactly on, one ulp and
+    1e-7 around every partial sum of the float32 chain, the first / last representable draws -- equals the sequential loops;
+    k_safe never passes the reference's position (checked in the hook); and the bound is not vacuous: it settles most draws
+    of short rows and leaves open what sits on a partial sum."""
+    lib = _lib.load()
+    w_out, w_prev = float(np.float32(w_out)), float(np.float32(w_prev))
+    rng = np.random.default_rng(int(w_out * 877 + w_prev * 31) + 9)
+    rows = []
+    for n in (1, 2, 5, 33, 64, 65, 400, 3000, 20000, 70000):
+        for p_common in (0.0, 0.03, 0.4, 1.0):
+            for with_prev in (False, True):
+                rows.append(random_row(rng, n, p_common, with_prev))
+    rows += lattice_rows(4096) + structured_rows(rng, 1500)
+    settled_uniform = total_uniform = open_on_sum = total_on_sum = 0
+    for cls in rows:
+        n = cls.size
+        tot, c32 = float_chain_reference(cls, w_out, w_prev)
+        cd = c32.astype(np.float64)
+        sub = slice(None, None, max(1, n // 300))
+        uni = rng.random(300)
+        on = cd[sub]
+        r = np.clip(np.concatenate([uni, on, np.nextafter(on, 0.0), np.nextafter(on, 2.0), on * (1 - 1e-7), on * (1 + 1e-7),
+                                    np.array([0.0, 1e-300, 1 - 2.0 ** -53])]), 0.0, np.nextafter(1.0, 0.0))
+        chain, lane = (np.empty(r.size, dtype=np.uint32) for _ in range(2))
+        _lib.check(lib.pw_selftest_lane_unit_bounded(np.ascontiguousarray(cls).ctypes.data_as(C.c_void_p), n, w_out, w_prev,
+                                                     r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
+                                                     lane.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(chain, np.searchsorted(cd, r, side="left").astype(np.uint32))       # the hook's own reference
+        decided = lane != LANE_AMBIGUOUS
+        assert np.array_equal(lane[decided], chain[decided]), (n, w_out, w_prev, np.flatnonzero(lane[decided] != chain[decided])[:5])
+        settled_uniform += int(decided[:300].sum()); total_uniform += 300
+        open_on_sum += int((~decided[300:300 + on.size]).sum()); total_on_sum += on.size
+    assert settled_uniform / total_uniform > 0.6, (settled_uniform, total_uniform)
+    assert open_on_sum / total_on_sum > 0.9, (open_on_sum, total_on_sum)      # a draw ON a partial sum cannot be settled by a bound
+
+
 # ---- weighted rows: float64 prefix sums + a rigorous bound on the float32 chain (lane_decide_weighted) ------------------
 def _weighted_run(vals, base, cls, r):
     vals = np.ascontiguousarray(vals, np.float32)
