@@ -1354,11 +1354,26 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     //  19.1-20.5 -> 21.0: nine jobs per resident lane is the crossover.  PECANPY_AMD_CHAIN_TAIL set: the queue rule alone decides.)
     // (not with a partial index: without a queue the steps whose list was left out hand their walks to walk_kernel for good)
     if (!weighted && !tail_env && g->list_max_len == 0xffffffffu && n_work <= 9 * lanes_resident) use_queue = false;
+    // CHAINS form (round 5): job arrays of a few walks per resident lane -- a shard of a multi-GPU run, RMAT-18..20 sized calls --
+    // in ONE launch whose wavefronts run the float chains themselves (from the pool, PW_LANES_CHAIN_TH steps at a time) instead
+    // of parking the walks for lanes_chain_kernel and a next round: every round of such a call lasts as long as its slowest
+    // walks.  Its chain code costs a wavefront per SIMD and its chain passes run at 28 of 64 lanes, so it pays up to ~14 jobs per
+    // resident lane (RMAT-22 graph, 1.3 / 2.6 M jobs: 13.3 -> 10.4, 16.8 -> 14.9 ms per call; 5.2 M: 23.9 vs 24.7; 41.9 M: 118 vs
+    // 146); lists of less than a job per lane keep the plain in-place launch.  PECANPY_AMD_LANE_CHAINS=0/1 overrides.
+    int occ_c = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, (const void *)pw::walk_lanes_kernel<false, false, false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ_c < 1) occ_c = 1;
+    const uint64_t lanes_resident_c = (uint64_t)g->n_cu * (uint64_t)occ_c * pw::WAVES_PER_BLOCK * pw::WAVE;
+    bool chains_form = !weighted && !getenv("PECANPY_AMD_VERIFY_TIGHT") && !tail_env && !getenv("PECANPY_AMD_NO_CHAIN_QUEUE") &&
+                       g->list_max_len == 0xffffffffu && n_work >= lanes_resident_c && n_work <= 14 * lanes_resident_c;
+    if (const char *ce = getenv("PECANPY_AMD_LANE_CHAINS")) chains_form = atoi(ce) != 0 && !weighted && !getenv("PECANPY_AMD_VERIFY_TIGHT");
+    if (chains_form) use_queue = true;      // (a step that finds the pool full is still parked: the round loop below takes care of it)
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
     const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;
     if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
         (void)hipGetLastError();
         use_queue = false;              // no room for the queues: chains run in place
+        chains_form = false;
     }
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
     // verification mode: every step the interval decision settles is recorded and decided again by the float chain
@@ -1386,14 +1401,15 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
-        const bool queue_out = use_queue && todo > tail && round < (weighted ? 512 : 64);
+        const bool chains_now = chains_form && round == 0;
+        const bool queue_out = chains_now || (use_queue && todo > tail && round < (weighted ? 512 : 64));
         la.susp = queue_out ? g->susp[round & 1].p : nullptr;
         la.susp_count = g->counters.p + 32;
         la.susp_chunk = todo > 32 * lanes_resident ? 128u : 1u;   // (void slots: < 128 per wavefront)
         la.resume = round ? g->susp[(round - 1) & 1].p : nullptr;
         la.n_resume = round ? todo : 0;
         uint64_t want = (todo + pw::WAVES_PER_BLOCK * pw::WAVE - 1) / (pw::WAVES_PER_BLOCK * pw::WAVE);
-        uint64_t grid = (uint64_t)g->n_cu * (uint64_t)(queue_out ? occ : occ_in);
+        uint64_t grid = (uint64_t)g->n_cu * (uint64_t)(chains_now ? occ_c : queue_out ? occ : occ_in);
         if (grid > want) grid = want;
         if (grid < 1) grid = 1;
         {   // consecutive jobs share pages of the draw stream and of the output: a wavefront reserves runs of them, at
@@ -1408,7 +1424,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         HIP_TRY(hipEventRecord(g->ev[4], g->stream));
         if (verify) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
         const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
-        if (weighted && queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        if (chains_now) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (weighted && queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (weighted) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out && tails) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, true>), lgrid, lblock, 0, g->stream, la);

@@ -196,6 +196,12 @@ __device__ unsigned long long g_lprof[16];
 #ifndef PW_LANES_QDRAW_EARLY
 #define PW_LANES_QDRAW_EARLY 1   // the next step's draw is requested together with the line, not after the record has arrived
 #endif
+#ifndef PW_LANES_CHAIN_TH
+#define PW_LANES_CHAIN_TH 28     // CHAINS form: steps waiting for their float chain that trigger a chain pass of the pool
+#endif
+#ifndef PW_LANES_MIN_WAVES_C
+#define PW_LANES_MIN_WAVES_C 3   // ... its occupancy (the chain code needs ~150 VGPRs)
+#endif
 #ifndef PW_LANES_FWAIT
 #define PW_LANES_FWAIT 40        // FLOATS form: steps the float64 bound leaves open gather before their float chains run together
 #endif
@@ -306,12 +312,20 @@ struct __attribute__((packed, aligned(4))) OutCells {   // four staged output ce
 // step of every walk and arrivals without a table are parked for lanes_eager_kernel<true, ..> -- the wave-per-walk scan
 // with the normaliser from the per-entry table -- and resumed by the next round.  No pool, no interval decision, no
 // float chain per lane here; without a queue (small job lists, the last round) such a walk goes to walk_kernel for good.
-template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false, bool WEIGHTED = false>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, INPLACE ? PW_LANES_MIN_WAVES
+// CHAINS (round 5; queueing form): a step the interval decision leaves open is NOT parked in the global queue for lanes_chain_kernel
+// and the next round -- it stays in its pool slot, and when PW_LANES_CHAIN_TH such steps wait the wavefront runs their float
+// chains itself, slot s by lane s, like the passes of the interval decision.  The walk is then taken up by a free lane in the
+// SAME launch: no rounds, no chain launches, no tails of half-empty rounds -- the form for job arrays of a few walks per
+// resident lane (a shard of a multi-GPU run, RMAT-18..20 sized calls), where every round lasts as long as its slowest walks.
+// The chain code costs registers (3 waves per SIMD), so whole-array calls at RMAT-22 keep the rounds.  Only a step that finds
+// the pool full is parked (the host's round loop handles what is left, usually nothing).
+template <bool INPLACE, bool VERIFY, bool FLOATS = false, bool TAILS = false, bool WEIGHTED = false, bool CHAINS = false>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, CHAINS ? PW_LANES_MIN_WAVES_C : INPLACE ? PW_LANES_MIN_WAVES
                                       : ((PW_LANES_QUAD && PW_LANES_DEFER && !FLOATS && !WEIGHTED) ? PW_LANES_MIN_WAVES_QD
                                          : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q)))
 walk_lanes_kernel(LanesArgs a) {
     constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS && !WEIGHTED;
+    static_assert(!CHAINS || (DEFER && !VERIFY && !TAILS), "the CHAINS form is the deferred queueing form plus in-kernel chain passes");
     // QUAD (round 5; the dyadic forms): what a step reads of the graph comes in WHOLE 64-byte sectors, fetched by quads of
     // lanes straight into LDS (global_load_lds, 16 bytes per lane: lane l moves piece l & 3 of the sector wanted by lane
     // 16 k + (l >> 2), k = 0..3 -- the 64 bytes of lane w's sector land contiguously at byte 64 w of the wavefront's buffer):
@@ -324,9 +338,9 @@ walk_lanes_kernel(LanesArgs a) {
     constexpr bool QUAD = PW_LANES_QUAD && !FLOATS && !WEIGHTED && !TAILS;
     constexpr bool LINE_LDS = (TAILS || PW_LANES_LINE_LDS) && !QUAD;
     static_assert(!(QUAD && PW_LANES_DRAW_LDS), "the QUAD form fetches its draws with the lines");
-    constexpr int POOL_N = QUAD ? (PW_LANES_POOL < PW_LANES_QPOOL ? PW_LANES_POOL : PW_LANES_QPOOL)
+    constexpr int POOL_N = CHAINS ? 64 : QUAD ? (PW_LANES_POOL < PW_LANES_QPOOL ? PW_LANES_POOL : PW_LANES_QPOOL)
                                 : (TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL);
-    constexpr int WIN_N = QUAD ? (PW_LANES_WIN < PW_LANES_QWIN ? PW_LANES_WIN : PW_LANES_QWIN)
+    constexpr int WIN_N = CHAINS ? 64 : QUAD ? (PW_LANES_WIN < PW_LANES_QWIN ? PW_LANES_WIN : PW_LANES_QWIN)
                                : (TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN);
     constexpr uint32_t DEFER_TH = TAILS ? (PW_LANES_DEFER_TH < 16 ? PW_LANES_DEFER_TH : 16) : PW_LANES_DEFER_TH;
     const int lane = lane_id();
@@ -357,12 +371,11 @@ walk_lanes_kernel(LanesArgs a) {
     // JOB WINDOW: what a new walk needs before its first step -- job, start vertex, its row, its stream position, its
     // first draw: a chain of three dependent scattered loads -- is fetched for the NEXT 64 jobs of the pool at once and
     // parked in LDS; a refill then costs one LDS read instead of that chain (nearly every loop iteration refills a lane
-    // or two: ~40 steps per walk, 64 lanes).  Entries [win_lo, win_lo + win_n) of the job array are in the window.
+    // or two: ~40 steps per walk, 64 lanes).  Round 5: only jobs whose start has neighbours enter the window (refill loop below).
     struct JobSlot { uint32_t job, start, s0, d; uint32_t soff_lo, soff_hi, r_lo, r_hi; };
     __shared__ JobSlot s_win[WAVES_PER_BLOCK][WIN_N];
     JobSlot *const win = s_win[readfirst_u32(threadIdx.x / WAVE)];
-    uint64_t win_lo = 0;
-    uint32_t win_n = 0;
+    uint32_t win_pos = 0, win_cnt = 0;   // entries [win_pos, win_cnt) of the window wait for a lane
     uint64_t sp_lo = 0, sp_hi = 0;       // ... queue slots reserved for parked walks
     // POOL of deferred steps (DEFER): slot s = words pool[q][s], q = 0..4:
     //   { job, j, s0, d } { n_in, pp, e, coff } { kmax -> choice once settled, soff lo, soff hi, k1 }
@@ -374,7 +387,8 @@ walk_lanes_kernel(LanesArgs a) {
     constexpr uint64_t POOL_MASK = POOL_N >= 64 ? ~0ull : ((1ull << (POOL_N & 63)) - 1ull);
     uint8_t *const pmap = s_map[DEFER ? readfirst_u32(threadIdx.x / WAVE) : 0];
     uint64_t m_def = 0, m_set = 0;
-    bool force_pass = false;
+    uint64_t m_chn = 0;       // CHAINS: slots whose step waits for its float chain
+    bool force_pass = false, force_chain = false;
     // queue slots for `pm` parked walks of this wavefront (wave-uniform mask; rank of a lane = its order in pm): what is
     // left of the previous reservation is used up first (only a wavefront's LAST reservation leaves void slots: the queue
     // never holds more than parked walks + susp_chunk slots per wavefront -- the host sizes it for that)
@@ -482,7 +496,7 @@ walk_lanes_kernel(LanesArgs a) {
         PW_WD(1, 2000000ull, wd_main);
         if (DEFER) {
             // ---- PASS: the interval decision of every deferred step, slot s by lane s ---------------------------------
-            if (m_def && (force_pass || (uint32_t)__popcll(m_def) >= DEFER_TH || (uint32_t)__popcll(m_def | m_set) >= (uint32_t)(POOL_N - POOL_N / 8))) {
+            if (m_def && (force_pass || (uint32_t)__popcll(m_def) >= (CHAINS ? 24u : DEFER_TH) || (uint32_t)__popcll(m_def | m_set | m_chn) >= (uint32_t)(POOL_N - POOL_N / 8))) {
                 force_pass = false;
                 LPROF_C(9, 1);
                 LPROF_C(10, __popcll(m_def));
@@ -522,7 +536,8 @@ walk_lanes_kernel(LanesArgs a) {
                     }
                 }
                 const uint64_t settled = ballot(mine && ch != LANE_AMBIGUOUS);
-                const uint64_t pm = m_def & ~settled;
+                const uint64_t pm = CHAINS ? 0ull : m_def & ~settled;
+                if (CHAINS) m_chn |= m_def & ~settled;   // left open: the float chain, by a chain pass of this wavefront (below)
                 if (pm) {   // left open: the float chain (lanes_chain_kernel) -- the walk is parked from its slot
                     const uint64_t qs = queue_slot(pm);
                     if (mine && ch == LANE_AMBIGUOUS) {
@@ -544,6 +559,31 @@ walk_lanes_kernel(LanesArgs a) {
                 m_def = 0;
                 wave_lds_fence();
                 LPROF_T(2);
+            }
+            // ---- CHAINS: the float chains of the steps the interval decision left open, slot s by lane s -----------------------
+            if (CHAINS && m_chn && (force_chain || (uint32_t)__popcll(m_chn) >= PW_LANES_CHAIN_TH ||
+                                    (uint32_t)__popcll(m_def | m_set | m_chn) >= (uint32_t)(POOL_N - POOL_N / 8))) {
+                force_chain = false;
+                n_wave += (unsigned long long)__popcll(m_chn);
+                if ((m_chn >> lane) & 1ull) {
+                    const uint4 p0 = pool[0][lane], p1 = pool[1][lane];
+                    const uint32_t kmax_s = *(const uint32_t *)&pool[2][lane];
+                    const uint2 p4 = *(const uint2 *)&pool[4][lane];
+                    const float wo_s = p0.y >= 2u ? w_out : 1.0f;
+                    const double r_s = __longlong_as_double((long long)(((unsigned long long)p4.y << 32) | p4.x));
+                    const float x_in = 1.0f / (float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev);
+                    uint32_t reads = 0;
+                    const uint32_t res = lane_chain(kmax_s, p1.x, p1.y, r_s, x_in, x_in * wo_s, x_in * w_prev,
+                                                    edge_list(a.lines, a.clist, p1.z, p0.w, p1.x, p1.w), reads);
+                    n_probes += reads;
+                    uint32_t ch = res;
+                    if (res == LANE_CHAIN_END) ch = p0.w;              // never reached: the mirrored overflow read (choice == degree)
+                    if (res == LANE_TIE) ch = LANE_NEEDS_WAVE;         // tie budget: the wave kernel takes the walk over at this step
+                    *(uint32_t *)&pool[2][lane] = ch;
+                }
+                m_set |= m_chn;
+                m_chn = 0;
+                wave_lds_fence();
             }
             // ---- settled walks first: free lanes take them up with their step's choice known -------------------------
             const uint64_t freel = ballot(!(A.flags & F_ACTIVE));
@@ -588,10 +628,10 @@ walk_lanes_kernel(LanesArgs a) {
             // jobs are taken from a wavefront-local pool; the shared counter is touched once per PW_LANES_CHUNK jobs
             // (one atomic per refill made every wavefront queue on ONE address ~40 M times a second -- the counter's
             // L2 channel, not the walks, set the pace).  Near the end of the work the chunks shrink to what is needed.
-            if (pool_lo == pool_hi) {
+            if ((a.resume || win_pos == win_cnt) && pool_lo == pool_hi) {
                 const uint64_t left = n_work > pool_hi ? n_work - pool_hi : 0;   // (as far as this wavefront knows)
                 const unsigned long long chunk = left > 4ull * grid_lanes ? (unsigned long long)a.job_chunk
-                                                                         : (unsigned long long)__popcll(need);
+                                                                         : (unsigned long long)__popcll(need) * (a.resume ? 1ull : 2ull);
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(a.job_counter, chunk);
                 base = readfirst_u64(base);
@@ -599,78 +639,93 @@ walk_lanes_kernel(LanesArgs a) {
                 pool_hi = base + chunk < n_work ? base + chunk : n_work;
                 if (pool_lo >= n_work) { pool_lo = pool_hi = n_work; exhausted = true; continue; }
             }
-            const uint64_t avail = pool_hi - pool_lo;
             const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
-            const uint64_t pool_base = pool_lo;
-            uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
-            if (WIN_N < WAVE && take > (uint64_t)WIN_N) take = WIN_N;   // (the rest: the next trip of this loop)
-            pool_lo += take;
             if (!a.resume) {
-                if (pool_base < win_lo || pool_base + take > win_lo + win_n) {   // (wave-uniform) window used up: the next jobs
-                    win_lo = pool_base;
-                    win_n = avail < (uint64_t)WIN_N ? (uint32_t)avail : (uint32_t)WIN_N;
+                // JOB WINDOW (round 5: compacted).  The next WIN_N jobs of the pool are fetched together -- job, start vertex, its
+                // row, stream position, first draw: three dependent scattered loads, once per batch instead of once per
+                // refill -- and the jobs whose start has no neighbours (52 % of an R-MAT job array) are FINISHED right
+                // there, by the lane that fetched them ([start, 0, .., 0, 1]: pecanpy.py:190-193); only the others enter
+                // the window.  A refill is then one LDS read, and one trip of this loop (round 4 handed the isolated starts
+                // to the idle lanes one by one: three to four trips per iteration, 14 % of the kernel's time).
+                if (win_pos == win_cnt) {
+                    const uint64_t avail = pool_hi - pool_lo;
+                    const uint32_t nb = avail < (uint64_t)WIN_N ? (uint32_t)avail : (uint32_t)WIN_N;
                     wave_lds_fence();                                      // (earlier reads of the window are over)
-                    if ((uint32_t)lane < win_n) {
-                        const uint64_t widx = pool_base + (uint64_t)lane;
-                        JobSlot js;
-                        js.job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
-                        js.start = a.starts[js.job];
-                        const uint4 vr = a.vrec[js.start];
-                        js.s0 = vr.x; js.d = vr.y;
-                        uint64_t so = 0;
-                        double r0 = 0.0;
-                        if (vr.y) { so = a.stream_off[js.job] - a.rng_base; if (!PW_LANES_DRAW_LDS) r0 = a.rng[so]; }
-                        js.soff_lo = (uint32_t)so; js.soff_hi = (uint32_t)(so >> 32);
-                        js.r_lo = (uint32_t)__double_as_longlong(r0);
-                        js.r_hi = (uint32_t)((unsigned long long)__double_as_longlong(r0) >> 32);
-                        uint4 *wp = (uint4 *)(win + lane);
-                        wp[0] = make_uint4(js.job, js.start, js.s0, js.d);
-                        wp[1] = make_uint4(js.soff_lo, js.soff_hi, js.r_lo, js.r_hi);
+                    bool live = false;
+                    uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
+                    if ((uint32_t)lane < nb) {
+                        const uint64_t widx = pool_lo + (uint64_t)lane;
+                        const uint32_t job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
+                        const uint32_t start = a.starts[job];
+                        const uint4 vr = a.vrec[start];
+                        uint32_t *row = a.out + (uint64_t)job * W;
+                        row[0] = start;
+                        if (vr.y == 0) {
+                            row[L + 1] = 1;          // start without neighbours; cells 1..L stay 0
+                            if (a.job_list)          // a repaired row may hold an older walk
+                                for (uint32_t z = 1; z <= L; z++) row[z] = 0;
+                        } else {
+                            const uint64_t so = a.stream_off[job] - a.rng_base;
+                            double r0 = 0.0;
+                            if (!PW_LANES_DRAW_LDS) r0 = a.rng[so];
+                            w0 = make_uint4(job, start, vr.x, vr.y);
+                            w1 = make_uint4((uint32_t)so, (uint32_t)(so >> 32), (uint32_t)__double_as_longlong(r0),
+                                            (uint32_t)((unsigned long long)__double_as_longlong(r0) >> 32));
+                            live = true;
+                        }
                     }
+                    const uint64_t lm = ballot(live);
+                    if (live) {
+                        uint4 *wp = (uint4 *)(win + __popcll(lm & lane_lt));
+                        wp[0] = w0;
+                        wp[1] = w1;
+                    }
+                    win_pos = 0;
+                    win_cnt = (uint32_t)__popcll(lm);
+                    pool_lo += nb;
                     wave_lds_fence();
+                    continue;
                 }
-            }
-            if (!(A.flags & F_ACTIVE) && !exhausted && rank < take) {
-                const uint64_t widx = pool_base + rank;
-                if (a.resume) {
-                    const uint4 *qp = (const uint4 *)(a.resume + widx);
-                    const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
-                    if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
-                        A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
-                        A.n_in = q1.x; A.pp = q1.y; A.e = q1.z; A.coff = q1.w;
-                        pre = q2.y;
-                        A.soff = ((uint64_t)q2.w << 32) | q2.z;
-                        const uint32_t slot = (A.j - 1u) & 3u;      // staged output cells of the group in progress
-                        const uint32_t *cell = a.out + (uint64_t)A.job * W + (A.j - slot);
-                        if (slot >= 1u) ob.v[0] = cell[0];
-                        if (slot >= 2u) ob.v[1] = cell[1];
-                        if (slot >= 3u) ob.v[2] = cell[2];
-                        A.flags = F_ACTIVE | F_PRE;
-                    }
-                } else {
-                    const uint4 *wp = (const uint4 *)(win + (uint32_t)(widx - win_lo));
+                const uint32_t avail_w = win_cnt - win_pos;
+                const uint32_t take_w = avail_w < (uint32_t)__popcll(need) ? avail_w : (uint32_t)__popcll(need);
+                if (!(A.flags & F_ACTIVE) && !exhausted && rank < take_w) {
+                    const uint4 *wp = (const uint4 *)(win + (win_pos + rank));
                     const uint4 j0 = wp[0], j1 = wp[1];
                     A.job = j0.x;
-                    const uint32_t start = j0.y;
-                    const uint4 vr = make_uint4(j0.z, j0.w, 0u, 0u);
-                    uint32_t *row = a.out + (uint64_t)A.job * W;
-                    row[0] = start;
-                    if (vr.y == 0) {
-                        row[L + 1] = 1;          // start without neighbours (pecanpy.py:190-193); cells 1..L stay 0
-                        if (a.job_list)          // a repaired row may hold an older walk
-                            for (uint32_t z = 1; z <= L; z++) row[z] = 0;
-                    } else {
-                        A.soff = ((uint64_t)j1.y << 32) | j1.x;
-                        A.s0 = vr.x; A.d = vr.y; A.n_in = 0; A.pp = NOT_FOUND; A.e = WEIGHTED ? start : 0u; A.coff = 0; A.j = 1;
-                        if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff); }
-                        else r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
-                        A.flags = F_ACTIVE;
-                    }
+                    A.soff = ((uint64_t)j1.y << 32) | j1.x;
+                    A.s0 = j0.z; A.d = j0.w; A.n_in = 0; A.pp = NOT_FOUND; A.e = WEIGHTED ? j0.y : 0u; A.coff = 0; A.j = 1;
+                    if (PW_LANES_DRAW_LDS) { PW_DRAW_STAGE(A.soff); }
+                    else r = __longlong_as_double((long long)(((unsigned long long)j1.w << 32) | j1.z));
+                    A.flags = F_ACTIVE;
+                }
+                win_pos += take_w;
+                continue;
+            }
+            const uint64_t avail = pool_hi - pool_lo;
+            const uint64_t pool_base = pool_lo;
+            const uint64_t take = avail < (uint64_t)__popcll(need) ? avail : (uint64_t)__popcll(need);
+            pool_lo += take;
+            if (!(A.flags & F_ACTIVE) && !exhausted && rank < take) {
+                const uint64_t widx = pool_base + rank;
+                const uint4 *qp = (const uint4 *)(a.resume + widx);
+                const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+                if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
+                    A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
+                    A.n_in = q1.x; A.pp = q1.y; A.e = q1.z; A.coff = q1.w;
+                    pre = q2.y;
+                    A.soff = ((uint64_t)q2.w << 32) | q2.z;
+                    const uint32_t slot = (A.j - 1u) & 3u;      // staged output cells of the group in progress
+                    const uint32_t *cell = a.out + (uint64_t)A.job * W + (A.j - slot);
+                    if (slot >= 1u) ob.v[0] = cell[0];
+                    if (slot >= 2u) ob.v[1] = cell[1];
+                    if (slot >= 3u) ob.v[2] = cell[2];
+                    A.flags = F_ACTIVE | F_PRE;
                 }
             }
         }
         if (!ballot(A.flags & F_ACTIVE)) {
             if (DEFER && m_def) { force_pass = true; continue; }   // (nothing else can run: decide what waits)
+            if (CHAINS && m_chn) { force_chain = true; continue; } // (... and run the chains that wait)
             break;                                                 // (m_set is empty: every lane was free to take from it)
         }
         LPROF_T(0);
@@ -906,7 +961,7 @@ walk_lanes_kernel(LanesArgs a) {
             const uint64_t am = ballot(amb0);
             if (am) {
                 n_amb += (unsigned long long)__popcll(am);
-                const uint64_t freem = ~(m_def | m_set) & POOL_MASK;
+                const uint64_t freem = ~(m_def | m_set | m_chn) & POOL_MASK;
                 const uint32_t nfree = (uint32_t)__popcll(freem), nd = (uint32_t)__popcll(am);
                 const bool taken = ((freem >> lane) & 1ull) && (uint32_t)__popcll(freem & lane_lt) < nd;   // (slot `lane`)
                 if (taken) pmap[__popcll(freem & lane_lt)] = (uint8_t)lane;
