@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--weighted", action="store_true", help="hashed U(0,1] edge weights (RMAT configs)")
     ap.add_argument("--extend", action="store_true", help="node2vec+ (weighted graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-call", action="store_true", help="skip the host-pointer call (config.host_call)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-chunks", default="auto",
                     help="N > 1: chunks per shard whose gathers overlap the next chunk's walk kernel; 'auto' = 2 / 3 / 4 for "
@@ -140,13 +141,19 @@ def er_bits_gpu(n, density, dev, seed=1):
 
 def load_pmc(key):
     """HBM-side traffic and issue counters of this exact workload from the committed rocprofv3 --pmc passes
-    (profiles/r04_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
+    (profiles/r05_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
     inside a timed run."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r04_traffic.json")) as f:
-            return json.load(f)["workloads"].get(key)
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r05_traffic.json", "r04_traffic.json"):   # (a workload not re-profiled this round keeps its last entry)
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                w = json.load(f)["workloads"].get(key)
+            if w:
+                w = dict(w)
+                w["source"] = "profiles/" + name
+                return w
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
 
 
 def main():
@@ -391,12 +398,18 @@ def main():
         entries = int(acc["list_entries_read"][-1])
         # ... and 128 bytes per step that needs the float32 chain (the walk's queue record, written and read back)
         chain_steps = int(acc["wave_chain_steps"][-1])
-        declared = (steps0 * (64 + 8 + 4) + entries * 2 + chain_steps * 128 + (hi - lo) * (4 + 8) + walks0 * (16 + 8) +
-                    (hi - lo - walks0) * 8)
-        kernel = ("walk_lanes_kernel (every round of a pass) + lanes_chain_kernel" if int(st["lane_kernel"]) == 1 else
-                  "walk_lanes_kernel<FLOATS> (1/p or 1/q not a power of two: two float32 chains per step, per lane)")
-        fmt = ("64 B edge line (record + inline list) + 8 B draw + 4 B output per step, 2 B per common-neighbour list entry "
-               "read (in-kernel counter), 128 B per parked step (queue record out and back), 36 B per walk")
+        floats_form = int(st["lane_kernel"]) == 2
+        declared = (steps0 * (64 + 8 + 4 + (4 if floats_form else 0)) + entries * 2 + (0 if floats_form else chain_steps * 128) +
+                    (hi - lo) * (4 + 8) + walks0 * (16 + 8) + (hi - lo - walks0) * 8)
+        kernel = ("walk_lanes_kernel (QUAD form: every round of a pass) + lanes_chain_kernel" if int(st["lane_kernel"]) == 1 else
+                  "walk_lanes_kernel<FLOATS> (1/p or 1/q not a power of two: float64-bounded decision from per-line row totals, "
+                  "float32 chains for the steps it leaves open, per lane)")
+        fmt = ("per step ONE 64 B edge line (record + inline list or pivots; fetched whole by a quad of lanes into LDS) + 8 B draw "
+               "+ 4 B output; 64 B per overflow-list sector a search visits (in-kernel counter, 32 two-byte entries' worth each) "
+               "and 2 B per list entry the float chains probe; 128 B per parked step (queue record out and back); 36 B per walk"
+               if int(st["lane_kernel"]) == 1 else
+               "64 B edge line + 8 B draw + 4 B output + 4 B row total per step, 2 B per common-neighbour list entry probed "
+               "(in-kernel counter), 36 B per walk")
     elif cfg["graph"] == "er":
         wpr = (n_nodes + 63) // 64
         if wpr <= 2048:
@@ -457,7 +470,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "declared_bytes_per_launch": int(declared), "declared_format": fmt,
         "avg_launch_ms": round(k_ms, 3), "rng_jump_and_expand_ms": round(float(np.mean(acc["rng_kernel_ms"])), 3),
-        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r04_traffic.json)"),
+        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r05_traffic.json)"),
         "random_sector_peak_GBps": RANDOM_SECTOR_GBS,
         "reference_format_bytes": ref_bytes,
     }
@@ -542,6 +555,25 @@ def main():
             "probe_msteps_per_s_by_threads": {str(c): round(v / 1e6, 3) for c, v in probed.items()},
         }
 
+    # ---- the call Base.simulate_walks actually makes: host pointers in, the walk matrix out into pageable NumPy memory ----
+    # (pw_simulate: parts walked while the finished ones leave over PCIe through a ring of pinned buffers; never `value`)
+    host_call = None
+    if world == 1 and not args.no_host_call and cfg["graph"] == "rmat":
+        try:
+            eng.simulate(mode, p, q, extend, starts[: max(1, n_jobs // 64)], L, seed=args.seed + 1000)   # (staging buffers exist)
+            t = time.perf_counter()
+            mat = eng.simulate(mode, p, q, extend, starts, L, seed=args.seed + 1001)
+            dt = time.perf_counter() - t
+            hs = int(eng.last_stats["total_steps"])
+            out_bytes = int(mat.nbytes)
+            del mat
+            host_call = {"value_host_call": round(hs / dt / 1e6, 3), "host_call_ms": round(dt * 1e3, 2), "matrix_bytes": out_bytes,
+                         "pcie_floor_ms_at_55GBps": round(out_bytes / 55e9 * 1e3, 2),
+                         "note": "wall clock of ONE pw_simulate call on host pointers (H2D of the starts, walks, D2H of the matrix into "
+                                 "fresh pageable memory), new seed; the device-resident `value` excludes the two copies"}
+        except MemoryError:
+            host_call = {"note": "not measured: the host could not allocate the walk matrix"}
+
     build_s = info["build_ms"] * 1e-3
     result = {
         "metric": f"million walk-steps/sec on {gdesc.split(' (')[0]} {mode} p={p:g} q={q:g}"
@@ -588,6 +620,7 @@ def main():
             "graph_index_bytes": info["index_bytes"],
             "lane_list_entries": info["lane_list_entries"],
             "value_incl_index_build": round(total_steps / (sec_per_step + build_s + param_index_ms[0] * 1e-3) / 1e6, 3),
+            "host_call": host_call,
         },
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -327,16 +327,18 @@ static pw::CsrDev csr_dev(const pw_graph *g);
 struct LaneWorkItems {
     std::vector<pw::LaneBuildItem> small, large;
     uint64_t segcnt_total = 0;
+    std::vector<uint32_t> vm0;      // per vertex: base of its per-segment counts (rows longer than LB_SEG; 0 otherwise)
 };
 static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneWorkItems &w) {
     const uint32_t JCHUNK = 16384;
+    w.vm0.assign((size_t)n_nodes + 1, 0u);
     for (uint32_t h = 0; h < n_nodes; h++) {
         const uint32_t d = indptr[h + 1] - indptr[h];
         if (d < 2) continue;   // one neighbour k: N(h) & N(k) = {k} & N(k) is empty without self loops
         if (d <= (uint32_t)pw::LB_SMALL) { w.small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
         const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
         uint32_t m0 = 0;
-        if (nseg > 1) { m0 = (uint32_t)w.segcnt_total; w.segcnt_total += (uint64_t)d * nseg; }
+        if (nseg > 1) { m0 = (uint32_t)w.segcnt_total; w.segcnt_total += (uint64_t)d * nseg; w.vm0[h] = m0; }
         for (uint32_t sg = 0; sg < nseg; sg++)
             for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) w.large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
     }
@@ -384,9 +386,12 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
     uint32_t *d_segcnt = nullptr;
     uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
+    uint32_t *d_log = nullptr, *d_seglo = nullptr, *d_vm0 = nullptr;    // LOGGED build (below)
+    unsigned long long *d_logoff = nullptr;
     const uint64_t n_tiles = ((uint64_t)n_lines + pw::CL_TILE - 1) / pw::CL_TILE;
     auto cleanup = [&]() {
-        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles})
+        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles, (void *)d_log, (void *)d_seglo,
+                        (void *)d_vm0, (void *)d_logoff})
             if (q) (void)hipFree(q);
     };
     auto drop = [&](int rc) {   // no lane index
@@ -418,17 +423,64 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     ba.clist = nullptr;
     ba.segcnt = d_segcnt;
     ba.max_len = 0xffffffffu;
+    ba.log = nullptr;
+    ba.log_off = nullptr;
+    ba.seglo = nullptr;
+    ba.logged = 0;
     INDEX_KERNELS_BEGIN(g);
     hipLaunchKernelGGL(pw::eline_init_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, c, d_edge_row, g->d_lines);
     if (vlines) hipLaunchKernelGGL(pw::vline_init_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, g->stream, c, g->d_lines);
     const unsigned vgrid = (unsigned)(((uint64_t)n_nodes * pw::WAVE + 255) / 256);
+    // LOGGED build (round 5; walk_lanes.hip.h: LaneBuildArgs): the COUNT pass keeps its matches in a log -- one block of d_k
+    // four-byte slots per pair, the pair's upper bound: 50 GB of address space at RMAT-22 of which the matches touch 5 -- and
+    // lane_scatter_kernel copies them to their places once the offsets are known, so the intersection of the long rows runs
+    // ONCE (the FILL pass streamed the same 50 GB of neighbour rows through LDS a second time: 61 of the index's 172 ms).
+    // Only when the log fits a third of the free memory (PECANPY_AMD_INDEX_TWO_PASS=1 forces the two passes).
+    uint64_t log_slots = 0;
+    bool logged = false;
+    const uint64_t nnz_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
+    if (!getenv("PECANPY_AMD_INDEX_TWO_PASS")) {
+        e = hipMalloc((void **)&d_logoff, sizeof(unsigned long long) * ((size_t)nnz + 1));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pw::log_tile_sums_kernel, dim3((unsigned)nnz_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, g->d_indptr,
+                               d_edge_row, nnz, d_tiles);
+            hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, d_tiles, nnz_tiles);
+            hipLaunchKernelGGL(pw::log_offsets_kernel, dim3((unsigned)nnz_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, g->d_indptr,
+                               d_edge_row, nnz, d_tiles, d_logoff);
+            e = hipMemcpyAsync(&log_slots, d_tiles + nnz_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+        }
+        INDEX_KERNELS_END(g);                       // (the allocations below are host time, not index-kernel time)
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        size_t free_now = 0, total_now = 0;
+        (void)hipMemGetInfo(&free_now, &total_now);
+        if (e == hipSuccess && log_slots && (log_slots + 64) * sizeof(uint32_t) <= free_now / 3) {
+            e = hipMalloc((void **)&d_log, (log_slots + 64) * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc((void **)&d_seglo, sizeof(uint32_t) * (size_t)(segcnt_total + 1));
+            if (e == hipSuccess) e = hipMalloc((void **)&d_vm0, sizeof(uint32_t) * ((size_t)n_nodes + 1));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_vm0, items.vm0.data(), sizeof(uint32_t) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, g->stream);
+            logged = e == hipSuccess;
+        }
+        if (!logged) {   // (no room: the two passes)
+            (void)hipGetLastError();
+            for (void **q : {(void **)&d_log, (void **)&d_seglo, (void **)&d_vm0, (void **)&d_logoff})
+                if (*q) { (void)hipFree(*q); *q = nullptr; }
+        } else {
+            ba.log = d_log;
+            ba.log_off = d_logoff;
+            ba.seglo = d_seglo;
+        }
+        stamp("log offsets + allocation");
+        INDEX_KERNELS_BEGIN(g);
+    }
     auto lists = [&](bool fill) {
         if (!large.empty()) {
             if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
+            else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
             else hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
         }
         if (!small.empty()) {
             if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, true>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
+            else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false, true>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
             else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
         }
         if (vlines) {
@@ -501,6 +553,12 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     ba.clist = g->d_clist;
     ba.max_len = max_len;
     INDEX_KERNELS_BEGIN(g);
+    if (logged) {   // the logged matches to their places; the FILL pass is left with the pairs of rows beyond 65536 entries
+        hipLaunchKernelGGL(pw::lane_scatter_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, ba, d_edge_row, d_vm0, nnz);
+        ba.logged = 1u;
+        if (g->max_degree > 65536u) lists(true);
+        else if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
+    } else
     lists(true);
     hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines,
                        g->d_clist, n_lines);

@@ -1480,7 +1480,18 @@ struct LaneBuildArgs {
     uint8_t *clist;                 // FILL only
     uint32_t *segcnt;               // per-(neighbour, segment) counts of the rows longer than LB_SEG
     uint32_t max_len;               // FILL: lists longer than this were left out of the index (partial index; 0xffffffff: none)
+    // LOGGED build (round 5): the COUNT pass keeps its matches -- (position in row k) | (position in row h) << 16, in match order,
+    // in a block of the log sized by the pair's upper bound d_k (log_off[e2] slots in; a segment's sub-block starts at the
+    // first key of row k inside the segment's id range) -- and lane_scatter_kernel copies them to their places once the
+    // offsets are known: the intersection of the long rows (50 GB of neighbour rows streamed through LDS at RMAT-22) runs
+    // ONCE.  Pairs whose positions do not fit 16 bits (a row beyond 65536 entries) keep the two passes.
+    uint32_t *log;
+    const unsigned long long *log_off;
+    uint32_t *seglo;                // per-(neighbour, segment): first key of row k inside the segment (sub-block start), like segcnt
+    uint32_t logged;                // FILL: the loggable pairs were written by lane_scatter_kernel -- skip them
 };
+// a pair (h -> k) handled by h whose two lists can be logged: both positions fit 16 bits
+__device__ __forceinline__ bool pair_loggable(uint32_t d_h, uint32_t d_k) { return d_h <= 65536u && d_k <= 65536u; }
 
 // ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
 // from one probe of the adjacency index (walk_sparse.hip.h)
@@ -1592,9 +1603,10 @@ struct LaneBuildItem {
     uint32_t j0, j1;   // neighbours (positions of row h) this workgroup takes: the longest rows are split further
 };
 
-template <int THREADS, int CAP, bool FILL>
+template <int THREADS, int CAP, bool FILL, bool LOG = false>
 __global__ void __launch_bounds__(THREADS)
 lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
+    static_assert(!(FILL && LOG), "the log is written by the COUNT pass");
     constexpr int NW = THREADS / WAVE;
     __shared__ uint32_t keys[CAP + 1];
     __shared__ uint32_t qj[THREADS], qlo[THREADS], qhi[THREADS];
@@ -1628,7 +1640,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             // more than 65536 entries that has no reverse entry is taken by h whatever the degrees, and its short list
             // lives in the overflow array as uint32 positions, which only the FILL pass writes.
             // Partial index: a list longer than max_len is stored nowhere (both directions: same length) -- nothing to fill.
-            const bool done = FILL && ((nseg == 1 && list_is_inline(d_k, r0.y)) || r0.y > a.max_len);
+            const bool done = FILL && ((nseg == 1 && list_is_inline(d_k, r0.y)) || r0.y > a.max_len || (a.logged && pair_loggable(d_h, d_k)));
             if (mine && d_k && !done) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
@@ -1659,10 +1671,13 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                                 p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                             }
                         }
+                        uint32_t *lg = nullptr;
+                        if (LOG && pair_loggable(d_h, d_k)) lg = a.log + a.log_off[e2] + lo_i;
                         for (uint32_t i = lo_i; i < hi_i; i++) {
                             const uint32_t w = a.indices[s_k + i];
                             const uint32_t idx = lds_lower_bound(keys, P, w);
                             if (keys[idx] == w) {
+                                if (LOG && lg) lg[cnt] = i | ((a0 + idx) << 16);
                                 if (FILL) {
                                     if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
                                     if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
@@ -1676,6 +1691,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                         if (!FILL) {
                             if (nseg > 1) {
                                 a.segcnt[it.m0 + j * nseg + it.seg] = cnt;
+                                if (LOG) a.seglo[it.m0 + j * nseg + it.seg] = lo_i;
                                 if (cnt) {
                                     atomicAdd(&a.lines[e2].n_in, cnt);
                                     if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, cnt);
@@ -1719,6 +1735,8 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                     p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, n1, c1);
                 }
             }
+            uint32_t *lg = nullptr;
+            if (LOG && pair_loggable(d_h, d_k)) lg = a.log + a.log_off[e2] + lo_i;
             for (uint32_t c0 = lo_i; c0 < hi_i; c0 += WAVE) {
                 const uint32_t i = c0 + (uint32_t)lane;
                 const bool valid = i < hi_i;
@@ -1726,6 +1744,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 const uint32_t idx = lds_lower_bound(keys, P, w);
                 const bool hit = valid && keys[idx] == w;
                 const uint64_t m = ballot(hit);
+                if (LOG && lg && hit) lg[run + (uint32_t)__popcll(m & lane_lt)] = i | ((a0 + idx) << 16);
                 if (FILL && hit) {
                     const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
                     if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
@@ -1742,6 +1761,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             if (!FILL && lane == 0) {
                 if (nseg > 1) {
                     a.segcnt[it.m0 + jq * nseg + it.seg] = run;
+                    if (LOG) a.seglo[it.m0 + jq * nseg + it.seg] = lo_i;
                     if (run) {
                         atomicAdd(&a.lines[e2].n_in, run);
                         if (rev != NOT_FOUND) atomicAdd(&a.lines[s_k + rev].n_in, run);
@@ -1753,6 +1773,122 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             }
         }
         __syncthreads();
+    }
+}
+
+constexpr int CL_BLOCK = 256;
+constexpr int CL_ITEMS = 16;
+constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;
+
+// ---- LOGGED build: slots of the log per entry, and the copy of the logged matches to their places ---------------------
+// slots of entry e2 = (h -> k): d_k when h takes the pair (the longer row; ties: the larger id; entries without a reverse
+// edge: their source) and both positions fit 16 bits, else 0
+__device__ __forceinline__ uint32_t log_slots(const ELine *lines, const uint32_t *indptr, const uint32_t *edge_row, uint64_t e2) {
+    const uint4 r0 = *(const uint4 *)(lines + e2);
+    const uint32_t h = edge_row[e2], k = r0.x, rev = r0.z, d_k = r0.w;
+    const uint32_t d_h = indptr[h + 1] - indptr[h];
+    const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
+    return (mine && d_h >= 2u && d_k && pair_loggable(d_h, d_k)) ? d_k : 0u;
+}
+__global__ void __launch_bounds__(CL_BLOCK)
+log_tile_sums_kernel(const ELine *__restrict__ lines, const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ edge_row, uint32_t nnz,
+                     uint64_t *tile_sums) {
+    __shared__ uint64_t sh[CL_BLOCK];
+    const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)threadIdx.x * CL_ITEMS;
+    uint64_t s = 0;
+    for (int k = 0; k < CL_ITEMS; k++)
+        if (base + k < nnz) s += log_slots(lines, indptr, edge_row, base + k);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = CL_BLOCK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(CL_BLOCK)
+log_offsets_kernel(const ELine *__restrict__ lines, const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ edge_row, uint32_t nnz,
+                   const uint64_t *__restrict__ tile_sums, unsigned long long *off_out) {
+    __shared__ uint64_t sh[CL_BLOCK];
+    const int t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * CL_TILE + (uint64_t)t * CL_ITEMS;
+    uint32_t loc[CL_ITEMS];
+    uint64_t s = 0;
+    for (int k = 0; k < CL_ITEMS; k++) {
+        loc[k] = base + k < nnz ? log_slots(lines, indptr, edge_row, base + k) : 0u;
+        s += loc[k];
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 1; off < CL_BLOCK; off <<= 1) {
+        const uint64_t add = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = tile_sums[blockIdx.x] + sh[t] - s;
+    for (int k = 0; k < CL_ITEMS; k++) {
+        if (base + k < nnz) off_out[base + k] = run;
+        run += loc[k];
+    }
+}
+
+// The logged matches of every pair to their places: list (h -> k) = the low halves (positions in row k), list (k -> h) = the
+// high halves (positions in row h), both uint16.  One wavefront per 64 consecutive entries: lists of up to 32 matches are
+// copied by their lane, longer ones by the whole wavefront, one after the other.  vm0[h] = base of h's per-segment counts
+// (rows longer than LB_SEG: their matches sit in one sub-block per segment, concatenated here in segment order).
+__global__ void __launch_bounds__(256)
+lane_scatter_kernel(LaneBuildArgs a, const uint32_t *__restrict__ edge_row, const uint32_t *__restrict__ vm0, uint32_t nnz) {
+    const int lane = lane_id();
+    const uint64_t e2 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool todo = false;
+    uint32_t n = 0, nseg = 1, segbase = 0, s_k = 0, rev = NOT_FOUND;
+    uint16_t *p2 = nullptr, *p1 = nullptr;
+    const uint32_t *src = nullptr;
+    if (e2 < nnz && log_slots(a.lines, a.indptr, edge_row, e2)) {
+        const uint4 r0 = *(const uint4 *)(a.lines + e2);
+        const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);
+        const uint32_t h = edge_row[e2], d_k = r0.w;
+        const uint32_t s_h = a.indptr[h], d_h = a.indptr[h + 1] - s_h;
+        n = r0.y; rev = r0.z; s_k = r1.x;
+        nseg = d_h > (uint32_t)LB_SEG ? (d_h + LB_SEG - 1) / LB_SEG : 1u;
+        // (single-segment rows: the COUNT pass wrote the lists that fit their lines itself; partial index: lists left out)
+        todo = n != 0u && !(nseg == 1u && list_is_inline(d_k, n)) && n <= a.max_len;
+        if (todo) {
+            p2 = (uint16_t *)list_base(a.lines, a.clist, (uint32_t)e2, d_k, n, r1.y);
+            if (rev != NOT_FOUND) {
+                const uint32_t e1 = s_k + rev;
+                p1 = (uint16_t *)list_base(a.lines, a.clist, e1, d_h, a.lines[e1].n_in, a.lines[e1].coff);
+            }
+            src = a.log + a.log_off[e2];
+            if (nseg > 1u) segbase = vm0[h] + ((uint32_t)e2 - s_h) * nseg;
+        }
+    }
+    const bool small_one = todo && nseg == 1u && n <= 32u;
+    if (small_one)
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t v = src[i];
+            p2[i] = (uint16_t)v;
+            if (p1) p1[i] = (uint16_t)(v >> 16);
+        }
+    uint64_t big = ballot(todo && !small_one);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        const uint32_t nsg = readlane_u32(nseg, l), sb = readlane_u32(segbase, l), nn = readlane_u32(n, l);
+        const uint32_t *sp = (const uint32_t *)readlane_u64((uint64_t)src, l);
+        uint16_t *q2 = (uint16_t *)readlane_u64((uint64_t)p2, l), *q1 = (uint16_t *)readlane_u64((uint64_t)p1, l);
+        uint32_t out = 0;
+        for (uint32_t sg = 0; sg < nsg; sg++) {
+            const uint32_t cnt = nsg > 1u ? a.segcnt[sb + sg] : nn;
+            const uint32_t *ss = sp + (nsg > 1u ? a.seglo[sb + sg] : 0u);
+            for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) {
+                const uint32_t v = ss[i];
+                q2[out + i] = (uint16_t)v;
+                if (q1) q1[out + i] = (uint16_t)(v >> 16);
+            }
+            out += cnt;
+        }
     }
 }
 
@@ -1797,9 +1933,6 @@ eline_pivots_kernel(ELine *lines, const uint8_t *__restrict__ clist, uint32_t n_
     }
 }
 
-constexpr int CL_BLOCK = 256;
-constexpr int CL_ITEMS = 16;
-constexpr int CL_TILE = CL_BLOCK * CL_ITEMS;
 
 // tile_sums[b] = 16-byte units of tile b; entry_sums[b] = list entries of tile b
 __global__ void __launch_bounds__(CL_BLOCK)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_all.sh <out dir> [configs...]   (on the GPU box): rocprofv3 --pmc passes (tools/pmc_run.sh) of one
-# bench.py pass per BASELINE config, folded into profiles/r04_traffic.json (tools/pmc_to_json.py); the summaries are
+# bench.py pass per BASELINE config, folded into profiles/r05_traffic.json (tools/pmc_to_json.py); the summaries are
 # kept under <out dir>/<config>/ and the JSON is copied next to them (gpurun merges only gpurun_out/).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$1; shift
@@ -25,4 +25,4 @@ PY
 )
   python tools/pmc_to_json.py gpurun_out/$OUT/$c "$KEY" "$KERN" "$STEPS" > gpurun_out/$OUT/$c/json.log 2>&1
 done
-cp profiles/r04_traffic.json gpurun_out/$OUT/r04_traffic.json
+cp profiles/r05_traffic.json gpurun_out/$OUT/r05_traffic.json

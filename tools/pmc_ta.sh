@@ -16,7 +16,7 @@ for grp in "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 400 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline > /tmp/pmc_$i.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-host-call > /tmp/pmc_$i.log 2>&1
   python $R/tools/prof_summary.py /tmp/pmc_$i/p_results.db $OUT/pass$i.txt > /dev/null 2>&1 || tail -3 /tmp/pmc_$i.log > $OUT/pass$i.err
 done
 cat $OUT/pass*.txt | grep -E "walk_kernel" 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r04_traffic.json, the file
+"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r05_traffic.json, the file
 bench.py reads the HBM-side traffic and the issue counters of a workload from.
 usage: pmc_to_json.py <dir with pass*.txt> <workload key> <kernel substring[+substring...]> <steps per pass> [note]"""
 import glob
@@ -45,11 +45,18 @@ def main(d, key, kernel, steps, note=""):
             "clock_assumed_ghz": 2.4,
         },
         "sectors_per_step": round((c.get("TCC_MISS_sum") or 0.0) / steps, 3),
+        # memory side of the L2 (round 5): read requests it sends to the fabric, those addressed to local DRAM (rocprofv3 on gfx950
+        # has no Infinity-Cache hit counter: both count a request whether the MALL or HBM serves it), and the average time one is
+        # outstanding (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ, L2 clocks) -- the latency the memory side answers with under this load
+        "ea_read_requests": c.get("TCC_EA0_RDREQ_sum"), "ea_read_requests_dram": c.get("TCC_EA0_RDREQ_DRAM_sum"),
+        "ea_read_latency_cycles": (round(c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"], 1)
+                                   if c.get("TCC_EA0_RDREQ_sum") and c.get("TCC_EA0_RDREQ_LEVEL_sum") else None),
+        "tcp_pending_stall_frac": (round(c["TCP_PENDING_STALL_CYCLES_sum"] / 256 / cyc, 3) if c.get("TCP_PENDING_STALL_CYCLES_sum") else None),
         "note": note or ("FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same launch (tools/pmc_run.sh); "
                          "scattered <= 64-byte accesses: FETCH_SIZE is exact at one 64-byte sector per access "
                          "(profiles/r02_fetch_calibration.txt)"),
     }
-    path = os.path.join(REPO, "profiles", "r04_traffic.json")
+    path = os.path.join(REPO, "profiles", "r05_traffic.json")
     try:
         doc = json.load(open(path))
     except (OSError, ValueError):

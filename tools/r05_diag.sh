@@ -17,7 +17,7 @@ for grp in "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE TA_TOTAL_WAVEFRONTS_sum" 
            "TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   i=$((i+1))
   rm -rf /tmp/dg_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/dg_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline > /tmp/dg_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/dg_$i -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-host-call > /tmp/dg_$i.log 2>&1
   python $R/tools/prof_summary.py /tmp/dg_$i/p_results.db $OUT/pass$i.txt > /dev/null 2>&1 || { echo "# group failed: $grp" > $OUT/pass$i.txt; tail -5 /tmp/dg_$i.log >> $OUT/pass$i.txt; }
 done
 grep -hE "walk_lanes_kernel|lanes_chain_kernel|group failed" $OUT/pass*.txt | grep -v "^void.*| [0-9]* | [0-9.]* | [0-9.]*$"
