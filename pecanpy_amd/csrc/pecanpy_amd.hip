@@ -326,6 +326,7 @@ static pw::CsrDev csr_dev(const pw_graph *g);
 // CSR travels to the device.
 struct LaneWorkItems {
     std::vector<pw::LaneBuildItem> small, large;
+    std::vector<pw::LaneBuildItem> wide;   // the items of `large` whose row has more than 65536 entries (positions beyond 16 bits)
     uint64_t segcnt_total = 0;
     std::vector<uint32_t> vm0;      // per vertex: base of its per-segment counts (rows longer than LB_SEG; 0 otherwise)
 };
@@ -346,6 +347,8 @@ static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneW
     std::stable_sort(w.large.begin(), w.large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
         return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];
     });
+    for (const pw::LaneBuildItem &it : w.large)
+        if (indptr[it.h + 1] - indptr[it.h] > 65536u) w.wide.push_back(it);
 }
 
 // device time of a group of index kernels: g->ev[2] / g->ev[3] around it, added to g->index_build_ms once it has run
@@ -383,15 +386,15 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     stamp("hipMemGetInfo");
     const uint64_t line_bytes = (uint64_t)n_lines * sizeof(pw::ELine) + 64;
     if (line_bytes > free_b / 2) return 0;
-    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
+    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr, *d_wide = nullptr;
     uint32_t *d_segcnt = nullptr;
     uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
-    uint32_t *d_log = nullptr, *d_seglo = nullptr, *d_vm0 = nullptr;    // LOGGED build (below)
+    uint32_t *d_log = nullptr, *d_seglo = nullptr, *d_vm0 = nullptr, *d_vlog = nullptr;    // LOGGED build (below)
     unsigned long long *d_logoff = nullptr;
     const uint64_t n_tiles = ((uint64_t)n_lines + pw::CL_TILE - 1) / pw::CL_TILE;
     auto cleanup = [&]() {
-        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles, (void *)d_log, (void *)d_seglo,
-                        (void *)d_vm0, (void *)d_logoff})
+        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_wide, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles, (void *)d_log,
+                        (void *)d_seglo, (void *)d_vm0, (void *)d_logoff, (void *)d_vlog})
             if (q) (void)hipFree(q);
     };
     auto drop = [&](int rc) {   // no lane index
@@ -435,6 +438,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     // four-byte slots per pair, the pair's upper bound: 50 GB of address space at RMAT-22 of which the matches touch 5 -- and
     // lane_scatter_kernel copies them to their places once the offsets are known, so the intersection of the long rows runs
     // ONCE (the FILL pass streamed the same 50 GB of neighbour rows through LDS a second time: 61 of the index's 172 ms).
+    // (The lists of the overflow lines keep their two lookup passes: a per-vertex scatter measured 15 ms against 6.4.)
     // Only when the log fits a third of the free memory (PECANPY_AMD_INDEX_TWO_PASS=1 forces the two passes).
     uint64_t log_slots = 0;
     bool logged = false;
@@ -458,11 +462,15 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
             if (e == hipSuccess) e = hipMalloc((void **)&d_seglo, sizeof(uint32_t) * (size_t)(segcnt_total + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&d_vm0, sizeof(uint32_t) * ((size_t)n_nodes + 1));
             if (e == hipSuccess) e = hipMemcpyAsync(d_vm0, items.vm0.data(), sizeof(uint32_t) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, g->stream);
+            if (e == hipSuccess && !items.wide.empty()) {
+                e = hipMalloc((void **)&d_wide, sizeof(pw::LaneBuildItem) * items.wide.size());
+                if (e == hipSuccess) e = hipMemcpyAsync(d_wide, items.wide.data(), sizeof(pw::LaneBuildItem) * items.wide.size(), hipMemcpyHostToDevice, g->stream);
+            }
             logged = e == hipSuccess;
         }
         if (!logged) {   // (no room: the two passes)
             (void)hipGetLastError();
-            for (void **q : {(void **)&d_log, (void **)&d_seglo, (void **)&d_vm0, (void **)&d_logoff})
+            for (void **q : {(void **)&d_log, (void **)&d_seglo, (void **)&d_vm0, (void **)&d_logoff, (void **)&d_wide, (void **)&d_vlog})
                 if (*q) { (void)hipFree(*q); *q = nullptr; }
         } else {
             ba.log = d_log;
@@ -484,8 +492,8 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
             else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
         }
         if (vlines) {
-            if (fill) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
-            else hipLaunchKernelGGL(pw::vline_lists_kernel<false>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, (uint8_t *)nullptr);
+            if (fill) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist, (uint32_t *)nullptr);
+            else hipLaunchKernelGGL(pw::vline_lists_kernel<false>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, (uint8_t *)nullptr, d_vlog);
         }
     };
     lists(false);
@@ -556,12 +564,15 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     if (logged) {   // the logged matches to their places; the FILL pass is left with the pairs of rows beyond 65536 entries
         hipLaunchKernelGGL(pw::lane_scatter_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, ba, d_edge_row, d_vm0, nnz);
         ba.logged = 1u;
-        if (g->max_degree > 65536u) lists(true);
-        else if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
+        if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist, (uint32_t *)nullptr);
     } else
     lists(true);
-    hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)n_lines + 255) / 256)), dim3(256), 0, g->stream, g->d_lines,
-                       g->d_clist, n_lines);
+    {   // (logged build: lane_scatter_kernel wrote the pivots of the CSR entries' lists with the lists; the overflow lines are left)
+        const uint32_t first = logged ? nnz : 0u;
+        if (n_lines > first)
+            hipLaunchKernelGGL(pw::eline_pivots_kernel, dim3((unsigned)(((uint64_t)(n_lines - first) + 255) / 256)), dim3(256), 0, g->stream,
+                               g->d_lines, g->d_clist, n_lines, first);
+    }
     e = hipGetLastError();
     INDEX_KERNELS_END(g);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);

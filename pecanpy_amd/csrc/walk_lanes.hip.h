@@ -1124,10 +1124,30 @@ walk_lanes_kernel(LanesArgs a) {
 #ifndef PW_CHAIN_WAVES
 #define PW_CHAIN_WAVES 5   // 88 VGPRs; six waves (80) spill 44 bytes and gain 0.5 %
 #endif
+#ifndef PW_CHAIN_SORT
+#define PW_CHAIN_SORT 1    // the 256 records of a workgroup are dealt to its lanes in the order of their prefix bound kmax (the chain's
+                           // length): a wavefront lasts as long as its longest chain, so chains of similar length share one
+#endif
 __global__ void __launch_bounds__(256, PW_CHAIN_WAVES)
 lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
                    unsigned long long *stats) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (PW_CHAIN_SORT) {
+        __shared__ uint32_t s_key[256];
+        __shared__ uint16_t s_ord[256];
+        uint32_t key = 0u;                                  // (void slots / steps for lanes_eager_kernel: first, they cost nothing)
+        if (i < n && q[i].job != NOT_FOUND && q[i].kmax != LANE_EAGER_MARK) key = q[i].kmax + 1u;
+        s_key[threadIdx.x] = key;
+        __syncthreads();
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < 256u; j++) {
+            const uint32_t kj = s_key[j];
+            rank += (kj < key || (kj == key && j < threadIdx.x)) ? 1u : 0u;
+        }
+        s_ord[rank] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        i = (uint64_t)blockIdx.x * 256 + s_ord[threadIdx.x];
+    }
     unsigned long long reads_l = 0, done = 0;
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
     typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -1484,14 +1504,18 @@ struct LaneBuildArgs {
     // in a block of the log sized by the pair's upper bound d_k (log_off[e2] slots in; a segment's sub-block starts at the
     // first key of row k inside the segment's id range) -- and lane_scatter_kernel copies them to their places once the
     // offsets are known: the intersection of the long rows (50 GB of neighbour rows streamed through LDS at RMAT-22) runs
-    // ONCE.  Pairs whose positions do not fit 16 bits (a row beyond 65536 entries) keep the two passes.
+    // ONCE.  Rows beyond 65536 entries log 64-bit words (log_wide).
     uint32_t *log;
     const unsigned long long *log_off;
     uint32_t *seglo;                // per-(neighbour, segment): first key of row k inside the segment (sub-block start), like segcnt
     uint32_t logged;                // FILL: the loggable pairs were written by lane_scatter_kernel -- skip them
 };
 // a pair (h -> k) handled by h whose two lists can be logged: both positions fit 16 bits
-__device__ __forceinline__ bool pair_loggable(uint32_t d_h, uint32_t d_k) { return d_h <= 65536u && d_k <= 65536u; }
+// Log words: (position in row k) | (position in row h) << 16 while row h has at most 65536 entries (an entry without a reverse
+// edge has no list (k -> h): its word is the position in row k alone, all 32 bits); rows h beyond that use 64-bit words,
+// (position in row k) | (position in row h) << 32, two slots each.  Every pair a vertex takes can be logged.
+__device__ __forceinline__ bool log_wide(uint32_t d_h) { return d_h > 65536u; }
+__device__ __forceinline__ uint32_t log_pair_slots(uint32_t d_h, uint32_t d_k) { return log_wide(d_h) ? 2u * d_k : (d_k + 1u) & ~1u; }
 
 // ELine[e] = { v, 0, position of u in row v, degree(v), indptr[v], 0 } for e = (u -> v); the reverse position comes
 // from one probe of the adjacency index (walk_sparse.hip.h)
@@ -1544,9 +1568,11 @@ vline_init_kernel(CsrDev g, ELine *lines) {
 // The lists of the overflow lines: one wavefront per vertex v streams row v and looks every neighbour up in x0's
 // adjacency index (one probe; x0 is a hub more often than not -- the smallest neighbour of the next vertex -- and its
 // table stays in L2): the hits, in row order, ARE the ascending positions in row x0.  FILL = false: the count.
+// vlog != nullptr (count pass of the LOGGED build): the hits are kept at vlog[indptr[v] + rank] and vline_scatter_kernel copies
+// them to their places once the offsets are known -- the rows are streamed through the index once.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
+vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist, uint32_t *vlog = nullptr) {
     const uint32_t v = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
     if (v >= g.n_nodes) return;
     const int lane = lane_id();
@@ -1574,9 +1600,27 @@ vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
             const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
             if (narrow) ((uint16_t *)p)[rk] = (uint16_t)gpos; else ((uint32_t *)p)[rk] = gpos;
         }
+        if (!FILL && vlog && hit) vlog[s_v + run + (uint32_t)__popcll(m & lane_lt)] = gpos;
         run += (uint32_t)__popcll(m);
     }
     if (!FILL && lane == 0) lines[e].n_in = run;
+}
+__global__ void __launch_bounds__(256)
+vline_scatter_kernel(CsrDev g, ELine *lines, uint8_t *clist, const uint32_t *__restrict__ vlog, uint32_t max_len) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_nodes) return;
+    const uint32_t e = g.nnz + v;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    const uint32_t n = r0.y, d0 = r0.w;
+    if (r0.x == NOT_FOUND || d0 == 0 || n == 0) return;
+    const bool narrow = d0 <= 65536u;
+    const uint32_t coff = lines[e].coff;
+    if (!(narrow && n <= EL_INLINE) && (coff == EL_NO_LIST || n > max_len)) return;   // (partial index: list left out)
+    uint8_t *p = (narrow && n <= EL_INLINE) ? (uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+    const uint32_t *src = vlog + g.indptr[v];
+    for (uint32_t i = 0; i < n; i++) {
+        if (narrow) ((uint16_t *)p)[i] = (uint16_t)src[i]; else ((uint32_t *)p)[i] = src[i];
+    }
 }
 
 __device__ __forceinline__ bool list_is_narrow(uint32_t deg) { return deg <= 65536u; }
@@ -1640,7 +1684,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             // more than 65536 entries that has no reverse entry is taken by h whatever the degrees, and its short list
             // lives in the overflow array as uint32 positions, which only the FILL pass writes.
             // Partial index: a list longer than max_len is stored nowhere (both directions: same length) -- nothing to fill.
-            const bool done = FILL && ((nseg == 1 && list_is_inline(d_k, r0.y)) || r0.y > a.max_len || (a.logged && pair_loggable(d_h, d_k)));
+            const bool done = FILL && ((nseg == 1 && list_is_inline(d_k, r0.y)) || r0.y > a.max_len || a.logged);
             if (mine && d_k && !done) {
                 uint32_t lo_i = 0, hi_i = d_k;
                 if (nseg > 1) {   // keys of row k inside this segment's id range
@@ -1672,12 +1716,15 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                             }
                         }
                         uint32_t *lg = nullptr;
-                        if (LOG && pair_loggable(d_h, d_k)) lg = a.log + a.log_off[e2] + lo_i;
+                        if (LOG) lg = a.log + a.log_off[e2] + (log_wide(d_h) ? 2u * lo_i : lo_i);
                         for (uint32_t i = lo_i; i < hi_i; i++) {
                             const uint32_t w = a.indices[s_k + i];
                             const uint32_t idx = lds_lower_bound(keys, P, w);
                             if (keys[idx] == w) {
-                                if (LOG && lg) lg[cnt] = i | ((a0 + idx) << 16);
+                                if (LOG) {
+                                    if (log_wide(d_h)) ((unsigned long long *)lg)[cnt] = (unsigned long long)i | ((unsigned long long)(a0 + idx) << 32);
+                                    else lg[cnt] = rev == NOT_FOUND ? i : (i | ((a0 + idx) << 16));
+                                }
                                 if (FILL) {
                                     if (k_narrow) ((uint16_t *)p2)[cnt] = (uint16_t)i; else ((uint32_t *)p2)[cnt] = i;
                                     if (p1) { if (h_narrow) ((uint16_t *)p1)[cnt] = (uint16_t)(a0 + idx); else ((uint32_t *)p1)[cnt] = a0 + idx; }
@@ -1736,7 +1783,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 }
             }
             uint32_t *lg = nullptr;
-            if (LOG && pair_loggable(d_h, d_k)) lg = a.log + a.log_off[e2] + lo_i;
+            if (LOG) lg = a.log + a.log_off[e2] + (log_wide(d_h) ? 2u * lo_i : lo_i);
             for (uint32_t c0 = lo_i; c0 < hi_i; c0 += WAVE) {
                 const uint32_t i = c0 + (uint32_t)lane;
                 const bool valid = i < hi_i;
@@ -1744,7 +1791,11 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
                 const uint32_t idx = lds_lower_bound(keys, P, w);
                 const bool hit = valid && keys[idx] == w;
                 const uint64_t m = ballot(hit);
-                if (LOG && lg && hit) lg[run + (uint32_t)__popcll(m & lane_lt)] = i | ((a0 + idx) << 16);
+                if (LOG && hit) {
+                    const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
+                    if (log_wide(d_h)) ((unsigned long long *)lg)[rk] = (unsigned long long)i | ((unsigned long long)(a0 + idx) << 32);
+                    else lg[rk] = rev == NOT_FOUND ? i : (i | ((a0 + idx) << 16));
+                }
                 if (FILL && hit) {
                     const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
                     if (k_narrow) ((uint16_t *)p2)[rk] = (uint16_t)i; else ((uint32_t *)p2)[rk] = i;
@@ -1788,7 +1839,7 @@ __device__ __forceinline__ uint32_t log_slots(const ELine *lines, const uint32_t
     const uint32_t h = edge_row[e2], k = r0.x, rev = r0.z, d_k = r0.w;
     const uint32_t d_h = indptr[h + 1] - indptr[h];
     const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
-    return (mine && d_h >= 2u && d_k && pair_loggable(d_h, d_k)) ? d_k : 0u;
+    return (mine && d_h >= 2u && d_k) ? log_pair_slots(d_h, d_k) : 0u;
 }
 __global__ void __launch_bounds__(CL_BLOCK)
 log_tile_sums_kernel(const ELine *__restrict__ lines, const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ edge_row, uint32_t nnz,
@@ -1842,8 +1893,8 @@ lane_scatter_kernel(LaneBuildArgs a, const uint32_t *__restrict__ edge_row, cons
     const int lane = lane_id();
     const uint64_t e2 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     bool todo = false;
-    uint32_t n = 0, nseg = 1, segbase = 0, s_k = 0, rev = NOT_FOUND;
-    uint16_t *p2 = nullptr, *p1 = nullptr;
+    uint32_t n = 0, nseg = 1, segbase = 0, s_k = 0, rev = NOT_FOUND, k_wide = 0, h_wide = 0;
+    uint8_t *p2 = nullptr, *p1 = nullptr;
     const uint32_t *src = nullptr;
     if (e2 < nnz && log_slots(a.lines, a.indptr, edge_row, e2)) {
         const uint4 r0 = *(const uint4 *)(a.lines + e2);
@@ -1851,43 +1902,95 @@ lane_scatter_kernel(LaneBuildArgs a, const uint32_t *__restrict__ edge_row, cons
         const uint32_t h = edge_row[e2], d_k = r0.w;
         const uint32_t s_h = a.indptr[h], d_h = a.indptr[h + 1] - s_h;
         n = r0.y; rev = r0.z; s_k = r1.x;
+        k_wide = list_is_narrow(d_k) ? 0u : 1u;
+        h_wide = log_wide(d_h) ? 1u : 0u;
         nseg = d_h > (uint32_t)LB_SEG ? (d_h + LB_SEG - 1) / LB_SEG : 1u;
         // (single-segment rows: the COUNT pass wrote the lists that fit their lines itself; partial index: lists left out)
         todo = n != 0u && !(nseg == 1u && list_is_inline(d_k, n)) && n <= a.max_len;
         if (todo) {
-            p2 = (uint16_t *)list_base(a.lines, a.clist, (uint32_t)e2, d_k, n, r1.y);
+            p2 = (uint8_t *)list_base(a.lines, a.clist, (uint32_t)e2, d_k, n, r1.y);
             if (rev != NOT_FOUND) {
                 const uint32_t e1 = s_k + rev;
-                p1 = (uint16_t *)list_base(a.lines, a.clist, e1, d_h, a.lines[e1].n_in, a.lines[e1].coff);
+                p1 = (uint8_t *)list_base(a.lines, a.clist, e1, d_h, a.lines[e1].n_in, a.lines[e1].coff);
             }
             src = a.log + a.log_off[e2];
             if (nseg > 1u) segbase = vm0[h] + ((uint32_t)e2 - s_h) * nseg;
         }
     }
-    const bool small_one = todo && nseg == 1u && n <= 32u;
-    if (small_one)
+    // word i of a block -> (position in row k, position in row h)
+    auto put = [](uint8_t *q2, uint8_t *q1, uint32_t at, uint32_t pk, uint32_t ph, uint32_t kw, uint32_t hw) {
+        if (kw) ((uint32_t *)q2)[at] = pk; else ((uint16_t *)q2)[at] = (uint16_t)pk;
+        if (q1) { if (hw) ((uint32_t *)q1)[at] = ph; else ((uint16_t *)q1)[at] = (uint16_t)ph; }
+    };
+    // ... and the PIVOTS of both lists into the inline areas of their lines (seqscan.h: entry (t + 1) * step of the list, 20 of them,
+    // 10 for uint32 lists) -- the words are at hand here; eline_pivots_kernel is left with the overflow lines
+    const bool small_one = todo && nseg == 1u && n <= 32u;    // (single-segment rows are narrow: 32-bit words)
+    if (small_one) {
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t v = src[i];
-            p2[i] = (uint16_t)v;
-            if (p1) p1[i] = (uint16_t)(v >> 16);
+            put(p2, p1, i, rev == NOT_FOUND ? v : (v & 0xffffu), v >> 16, k_wide, 0u);
         }
+        if (list_has_pivots(k_wide, n)) {                     // (n > 20: the list (h -> k) lives in the overflow array)
+            const uint32_t np = list_pivot_count(k_wide), step = list_pivot_step(k_wide, n);
+            uint8_t *dst = (uint8_t *)(a.lines + e2) + 24;
+            for (uint32_t t = 0; t < np; t++) {
+                const uint32_t v = src[(t + 1u) * step];
+                put(dst, nullptr, t, rev == NOT_FOUND ? v : (v & 0xffffu), 0u, k_wide, 0u);
+            }
+        }
+        if (p1 && list_has_pivots(0u, n)) {
+            const uint32_t step = list_pivot_step(0u, n);
+            uint16_t *dst = (uint16_t *)((uint8_t *)(a.lines + (s_k + rev)) + 24);
+            for (uint32_t t = 0; t < LIST_PIVOTS_NARROW; t++) dst[t] = (uint16_t)(src[(t + 1u) * step] >> 16);
+        }
+    }
     uint64_t big = ballot(todo && !small_one);
     while (big) {
         const int l = __ffsll((long long)big) - 1;
         big &= big - 1ull;
         const uint32_t nsg = readlane_u32(nseg, l), sb = readlane_u32(segbase, l), nn = readlane_u32(n, l);
+        const uint32_t kw = readlane_u32(k_wide, l), hw = readlane_u32(h_wide, l), norev = readlane_u32(rev, l) == NOT_FOUND ? 1u : 0u;
         const uint32_t *sp = (const uint32_t *)readlane_u64((uint64_t)src, l);
-        uint16_t *q2 = (uint16_t *)readlane_u64((uint64_t)p2, l), *q1 = (uint16_t *)readlane_u64((uint64_t)p1, l);
+        uint8_t *q2 = (uint8_t *)readlane_u64((uint64_t)p2, l), *q1 = (uint8_t *)readlane_u64((uint64_t)p1, l);
         uint32_t out = 0;
         for (uint32_t sg = 0; sg < nsg; sg++) {
             const uint32_t cnt = nsg > 1u ? a.segcnt[sb + sg] : nn;
-            const uint32_t *ss = sp + (nsg > 1u ? a.seglo[sb + sg] : 0u);
+            const uint32_t lo = nsg > 1u ? a.seglo[sb + sg] : 0u;
             for (uint32_t i = (uint32_t)lane; i < cnt; i += WAVE) {
-                const uint32_t v = ss[i];
-                q2[out + i] = (uint16_t)v;
-                if (q1) q1[out + i] = (uint16_t)(v >> 16);
+                if (hw) {
+                    const unsigned long long v = ((const unsigned long long *)sp)[lo + i];
+                    put(q2, q1, out + i, (uint32_t)v, (uint32_t)(v >> 32), kw, 1u);
+                } else {
+                    const uint32_t v = sp[lo + i];
+                    put(q2, q1, out + i, norev ? v : (v & 0xffffu), v >> 16, kw, 0u);
+                }
             }
             out += cnt;
+        }
+        // pivots: lane t looks entry (t + 1) * step up through the segment table
+        const uint32_t e2l = (uint32_t)((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u) + (uint32_t)l);
+        const uint32_t s_kl = readlane_u32(s_k, l), revl = readlane_u32(rev, l);
+        for (int which = 0; which < 2; which++) {
+            const uint32_t wide = which == 0 ? kw : hw;
+            if (which == 1 && !q1) break;
+            // (the list must live in the overflow array: its inline area is free for the pivots)
+            if (!list_has_pivots(wide, nn)) continue;
+            const uint32_t np = list_pivot_count(wide), step = list_pivot_step(wide, nn);
+            if ((uint32_t)lane < np) {
+                uint32_t target = ((uint32_t)lane + 1u) * step, base = 0, pk = 0, ph = 0;
+                for (uint32_t sg = 0; sg < nsg; sg++) {
+                    const uint32_t cnt = nsg > 1u ? a.segcnt[sb + sg] : nn;
+                    if (target < base + cnt) {
+                        const uint32_t lo = nsg > 1u ? a.seglo[sb + sg] : 0u;
+                        if (hw) { const unsigned long long v = ((const unsigned long long *)sp)[lo + target - base]; pk = (uint32_t)v; ph = (uint32_t)(v >> 32); }
+                        else { const uint32_t v = sp[lo + target - base]; pk = norev ? v : (v & 0xffffu); ph = v >> 16; }
+                        break;
+                    }
+                    base += cnt;
+                }
+                uint8_t *dst = (uint8_t *)(a.lines + (which == 0 ? e2l : s_kl + revl)) + 24;
+                if (wide) ((uint32_t *)dst)[lane] = which == 0 ? pk : ph; else ((uint16_t *)dst)[lane] = (uint16_t)(which == 0 ? pk : ph);
+            }
         }
     }
 }
@@ -1914,8 +2017,8 @@ clist_length_hist_kernel(const ELine *__restrict__ lines, uint32_t n_lines, unsi
 // PIVOTS of the lists that live in the overflow array, written into the unused inline area of their lines after the FILL
 // pass (seqscan.h: ListView / list_search_pivots): entry (k + 1) * step of the list, k = 0 .. 19 (9 for uint32 lists)
 __global__ void __launch_bounds__(256)
-eline_pivots_kernel(ELine *lines, const uint8_t *__restrict__ clist, uint32_t n_lines) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+eline_pivots_kernel(ELine *lines, const uint8_t *__restrict__ clist, uint32_t n_lines, uint32_t first = 0) {
+    const uint64_t e = (uint64_t)first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_lines) return;
     const uint4 r0 = *(const uint4 *)(lines + e);
     if (r0.x == NOT_FOUND) return;                    // (an overflow line without a target)
