@@ -197,7 +197,14 @@ __device__ unsigned long long g_lprof[16];
 #define PW_LANES_QDRAW_EARLY 1   // the next step's draw is requested together with the line, not after the record has arrived
 #endif
 #ifndef PW_LANES_CHAIN_TH
-#define PW_LANES_CHAIN_TH 28     // CHAINS form: steps waiting for their float chain that trigger a chain pass of the pool
+#define PW_LANES_CHAIN_TH 20     // CHAINS form: steps waiting for their float chain that trigger a chain pass of the pool (28: the pool
+                                 // fills up and steps are parked after all -- 5.2 M jobs at RMAT-22: 23.8 ms, two rounds; 20: 21.4, one; 12: 22.8)
+#endif
+#ifndef PW_LANES_CPOOL
+#define PW_LANES_CPOOL 64        // ... its pool slots / window jobs
+#endif
+#ifndef PW_LANES_CWIN
+#define PW_LANES_CWIN 64
 #endif
 #ifndef PW_LANES_MIN_WAVES_C
 #define PW_LANES_MIN_WAVES_C 3   // ... its occupancy (the chain code needs ~150 VGPRs)
@@ -338,9 +345,9 @@ walk_lanes_kernel(LanesArgs a) {
     constexpr bool QUAD = PW_LANES_QUAD && !FLOATS && !WEIGHTED && !TAILS;
     constexpr bool LINE_LDS = (TAILS || PW_LANES_LINE_LDS) && !QUAD;
     static_assert(!(QUAD && PW_LANES_DRAW_LDS), "the QUAD form fetches its draws with the lines");
-    constexpr int POOL_N = CHAINS ? 64 : QUAD ? (PW_LANES_POOL < PW_LANES_QPOOL ? PW_LANES_POOL : PW_LANES_QPOOL)
+    constexpr int POOL_N = CHAINS ? PW_LANES_CPOOL : QUAD ? (PW_LANES_POOL < PW_LANES_QPOOL ? PW_LANES_POOL : PW_LANES_QPOOL)
                                 : (TAILS ? (PW_LANES_POOL < 32 ? PW_LANES_POOL : 32) : PW_LANES_POOL);
-    constexpr int WIN_N = CHAINS ? 64 : QUAD ? (PW_LANES_WIN < PW_LANES_QWIN ? PW_LANES_WIN : PW_LANES_QWIN)
+    constexpr int WIN_N = CHAINS ? PW_LANES_CWIN : QUAD ? (PW_LANES_WIN < PW_LANES_QWIN ? PW_LANES_WIN : PW_LANES_QWIN)
                                : (TAILS ? (PW_LANES_WIN < 32 ? PW_LANES_WIN : 32) : PW_LANES_WIN);
     constexpr uint32_t DEFER_TH = TAILS ? (PW_LANES_DEFER_TH < 16 ? PW_LANES_DEFER_TH : 16) : PW_LANES_DEFER_TH;
     const int lane = lane_id();
