@@ -308,7 +308,7 @@ int pw_selftest_lane_unit_bounded(const uint8_t *cls, uint32_t n, float w_out, f
  * step then takes the wave-per-walk scan). */
 int pw_selftest_lane_weighted(const float *vals, const float *base, const uint8_t *cls, uint32_t n, const double *r,
                               uint32_t n_r, uint32_t *chain, uint32_t *lane);
-/* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). *//* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
+/* float64 flavour (DenseOTF column-space kernel, dense_rw.py:34-72 semantics; exact_thresholds_f64). */
 int pw_selftest_exact_decision_f64(const uint8_t *cls, uint32_t n, double w_out, double w_prev, const double *r,
                                    uint32_t n_r, uint32_t *chain, uint32_t *exact);
 

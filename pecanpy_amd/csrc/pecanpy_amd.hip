@@ -609,7 +609,12 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     bool monotone = true;
     for (uint32_t i = 0; i < n_nodes && monotone; i++) monotone = indptr[i + 1] >= indptr[i];
     if (!monotone) return fail(PW_ERR_INVALID, "indptr not monotone");
-    std::thread item_thread([&]() { if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items); });
+    std::thread item_thread;
+    try {
+        item_thread = std::thread([&]() { if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items); });
+    } catch (const std::system_error &) {   // (thread limit of the process: the items are made on this thread)
+        if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items);
+    }
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{item_thread};
     pw_graph *g = new pw_graph();
     int rc = graph_common_init(g, device);
@@ -2220,6 +2225,7 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     memset(&total, 0, sizeof(total));
     CopyFeed feed;
     std::thread copier;
+    bool copy_inline = false;
     int copy_rc = 0;
     std::string copy_err;
     uint64_t skip = stream_skip;
@@ -2263,17 +2269,26 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
             total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch; total.verify_dropped += st.verify_dropped;
             total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
         }
-        if (!copier.joinable())                        // (ONE copy for all parts: it follows the rows announced below)
-            copier = std::thread([&]() {
-                (void)hipSetDevice(g->device);
-                copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
-                if (copy_rc) copy_err = g_err;         // (g_err is thread local: carried over below)
-            });
+        if (!copier.joinable() && !copy_inline) {      // (ONE copy for all parts: it follows the rows announced below)
+            try {
+                copier = std::thread([&]() {
+                    (void)hipSetDevice(g->device);
+                    copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
+                    if (copy_rc) copy_err = g_err;     // (g_err is thread local: carried over below)
+                });
+            } catch (const std::system_error &) {      // (thread limit of the process: the copy runs on this thread, after the parts)
+                copy_inline = true;
+            }
+        }
         feed.announce((size_t)hi * row_bytes);
     }
     if (rc) feed.stop();
     const double t3 = now();
     if (copier.joinable()) copier.join();
+    else if (!rc && copy_inline) {
+        copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
+        if (copy_rc) copy_err = g_err;
+    }
     if (!rc && copy_rc) rc = fail(copy_rc, copy_err);
     if (!rc && g->rng_hold.valid) {   // (the parts found their draws in place: the one expansion is the call's generator time)
         float ms = 0;

@@ -146,7 +146,11 @@ class PeerRowWriter:
     tensors and scatters nothing: it only walks its own shard and prefills the rows nobody sends.  Same interface as
     ``RowGather`` (``post`` / ``expect`` / ``finish`` / ``prefill`` / ``own_rows``); ``expect`` is a no-op.
     Selected by ``bench.py --gather-mode peer``; the RCCL send/recv form stays the default until an 8-GPU run has
-    compared them (single node, CUDA tensors and the nccl backend only)."""
+    compared them (single node, CUDA tensors and the nccl backend only).
+
+    HAZARD (unlike ``RowGather``, whose receives are posted by the reader): a sender's ``post`` of the NEXT pass writes straight
+    into rank ``dst``'s matrix.  The matrix returned by ``finish()`` must be consumed or copied before any rank starts its next
+    pass -- ``bench.py`` brackets every pass with a barrier on both sides."""
 
     def __init__(self, n_rows, width, bounds, dtype, device, dst=0, group=None, known=None, fill_known=None):
         import torch
@@ -169,6 +173,11 @@ class PeerRowWriter:
         else:
             rebuild, args = handle[0]
             args = list(args)
+            # torch's private rebuild_cuda_tensor tuple: (cls, size, stride, offset, storage_cls, dtype, storage_device, handle, ...);
+            # the layout is checked before element 6 is patched -- a different torch release fails here, loudly, and the caller
+            # (bench.py) falls back to the RCCL send / recv gather on every rank
+            if len(args) < 8 or not isinstance(args[6], int) or not isinstance(args[1], (tuple, torch.Size)):
+                raise RuntimeError("unexpected rebuild_cuda_tensor argument layout: peer gather unavailable with this torch")
             args[6] = torch.cuda.current_device()     # (storage device index: the mapping lives in THIS process's context)
             self.full = rebuild(*args)                # dst's matrix, mapped into this process: stores go over xGMI
         self._sel_cache = {}

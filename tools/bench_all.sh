@@ -7,7 +7,7 @@ cd $R
 : > $OUT/configs.jsonl
 timeout 200 python bench.py --steps 5 --warmup 2 > $OUT/headline.json 2> $OUT/headline.err
 for c in C2 C3 C5 C4; do
-  timeout 300 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline 2> $OUT/$c.err | tail -1 >> $OUT/configs.jsonl
+  timeout 300 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-host-call 2> $OUT/$c.err | tail -1 >> $OUT/configs.jsonl
 done
 # unit graph, p and q not powers of two: no lane kernel (the float32 chain is the only decision), wave kernel with masks from the lists
-timeout 300 python bench.py --p 0.3 --q 1.7 --steps 2 --warmup 1 --no-cpu-baseline 2> $OUT/nondyadic.err | tail -1 >> $OUT/configs.jsonl
+timeout 300 python bench.py --p 0.3 --q 1.7 --steps 2 --warmup 1 --no-cpu-baseline --no-host-call 2> $OUT/nondyadic.err | tail -1 >> $OUT/configs.jsonl
