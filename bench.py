@@ -251,7 +251,8 @@ def main():
     # stream) overlaps the walk kernel of chunk c + 1; --gather-chunks 1 = one blocking gather at the end
     if args.gather_chunks == "auto":   # (the same on every rank: from the LARGEST shard)
         largest = max(b - a for a, b in all_bounds)
-        auto_chunks = 2 if largest < 8_000_000 else 3 if largest < 16_000_000 else 4
+        # (round 5: a chunk of a shard costs ~2.9 ms + 3.55 ms per million jobs in the CHAINS form -- three chunks even for small shards)
+        auto_chunks = 3 if largest < 16_000_000 else 4
     n_chunks = (auto_chunks if args.gather_chunks == "auto" else max(1, int(args.gather_chunks))) if do_gather else 1
     chunk_bounds = tapered_bounds(hi - lo, n_chunks)   # decreasing sizes: the exposed tail is the smallest chunk's transfer
     csum = np.concatenate([[0], np.cumsum(has_nbr[starts[lo:hi]], dtype=np.int64)])

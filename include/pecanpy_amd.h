@@ -63,8 +63,9 @@ typedef struct {
     double walk_kernel_ms;    /* HIP-event time of the walk kernel launches of this call */
     double rng_kernel_ms;     /* HIP-event time of the MT19937 expansion kernels */
     uint32_t walk_kernel_launches;
-    uint32_t stream_addressing; /* 0: the reference's exact draw assignment; 1: nominal per-walk slots
-                                   (fallback on sink-heavy directed graphs) */
+    uint32_t stream_addressing; /* 0: the reference's exact draw assignment (also on sink-heavy directed graphs: block-wise
+                                   repair); 1: nominal per-walk slots -- only with the explicit opt-in
+                                   PECANPY_AMD_NOMINAL_STREAM=1 in the environment, after 32 re-addressing passes */
     /* lane kernel (one walk per lane, csrc/walk_lanes.hip.h): unit-weight CSR graphs, 1/p and 1/q powers of two */
     uint32_t lane_kernel;       /* 1: the call ran on the lane kernel; 2: on its float-chain form (1/p or 1/q not a power of two);
                                    3: on its weighted form (weighted CSR graphs: float64-bounded decision, eager_steps = the steps
