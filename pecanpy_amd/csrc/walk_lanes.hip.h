@@ -857,23 +857,25 @@ walk_lanes_kernel(LanesArgs a) {
                 choice = lane_decide_begin(A.d, A.n_in, A.pp, r, wo, w_prev, ls, dc);
                 go = choice != LANE_REDO;
                 if (go && A.n_in) {
-                    const MassEval ev{A.pp, dc.sh_in, dc.sh_out, dc.sh_prev};
-                    ListView v{nullptr, narrow ? 0u : 1u};
-                    v.tail = qslot + 16u; v.tshift = 4u;
-                    if (narrow && A.n_in <= EL_INLINE) {          // the list itself is in the line
-                        v.inl = 1u;
-                        sr = list_search(v, 0u, A.n_in, ev, (uint64_t)dc.lo_th, ls.probes);
-                        ls.probes = 0;                            // (LDS reads: no list bytes left the memory)
-                    } else {
-                        s_hi = A.n_in;
-                        if (list_has_pivots(v.wide, A.n_in)) {
-                            v.npiv = list_pivot_count(v.wide);
-                            v.step = list_pivot_step(v.wide, A.n_in);
-                            list_search_pivots(v, ev, (uint64_t)dc.lo_th, s_lo, s_hi, sr);
-                        }
-                        need = s_lo < s_hi;
-                        sr.f = s_lo;
+                    // ONE bisection over what the line holds -- the list itself (n_in <= 20 entries of a narrow row) or the pivots of a
+                    // longer one, entry (t + 1) * step at slot t -- for all lanes together (two loops, one per kind, cost the
+                    // wavefront twice the instructions); every mass is below 2^24 units: 32-bit arithmetic
+                    const MassEval ev64{A.pp, dc.sh_in, dc.sh_out, dc.sh_prev};
+                    const uint32_t wide = narrow ? 0u : 1u;
+                    const bool inl = narrow && A.n_in <= EL_INLINE;
+                    const uint32_t step = inl ? 1u : list_pivot_step(wide, A.n_in);
+                    uint32_t klo = 0, khi = inl ? A.n_in : (list_has_pivots(wide, A.n_in) ? list_pivot_count(wide) : 0u);
+                    s_hi = A.n_in;
+                    while (klo < khi) {
+                        const uint32_t km = (klo + khi) >> 1;
+                        const uint32_t ik = inl ? km : (km + 1u) * step;
+                        const uint32_t P = narrow ? q_u16(24u + (km << 1)) : q_u32(24u + (km << 2));
+                        const uint32_t vm = (uint32_t)ev64(ik, P);
+                        if (vm >= dc.lo_th) { khi = km; s_hi = ik; sr.p_at = P; sr.v_at = vm; }
+                        else { klo = km + 1u; s_lo = ik + 1u; sr.p_below = P; sr.v_below = vm; sr.has_below = true; }
                     }
+                    need = !inl && s_lo < s_hi;
+                    sr.f = s_lo;
                 }
             }
             for (uint32_t trip = 0; ballot(need); trip++) {
