@@ -562,23 +562,6 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
 // positions that holds it); the chain is monotone, so c_{k1-1} < r <= c_{k1} -- i.e. hi(k1 - 1) < r and lo(k1) >= r --
 // makes k1 the reference's answer.  Otherwise LANE_AMBIGUOUS: the step goes to the wave-per-walk scan (RMAT-20 with
 // hashed weights: 10 % of the steps; the bound saturates on rows beyond a few thousand entries).
-struct WeightedRow {
-    const double *pq;   // [d] inclusive float64 prefix sums of the base values of cur's row
-    const double *dl;   // [n_in] inclusive prefix sums, in list order, of (step value - base value) of the common neighbours
-    double dprev;       // (step value - base value) of prev's element (0: prev is not in the row)
-    PW_HD double pq_at(uint32_t k) const { return pq[k]; }
-    PW_HD double dl_at(uint32_t i) const { return dl[i]; }   // (through the common neighbour of index i: i + 1 of them)
-};
-// The same row description in CLOSED FORM for unit weights (round 5: unit graphs whose 1/p or 1/q is not a power of two):
-// every neighbour weighs b = fl32(1/q) (1 on the first step of a walk) unless it is a common neighbour (1) or prev (fl32(1/p)),
-// so the prefix sums need no tables: PQ[k] = (k + 1) b, DL[i] = (i + 1)(1 - b), dprev = fl32(1/p) - b -- products of a
-// float32 by an integer below 2^24, exact in float64.
-struct UnitPrefixRow {
-    double b, db;       // base value, (1 - base value)
-    double dprev;
-    PW_HD double pq_at(uint32_t k) const { return ((double)k + 1.0) * b; }
-    PW_HD double dl_at(uint32_t i) const { return ((double)i + 1.0) * db; }
-};
 // Relative drift of the float32 chain after element k: v_i = fl32(w'_i / tot) and k float32 additions of non-negative terms
 // give |c_k - S(k) / tot| <= ((1 + u)^(k + 1) - 1) S(k) / tot, u = 2^-24, and (1 + u)^n - 1 <= n u / (1 - n u) for n u < 1
 // (valid for EVERY k -- round 4's 1.05 (k + 3) u covered the second-order term only up to k ~ 800 000); n = k + 3 and the
@@ -589,6 +572,43 @@ PW_HD double weighted_eps(uint32_t k) {
     return nu < 0.25 ? nu / (1.0 - nu) * 1.000001 + 1e-9 : 1e300;
 }
 
+struct WeightedRow {
+    const double *pq;   // [d] inclusive float64 prefix sums of the base values of cur's row
+    const double *dl;   // [n_in] inclusive prefix sums, in list order, of (step value - base value) of the common neighbours
+    double dprev;       // (step value - base value) of prev's element (0: prev is not in the row)
+    PW_HD double pq_at(uint32_t k) const { return pq[k]; }
+    PW_HD double dl_at(uint32_t i) const { return dl[i]; }   // (through the common neighbour of index i: i + 1 of them)
+    // half-width of the interval around S(k) (before the division by tot) that holds tot * c_k: the first-order bound
+    PW_HD double margin(uint32_t k, uint32_t /*f*/, uint32_t /*pp*/, double S) const { return S * weighted_eps(k); }
+};
+// The same row description in CLOSED FORM for unit weights (round 5: unit graphs whose 1/p or 1/q is not a power of two):
+// every neighbour weighs b = fl32(1/q) (1 on the first step of a walk) unless it is a common neighbour (1) or prev (fl32(1/p)),
+// so the prefix sums need no tables: PQ[k] = (k + 1) b, DL[i] = (i + 1)(1 - b), dprev = fl32(1/p) - b -- products of a
+// float32 by an integer below 2^24, exact in float64.
+struct UnitPrefixRow {
+    double b, db;       // base value, (1 - base value)
+    double dprev;
+    PW_HD double pq_at(uint32_t k) const { return ((double)k + 1.0) * b; }
+    PW_HD double dl_at(uint32_t i) const { return ((double)i + 1.0) * db; }
+    // The SHARPER bound this row admits: the rounding of addition j is relative to the partial sum c_j it produces, so
+    //   |c_k - s_k| <= u / (1 - u) * sum_{j = 1..k} c_j <= u (1 + 2 gamma_k) * sum_{j <= k} s_j,    s_j = sum of the rounded quotients,
+    // and s_j <= S(j) / tot * (1 + u): the drift is bounded by the SUM OF THE PREFIX SUMS T(k) = sum_{j <= k} S(j), about half of
+    // (k + 1) S(k) when the sums grow evenly.  T(k) in closed form needs the positions of the common neighbours; with f of them at
+    // positions <= k it is bounded from above WITHOUT the list: sum_{j <= k} #commons(j) lies in [f (f + 1) / 2, (k + 1) f - f (f - 1) / 2]
+    // (all as late / as early as distinct positions allow), prev contributes dprev (k - pp + 1) when it is in the prefix (0 when
+    // dprev < 0: an upper bound).  Monotone in k (b (k + 2) per position outweighs the commons' term), and never above the
+    // first-order bound (k + 1) S(k).  f = common neighbours at positions <= k.
+    PW_HD double margin(uint32_t k, uint32_t f, uint32_t pp, double S) const {
+        const double kd = (double)k, fd = (double)f;
+        double T = 0.5 * b * (kd + 1.0) * (kd + 2.0);
+        T += db >= 0.0 ? db * ((kd + 1.0) * fd - 0.5 * fd * (fd - 1.0)) : db * (0.5 * fd * (fd + 1.0));
+        if (pp <= k && dprev > 0.0) T += dprev * (kd - (double)pp + 1.0);
+        const double u = 1.0 / 16777216.0, ku = (kd + 3.0) * u;
+        if (!(ku < 0.25)) return 1e300;
+        const double rho = u * (1.0 + 2.0 * ku / (1.0 - ku)) * 1.000001;
+        return S * (u * 1.000001 + 1e-9) + rho * T;
+    }
+};
 template <class Row>
 struct BoundedEval {   // upper bound of the chain at the common neighbour i (position P), as order-preserving bits
     const Row *wr;
@@ -596,7 +616,7 @@ struct BoundedEval {   // upper bound of the chain at the common neighbour i (po
     double inv;
     PW_HD uint64_t operator()(uint32_t i, uint32_t P) const {
         const double S = wr->pq_at(P) + wr->dl_at(i) + (pp < P ? wr->dprev : 0.0);
-        const double hi = S * inv * (1.0 + weighted_eps(P)) + 3e-45 * ((double)P + 1.0);
+        const double hi = (S + wr->margin(P, i + 1u, pp, S)) * inv + 3e-45 * ((double)P + 1.0);
         return FloatTraits<double>::bits(hi > 0.0 ? hi : 0.0);
     }
 };
@@ -623,26 +643,27 @@ PW_HD uint32_t lane_decide_bounded(uint32_t d, uint32_t n_in, uint32_t pp, doubl
     auto sum_at = [&](uint32_t k, uint32_t commons) -> double {   // S(k) with `commons` common neighbours at positions <= k
         return wr.pq_at(k) + (commons ? wr.dl_at(commons - 1u) : 0.0) + (pp <= k ? wr.dprev : 0.0);
     };
-    auto hi_of = [&](uint32_t k, double S) { return S * inv * (1.0 + weighted_eps(k)) + 3e-45 * ((double)k + 1.0); };
-    auto lo_of = [&](uint32_t k, double S) { return S * inv * (1.0 - weighted_eps(k)) - 3e-45 * ((double)k + 1.0); };
+    // (commons: common neighbours at positions <= k)
+    auto hi_of = [&](uint32_t k, double S, uint32_t commons) { return (S + wr.margin(k, commons, pp, S)) * inv + 3e-45 * ((double)k + 1.0); };
+    auto lo_of = [&](uint32_t k, double S, uint32_t commons) { return (S - wr.margin(k, commons, pp, S)) * inv - 3e-45 * ((double)k + 1.0); };
     // first position of the run [ks, ke) whose upper bound reaches r (none: ke -- the common neighbour there, or d)
     uint32_t lo = ks, hi = ke;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         const double S = wr.pq_at(mid) + dbase + (pp <= mid ? wr.dprev : 0.0);
         probes++;
-        if (hi_of(mid, S) >= r) hi = mid; else lo = mid + 1u;
+        if (hi_of(mid, S, f) >= r) hi = mid; else lo = mid + 1u;
     }
     const uint32_t k1 = lo;
     // the chain is monotone: c_{k1 - 1} < r <= c_{k1} settles it
     if (k1 > 0u) {
         const uint32_t kp = k1 - 1u;                       // (>= ks - 1: `f` common neighbours at positions <= kp)
-        if (!(hi_of(kp, sum_at(kp, f)) < r)) return LANE_AMBIGUOUS;
+        if (!(hi_of(kp, sum_at(kp, f), f) < r)) return LANE_AMBIGUOUS;
     }
     k_safe = k1;                                           // (c_j <= c_{k1 - 1} < r for every j < k1: the chain is monotone)
     if (k1 >= d) return d;                                 // never reached: the mirrored overflow read (choice == degree)
     const uint32_t commons = (k1 == ke && f < n_in) ? f + 1u : f;
-    if (!(lo_of(k1, sum_at(k1, commons)) >= r)) return LANE_AMBIGUOUS;
+    if (!(lo_of(k1, sum_at(k1, commons), commons) >= r)) return LANE_AMBIGUOUS;
     return k1;
 }
 PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
