@@ -274,6 +274,52 @@ def test_parked_walks_and_chain_kernel_equal_in_place_chains_and_oracle(p, q, mo
     assert runs["queue"]["ambiguous_steps"] == runs["in_place"]["ambiguous_steps"] > runs["queue"]["wave_chain_steps"]
 
 
+@pytest.mark.parametrize("p,q", [(0.5, 2), (0.25, 4)])
+def test_chains_form_equals_the_rounds_and_the_oracle(p, q, monkeypatch):
+    """Round 5, CHAINS form: job arrays of 1..32 jobs per resident lane run in ONE launch whose wavefronts run the float chains
+    themselves, from the pool (no parking, no chain kernel, no rounds).  Same walks as the queueing form with its rounds, as the
+    plain in-place launch, and as the oracle on a prefix -- on an R-MAT graph large enough for the form to be picked by the
+    engine's own rule, and on the hub graph forced into it (chains on long rows, overflow lists searched sector by sector)."""
+    import torch
+
+    indptr, indices, data = rmat_csr(17, seed=5)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 10)
+    np.random.RandomState(1).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    runs = {}
+    for name, env in (("chains", {"PECANPY_AMD_LANE_CHAINS": "1"}), ("rounds", {"PECANPY_AMD_LANE_CHAINS": "0", "PECANPY_AMD_CHAIN_TAIL": "65536"}),
+                      ("in_place", {"PECANPY_AMD_LANE_CHAINS": "0", "PECANPY_AMD_NO_CHAIN_QUEUE": "1"}), ("default", {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = eng.simulate_device("SparseOTF", p, q, False, d_starts, 80, seed=7)
+        for k in env:
+            monkeypatch.delenv(k)
+        runs[name] = (out, dict(eng.last_stats))
+    want, ost = orc.walks_sparse_otf(indptr, indices, data, p, q, starts[:8000], 80, 7, return_stats=True)
+    for name, (out, st) in runs.items():
+        assert st["lane_kernel"] == 1 and st["redo_walks"] == 0, (name, st)
+        assert torch.equal(out, runs["chains"][0]), name
+        assert st["total_steps"] == runs["chains"][1]["total_steps"]
+    assert np.array_equal(runs["chains"][0][:8000].cpu().numpy().view(np.uint32), want)
+    assert runs["chains"][1]["lane_rounds"] == 1 and runs["rounds"][1]["lane_rounds"] > 1
+    assert runs["chains"][1]["wave_chain_steps"] > 0
+    assert runs["default"][1]["lane_rounds"] == 1          # (1.3 M jobs: the engine's rule picks the CHAINS form)
+    # the hub graph: long rows, most steps ambiguous, many chains per wavefront
+    rng = np.random.default_rng(13)
+    indptr, indices, data = _hub_graph(rng)
+    hn = indptr.size - 1
+    hstarts = np.concatenate([np.zeros(300, dtype=np.uint32), rng.integers(0, hn, 30000).astype(np.uint32)])
+    hwant = orc.walks_sparse_otf(indptr, indices, data, p, q, hstarts, 24, 4)
+    heng = WalkEngine.from_csr(indptr, indices, data)
+    monkeypatch.setenv("PECANPY_AMD_LANE_CHAINS", "1")
+    got = heng.simulate("SparseOTF", p, q, False, hstarts, 24, seed=4)
+    monkeypatch.delenv("PECANPY_AMD_LANE_CHAINS")
+    assert heng.last_stats["lane_kernel"] == 1 and heng.last_stats["wave_chain_steps"] > 0
+    assert np.array_equal(got, hwant)
+
+
 def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
     """Directed graph with sinks: the repair passes run the lane kernel on job lists; with every chain step parked the
     rounds resume walks of a job list."""
