@@ -107,10 +107,11 @@ struct pw_graph {
     bool utot_failed = false;
     // weighted lane form (walk_lanes.hip.h: WEIGHTED): base values, their per-row float64 prefix sums, per-entry delta prefix sums
     float *d_wb = nullptr;
-    double *d_wpq = nullptr, *d_wdl = nullptr, *d_wl_dprev = nullptr;
+    pw::PrefixPair *d_wpq = nullptr;
+    double *d_wdl = nullptr, *d_wl_dprev = nullptr;
     unsigned long long *d_wl_off = nullptr;
     uint32_t *d_wedge_row = nullptr;                    // ... source vertex of every CSR entry
-    double *d_wp1 = nullptr;                            // ... per-row prefix sums of the raw weights (first steps; graph-static)
+    pw::PrefixPair *d_wp1 = nullptr;                    // ... per-row prefix sums of the raw weights (first steps; graph-static)
     unsigned long long *d_wck_off = nullptr;            // ... recorded chain values (wckpt_kernel): first record of entry e
     float *d_wck = nullptr;
     uint64_t wdl_cap = 0, wck_cap = 0;
@@ -1243,12 +1244,12 @@ static int ensure_wlane_tables(pw_graph *g, const pw::WalkArgs &wa, bool extend,
     auto give_up = [&]() { g->wl_failed = true; (void)hipGetLastError(); return 0; };
     if (!g->d_wb) {
         hipError_t e = hipMalloc((void **)&g->d_wb, sizeof(float) * (size_t)nnz);
-        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wpq, sizeof(double) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wpq, sizeof(pw::PrefixPair) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_dprev, sizeof(double) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_off, sizeof(unsigned long long) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wck_off, sizeof(unsigned long long) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wedge_row, sizeof(uint32_t) * (size_t)nnz);
-        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wp1, sizeof(double) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wp1, sizeof(pw::PrefixPair) * (size_t)nnz);
         if (e != hipSuccess) return give_up();
         hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_wedge_row);
         hipLaunchKernelGGL(pw::wprefix_kernel, dim3((unsigned)(((uint64_t)g->n_nodes * pw::WAVE + 255) / 256)), dim3(256), 0, g->stream, g->d_indptr,
@@ -1383,6 +1384,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     la.wl_dprev = g->d_wl_dprev;
     la.tot_e = wa.tot_e;
     la.wp1 = getenv("PECANPY_AMD_NO_WFIRST") ? nullptr : g->d_wp1;
+    la.wl_pos = wa.q >= 1.0 ? 1u : 0u;
     la.tot_v = wa.tot_v;
     // TAILS form (the rest of the edge line staged in LDS): for graphs whose edge lines stay cache resident -- there the
     // probes of inline lists and pivots are L2 hits that LDS reads replace; beyond that the HBM probes of the long lists
@@ -2894,7 +2896,10 @@ PW_EXPORT int pw_selftest_lane_weighted(const float *vals, const float *base, co
     std::vector<float> c(n);
     float acc = 0.0f;
     for (uint32_t k = 0; k < n; k++) { acc = acc + vals[k] / tot; c[k] = acc; }   // cumsum of fl32(w / tot)
-    std::vector<double> pq(n), dl;
+    std::vector<pw::PrefixPair> pq(n);
+    std::vector<double> dl;
+    double trun = 0.0;
+    bool any_pos = false, any_neg = false;
     std::vector<uint16_t> cl16;
     std::vector<uint32_t> cl32;
     const uint32_t wide = n > 65536u ? 1u : 0u;
@@ -2902,8 +2907,11 @@ PW_EXPORT int pw_selftest_lane_weighted(const float *vals, const float *base, co
     uint32_t pp = 0xffffffffu;
     for (uint32_t k = 0; k < n; k++) {
         run += (double)base[k];
-        pq[k] = run;
+        trun += run;
+        pq[k] = pw::PrefixPair{run, trun};
         if (cls[k] == 1) {
+            if (vals[k] > base[k]) any_pos = true;
+            if (vals[k] < base[k]) any_neg = true;
             drun += (double)vals[k] - (double)base[k];
             dl.push_back(drun);
             if (wide) cl32.push_back(k); else cl16.push_back((uint16_t)k);
@@ -2924,7 +2932,8 @@ PW_EXPORT int pw_selftest_lane_weighted(const float *vals, const float *base, co
     }
     dl.push_back(0.0);
     const pw::ListView view = pw::list_view_of(wide ? (const void *)cl32.data() : (const void *)cl16.data(), wide, n_cl, piv_off);
-    const pw::WeightedRow wr{pq.data(), dl.data(), dprev};
+    if (any_pos && any_neg) return fail(PW_ERR_INVALID, "the common neighbours' differences must share one sign (that of q - 1)");
+    const pw::WeightedRow wr{pq.data(), dl.data(), dprev, !any_neg};
     for (uint32_t i = 0; i < n_r; i++) {
         uint32_t lo = 0, hi = n;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }

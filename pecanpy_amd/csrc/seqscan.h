@@ -569,17 +569,36 @@ PW_HD uint32_t lane_decide(uint32_t d, uint32_t n_in, uint32_t pp, double r, flo
 // left to the exact scan).
 PW_HD double weighted_eps(uint32_t k) {
     const double nu = ((double)k + 3.0) * (1.0 / 16777216.0);
-    return nu < 0.25 ? nu / (1.0 - nu) * 1.000001 + 1e-9 : 1e300;
+    return nu < 0.25 ? nu * (1.0 + 1.34 * nu) * 1.000001 + 1e-9 : 1e300;   // (1 / (1 - x) <= 1 + 1.34 x for x < 0.25: no division)
 }
 
+struct PrefixPair {     // of a row's base values: p = their inclusive prefix sum at this element, t = the sum of the prefix sums so far
+    double p, t;
+};
 struct WeightedRow {
-    const double *pq;   // [d] inclusive float64 prefix sums of the base values of cur's row
+    const PrefixPair *pq;   // [d] float64 prefix sums of the base values of cur's row (+ their running sum: one 16-byte load)
     const double *dl;   // [n_in] inclusive prefix sums, in list order, of (step value - base value) of the common neighbours
     double dprev;       // (step value - base value) of prev's element (0: prev is not in the row)
-    PW_HD double pq_at(uint32_t k) const { return pq[k]; }
+    bool dl_pos;        // the common neighbours' differences are all >= 0 (q >= 1) -- else all <= 0
+    PW_HD double pq_at(uint32_t k) const { return pq[k].p; }
     PW_HD double dl_at(uint32_t i) const { return dl[i]; }   // (through the common neighbour of index i: i + 1 of them)
-    // half-width of the interval around S(k) (before the division by tot) that holds tot * c_k: the first-order bound
-    PW_HD double margin(uint32_t k, uint32_t /*f*/, uint32_t /*pp*/, double S) const { return S * weighted_eps(k); }
+    // Half-width of the interval around S(k) (before the division by tot) that holds tot * c_k.  Round 5: the sharper bound of
+    // UnitPrefixRow::margin (below) -- u (1 + 2 gamma) times the SUM OF THE PREFIX SUMS T(k) -- with T's base part from the table
+    // (pq[k].t) and the common neighbours' part bounded without their positions: their differences share the sign of q - 1
+    // (value >= base for q >= 1: sparse_rw.py:84-86 / 119-125, rounding is monotone), so sum_j DL(#commons(j)) <= (k + 1) DL(f) when
+    // they are positive and <= 0 otherwise; prev likewise.  Never above the first-order bound (k + 3) u S(k), which remains the
+    // fallback (a negative DL(f) under dl_pos cannot happen and is not trusted).
+    PW_HD double margin(uint32_t k, uint32_t f, uint32_t pp, double S) const {
+        const double DLf = f ? dl[f - 1u] : 0.0;
+        if (dl_pos ? DLf < 0.0 : DLf > 0.0) return S * weighted_eps(k);
+        const double kd = (double)k;
+        double T = pq[k].t + (dl_pos ? (kd + 1.0) * DLf : 0.0);
+        if (pp <= k && dprev > 0.0) T += dprev * (kd - (double)pp + 1.0);
+        const double u = 1.0 / 16777216.0, ku = (kd + 3.0) * u;
+        if (!(ku < 0.25)) return 1e300;
+        const double rho = u * (1.0 + 3.0 * ku) * 1.000001;          // (2 / (1 - ku) < 3 for ku < 0.25)
+        return S * (u * 1.000001 + 1e-9) + rho * T;                   // (T <= (k + 1) S: never above the first-order bound)
+    }
 };
 // The same row description in CLOSED FORM for unit weights (round 5: unit graphs whose 1/p or 1/q is not a power of two):
 // every neighbour weighs b = fl32(1/q) (1 on the first step of a walk) unless it is a common neighbour (1) or prev (fl32(1/p)),
@@ -605,7 +624,7 @@ struct UnitPrefixRow {
         if (pp <= k && dprev > 0.0) T += dprev * (kd - (double)pp + 1.0);
         const double u = 1.0 / 16777216.0, ku = (kd + 3.0) * u;
         if (!(ku < 0.25)) return 1e300;
-        const double rho = u * (1.0 + 2.0 * ku / (1.0 - ku)) * 1.000001;
+        const double rho = u * (1.0 + 3.0 * ku) * 1.000001;          // (2 / (1 - ku) < 3 for ku < 0.25)
         return S * (u * 1.000001 + 1e-9) + rho * T;
     }
 };

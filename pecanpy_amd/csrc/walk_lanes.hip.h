@@ -108,12 +108,13 @@ struct LanesArgs {
     uint32_t ver_poison;                      // PECANPY_AMD_VERIFY_TIGHT=poison: every 1024th RECORD (not the walk) gets a wrong
                                               // position, which the check must report -- proves the check is live
     // WEIGHTED form (weighted CSR graphs; per (p, q, extend, thresholds) tables built by wbase / wprefix / wlist kernels)
-    const double *wpq;                        // [nnz] per-row inclusive float64 prefix sums of the base values
+    const PrefixPair *wpq;                    // [nnz] per-row inclusive float64 prefix sums of the base values (+ their running sums)
     const double *wdl;                        // per-entry lists of delta prefix sums (entry e: wdl + wl_off[e], n_in values)
     const unsigned long long *wl_off;         // [nnz] offset of entry e's deltas; ~0: no table for this entry (eager step)
     const double *wl_dprev;                   // [nnz] (step value - base value) of prev's element when arriving by entry e
     const float *tot_e;                       // [nnz] the step's normaliser (sequential float32 row total) by arriving entry
-    const double *wp1;                        // [nnz] per-row inclusive float64 prefix sums of the RAW weights (first step of a walk)
+    const PrefixPair *wp1;                    // [nnz] per-row inclusive float64 prefix sums of the RAW weights (first step of a walk)
+    uint32_t wl_pos;                          // q >= 1: the common neighbours' (step value - base value) are all >= 0
     const float *tot_v;                       // [n_nodes] ... and its normaliser, by vertex
 };
 
@@ -818,14 +819,14 @@ walk_lanes_kernel(LanesArgs a) {
                 if (A.j == 1u && a.wp1) {
                     // first step: no prev, the raw weights over their sequential float32 total (sparse_rw.py:66-67 / 89) -- the
                     // same decision on the prefix sums of the raw row (A.e holds the start vertex until the step is applied)
-                    const WeightedRow wr{a.wp1 + A.s0, nullptr, 0.0};
+                    const WeightedRow wr{a.wp1 + A.s0, nullptr, 0.0, true};
                     uint32_t probes_ = 0;
                     choice = lane_decide_weighted(A.d, 0u, NOT_FOUND, r, a.tot_v[A.e], wr, ListView{nullptr, 0u}, probes_, wk_safe);
                     n_probes += probes_;
                     if (choice == LANE_REDO) choice = LANE_AMBIGUOUS;
                 }
                 if (wo_ != ~0ull) {
-                    const WeightedRow wr{a.wpq + A.s0, a.wdl + wo_, a.wl_dprev[A.e]};
+                    const WeightedRow wr{a.wpq + A.s0, a.wdl + wo_, a.wl_dprev[A.e], a.wl_pos != 0u};
                     uint32_t probes_ = 0;
                     choice = lane_decide_weighted(A.d, A.n_in, A.pp, r, a.tot_e[A.e], wr, lane_list(A.e, A.d, A.n_in, A.coff), probes_, wk_safe);
                     n_probes += probes_;
@@ -1372,14 +1373,14 @@ wbase_kernel(const float *__restrict__ data, const uint32_t *__restrict__ edge_r
     wb[e] = Arith<float>::bias_mul(w, alpha);
 }
 
-// Per-row inclusive float64 prefix sums of the base values (one wavefront per row)
+// Per-row inclusive float64 prefix sums of the base values, and the running sums of those prefix sums (one wavefront per row)
 __global__ void __launch_bounds__(256)
-wprefix_kernel(const uint32_t *__restrict__ indptr, const float *__restrict__ wb, uint32_t n_nodes, double *pq) {
+wprefix_kernel(const uint32_t *__restrict__ indptr, const float *__restrict__ wb, uint32_t n_nodes, PrefixPair *pq) {
     const uint32_t v = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
     if (v >= n_nodes) return;
     const int lane = lane_id();
     const uint32_t s0 = indptr[v], d = indptr[v + 1] - s0;
-    double carry = 0.0;
+    double carry = 0.0, carry2 = 0.0;
     for (uint32_t c0 = 0; c0 < d; c0 += WAVE) {
         const uint32_t k = c0 + (uint32_t)lane;
         double x = k < d ? (double)wb[s0 + k] : 0.0;
@@ -1388,8 +1389,16 @@ wprefix_kernel(const uint32_t *__restrict__ indptr, const float *__restrict__ wb
             const double y = __shfl_up(x, (unsigned)off, WAVE);
             if (lane >= off) x += y;
         }
-        if (k < d) pq[s0 + k] = carry + x;
+        const double pk = carry + x;                  // prefix sum at element k (lanes beyond the row: the row's total so far)
+        double t = k < d ? pk : 0.0;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const double y = __shfl_up(t, (unsigned)off, WAVE);
+            if (lane >= off) t += y;
+        }
+        if (k < d) pq[s0 + k] = PrefixPair{pk, carry2 + t};
         carry += __shfl(x, WAVE - 1, WAVE);
+        carry2 += __shfl(t, WAVE - 1, WAVE);
     }
 }
 
