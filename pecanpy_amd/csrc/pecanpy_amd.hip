@@ -327,7 +327,6 @@ static pw::CsrDev csr_dev(const pw_graph *g);
 // CSR travels to the device.
 struct LaneWorkItems {
     std::vector<pw::LaneBuildItem> small, large;
-    std::vector<pw::LaneBuildItem> wide;   // the items of `large` whose row has more than 65536 entries (positions beyond 16 bits)
     uint64_t segcnt_total = 0;
     std::vector<uint32_t> vm0;      // per vertex: base of its per-segment counts (rows longer than LB_SEG; 0 otherwise)
 };
@@ -348,8 +347,6 @@ static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneW
     std::stable_sort(w.large.begin(), w.large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
         return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];
     });
-    for (const pw::LaneBuildItem &it : w.large)
-        if (indptr[it.h + 1] - indptr[it.h] > 65536u) w.wide.push_back(it);
 }
 
 // device time of a group of index kernels: g->ev[2] / g->ev[3] around it, added to g->index_build_ms once it has run
@@ -387,15 +384,15 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     stamp("hipMemGetInfo");
     const uint64_t line_bytes = (uint64_t)n_lines * sizeof(pw::ELine) + 64;
     if (line_bytes > free_b / 2) return 0;
-    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr, *d_wide = nullptr;
+    pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
     uint32_t *d_segcnt = nullptr;
     uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
-    uint32_t *d_log = nullptr, *d_seglo = nullptr, *d_vm0 = nullptr, *d_vlog = nullptr;    // LOGGED build (below)
+    uint32_t *d_log = nullptr, *d_seglo = nullptr, *d_vm0 = nullptr;    // LOGGED build (below)
     unsigned long long *d_logoff = nullptr;
     const uint64_t n_tiles = ((uint64_t)n_lines + pw::CL_TILE - 1) / pw::CL_TILE;
     auto cleanup = [&]() {
-        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_wide, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles, (void *)d_log,
-                        (void *)d_seglo, (void *)d_vm0, (void *)d_logoff, (void *)d_vlog})
+        for (void *q : {(void *)d_small, (void *)d_large, (void *)d_segcnt, (void *)d_tiles, (void *)d_etiles, (void *)d_log,
+                        (void *)d_seglo, (void *)d_vm0, (void *)d_logoff})
             if (q) (void)hipFree(q);
     };
     auto drop = [&](int rc) {   // no lane index
@@ -463,15 +460,11 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
             if (e == hipSuccess) e = hipMalloc((void **)&d_seglo, sizeof(uint32_t) * (size_t)(segcnt_total + 1));
             if (e == hipSuccess) e = hipMalloc((void **)&d_vm0, sizeof(uint32_t) * ((size_t)n_nodes + 1));
             if (e == hipSuccess) e = hipMemcpyAsync(d_vm0, items.vm0.data(), sizeof(uint32_t) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, g->stream);
-            if (e == hipSuccess && !items.wide.empty()) {
-                e = hipMalloc((void **)&d_wide, sizeof(pw::LaneBuildItem) * items.wide.size());
-                if (e == hipSuccess) e = hipMemcpyAsync(d_wide, items.wide.data(), sizeof(pw::LaneBuildItem) * items.wide.size(), hipMemcpyHostToDevice, g->stream);
-            }
             logged = e == hipSuccess;
         }
         if (!logged) {   // (no room: the two passes)
             (void)hipGetLastError();
-            for (void **q : {(void **)&d_log, (void **)&d_seglo, (void **)&d_vm0, (void **)&d_logoff, (void **)&d_wide, (void **)&d_vlog})
+            for (void **q : {(void **)&d_log, (void **)&d_seglo, (void **)&d_vm0, (void **)&d_logoff})
                 if (*q) { (void)hipFree(*q); *q = nullptr; }
         } else {
             ba.log = d_log;
@@ -493,8 +486,8 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
             else hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, false>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);
         }
         if (vlines) {
-            if (fill) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist, (uint32_t *)nullptr);
-            else hipLaunchKernelGGL(pw::vline_lists_kernel<false>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, (uint8_t *)nullptr, d_vlog);
+            if (fill) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
+            else hipLaunchKernelGGL(pw::vline_lists_kernel<false>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, (uint8_t *)nullptr);
         }
     };
     lists(false);
@@ -565,7 +558,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     if (logged) {   // the logged matches to their places; the FILL pass is left with the pairs of rows beyond 65536 entries
         hipLaunchKernelGGL(pw::lane_scatter_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, ba, d_edge_row, d_vm0, nnz);
         ba.logged = 1u;
-        if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist, (uint32_t *)nullptr);
+        if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
     } else
     lists(true);
     {   // (logged build: lane_scatter_kernel wrote the pivots of the CSR entries' lists with the lists; the overflow lines are left)

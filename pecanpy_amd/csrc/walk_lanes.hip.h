@@ -23,25 +23,32 @@
 // A step of the reference (SparseOTF.move_forward, src/pecanpy/pecanpy.py:543-559; get_normalized_probs,
 // src/pecanpy/rw/sparse_rw.py:51-91) then is: the exact-arithmetic decision of seqscan.h (E(k) = exact mass of
 // elements 0..k in units of the smallest weight; first k with E(k) >= ceil(R - z) and E(k) >= ceil(R + z))
-// evaluated by ONE LANE: a bisection over the edge's common-neighbour positions (each P_i splits the row into
+// evaluated by ONE LANE: a search over the edge's common-neighbour positions (each P_i splits the row into
 // runs of "out" neighbours whose mass is a closed form), no membership work at all.  64 walks advance per
-// wavefront instruction; a step costs one 64-byte line, ~log2(n_common / 21) probes of the overflow array for the
-// lists that have one, one 8-byte draw and one 4-byte output cell.
+// wavefront instruction.
+//
+// Round 5, QUAD form: what a step reads of the graph arrives in WHOLE 64-byte sectors fetched by quads of lanes straight into
+// LDS -- the edge line the walk enters (record + inline list or pivots: one request per step) and the sectors of an overflow
+// list its search looks into (chosen by interpolation between the masses at the ends of the range) -- because the vector memory
+// path charges per (instruction, line) request, not per byte (tools/lane_mem_bench.hip, profiles/r05_lane_mem_bench.txt).
 //
 // Steps the a-priori bound cannot settle (a partial sum of the exact CDF lies within the float32 drift bound of
 // the target, 12 % of the steps at RMAT-22) go through two more routines of seqscan.h:
 //   lane_tight : the chain's SYSTEMATIC drift bounded from the class counts the decision already has -- arithmetic
-//                only, ~850 instructions, settles nine in ten of them.  Round 4: NOT run where the ambiguity turns up
-//                (an eighth of the lanes enabled, nearly every loop iteration: 40 % of the kernel's vector
-//                instructions in round 3) but DEFERRED: the walk's context waits in a per-wavefront POOL in LDS, the
-//                lane takes another walk, and one PASS decides 32+ waiting steps at once (DEFER, below).
-//   lane_chain : the float32 chain itself.  Not run in place either: the walk is PARKED (SuspRec into a global queue),
-//                lanes_chain_kernel settles a whole queue at full width and the next ROUND of this kernel resumes the
-//                walks (host loop: pecanpy_amd.hip, launch_lane_walks).  The last, small round runs them in place.
+//                only, ~850 instructions, settles nine in ten of them.  DEFERRED (round 4): the walk's context waits in a
+//                per-wavefront POOL in LDS, the lane takes another walk, and one PASS decides 32+ waiting steps at once.
+//   lane_chain : the float32 chain itself (1.2 % of the steps).  Queueing form: the walk is PARKED (SuspRec into a global
+//                queue), lanes_chain_kernel settles a whole queue at full width and the next ROUND of this kernel resumes the
+//                walks (host loop: pecanpy_amd.hip, launch_lane_walks); the last, small round runs them in place.  CHAINS form
+//                (round 5, small job arrays): the open steps stay in the pool and the wavefront runs their chains itself, 20
+//                at a time -- one launch, no rounds.
+// Other forms of the same kernel: FLOATS (unit weights, 1/p or 1/q not a power of two: a float64-bounded decision from
+// closed-form prefix sums and per-line row totals, chains for what it leaves open) and WEIGHTED (the same bound over per-(p, q)
+// tables; open steps decided by lanes_eager_weighted_kernel).
 // The rare rest -- rows whose total is not exact in float32, tie binades beyond the budget, overflow reads without a
 // line -- is not handled here: the job is appended to a redo list and walk_kernel takes the walk over at that step.
-// Registers decide everything here: the queueing form needs 92 VGPRs (5 waves/SIMD, no scratch; with lane_tight in
-// place it was 80 / 6 waves), the in-place form ~120 (4 waves); any spill in the step loop costs more than a wave brings.
+// Registers decide everything here: any spill in the step loop costs more than a wave brings (queueing form: 106 VGPRs,
+// 4 workgroups per CU with its 36 KB of LDS; in place: 128; CHAINS: 142, 3 per CU).
 #pragma once
 #include "walk_sparse.hip.h"
 
@@ -1586,11 +1593,11 @@ vline_init_kernel(CsrDev g, ELine *lines) {
 // The lists of the overflow lines: one wavefront per vertex v streams row v and looks every neighbour up in x0's
 // adjacency index (one probe; x0 is a hub more often than not -- the smallest neighbour of the next vertex -- and its
 // table stays in L2): the hits, in row order, ARE the ascending positions in row x0.  FILL = false: the count.
-// vlog != nullptr (count pass of the LOGGED build): the hits are kept at vlog[indptr[v] + rank] and vline_scatter_kernel copies
-// them to their places once the offsets are known -- the rows are streamed through the index once.
+// (Round 5 tried keeping the count pass's hits and copying them by a per-vertex scatter instead of the second lookup pass: 15 ms
+// against 6.4 -- one thread per vertex with scattered reads; the two passes stay.)
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist, uint32_t *vlog = nullptr) {
+vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
     const uint32_t v = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
     if (v >= g.n_nodes) return;
     const int lane = lane_id();
@@ -1618,29 +1625,10 @@ vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist, uint32_t *vlog = null
             const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
             if (narrow) ((uint16_t *)p)[rk] = (uint16_t)gpos; else ((uint32_t *)p)[rk] = gpos;
         }
-        if (!FILL && vlog && hit) vlog[s_v + run + (uint32_t)__popcll(m & lane_lt)] = gpos;
         run += (uint32_t)__popcll(m);
     }
     if (!FILL && lane == 0) lines[e].n_in = run;
 }
-__global__ void __launch_bounds__(256)
-vline_scatter_kernel(CsrDev g, ELine *lines, uint8_t *clist, const uint32_t *__restrict__ vlog, uint32_t max_len) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_nodes) return;
-    const uint32_t e = g.nnz + v;
-    const uint4 r0 = *(const uint4 *)(lines + e);
-    const uint32_t n = r0.y, d0 = r0.w;
-    if (r0.x == NOT_FOUND || d0 == 0 || n == 0) return;
-    const bool narrow = d0 <= 65536u;
-    const uint32_t coff = lines[e].coff;
-    if (!(narrow && n <= EL_INLINE) && (coff == EL_NO_LIST || n > max_len)) return;   // (partial index: list left out)
-    uint8_t *p = (narrow && n <= EL_INLINE) ? (uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
-    const uint32_t *src = vlog + g.indptr[v];
-    for (uint32_t i = 0; i < n; i++) {
-        if (narrow) ((uint16_t *)p)[i] = (uint16_t)src[i]; else ((uint32_t *)p)[i] = src[i];
-    }
-}
-
 __device__ __forceinline__ bool list_is_narrow(uint32_t deg) { return deg <= 65536u; }
 __device__ __forceinline__ bool list_is_inline(uint32_t deg, uint32_t n_in) { return list_is_narrow(deg) && n_in <= EL_INLINE; }
 __device__ __forceinline__ const uint8_t *list_base(const ELine *lines, const uint8_t *clist, uint32_t e, uint32_t deg,
