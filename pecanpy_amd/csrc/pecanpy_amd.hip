@@ -84,6 +84,7 @@ struct pw_graph {
     bool unit = false;  // all weights are 1.0f (data not stored)
     uint32_t max_degree = 0;
     uint32_t *d_indptr = nullptr, *d_indices = nullptr;
+    uint32_t *d_hasnbr = nullptr;                       // bit v: vertex v has neighbours (stream offsets; built by the first call)
     void *d_data = nullptr;          // float32 (CSR graphs) or float64 (dense graphs); null when unit
     float *d_thr = nullptr;
     uint64_t *d_adjbits = nullptr;   // dense graphs: bit-packed adjacency rows
@@ -258,6 +259,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (g->d_clist) (void)hipFree(g->d_clist);
     if (g->d_tot_e) (void)hipFree(g->d_tot_e);
     if (g->d_utot) (void)hipFree(g->d_utot);
+    if (g->d_hasnbr) (void)hipFree(g->d_hasnbr);
     if (g->d_tot_v) (void)hipFree(g->d_tot_v);
     for (void *q : {(void *)g->d_wb, (void *)g->d_wpq, (void *)g->d_wdl, (void *)g->d_wl_dprev, (void *)g->d_wl_off, (void *)g->d_wedge_row, (void *)g->d_wp1,
                     (void *)g->d_wck_off, (void *)g->d_wck})
@@ -895,15 +897,20 @@ static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t
     if (g->stream_off.ensure(n_jobs + 1)) return PW_ERR_NOMEM;
     if (g->tile_sums.ensure(n_tiles + 1)) return PW_ERR_NOMEM;
     if (track_changes && g->changed.ensure(n_jobs)) return PW_ERR_NOMEM;
+    if (!g->d_hasnbr) {
+        const uint32_t words = (g->n_nodes + 31u) / 32u;
+        HIP_TRY(hipMalloc((void **)&g->d_hasnbr, sizeof(uint32_t) * (size_t)(words ? words : 1)));
+        hipLaunchKernelGGL(pw::has_nbr_bits_kernel, dim3((words + 255) / 256 ? (words + 255) / 256 : 1), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_hasnbr);
+    }
     unsigned long long *cc = g->counters.p + 5;
     if (track_changes) HIP_TRY(hipMemsetAsync(cc, 0, sizeof(unsigned long long), g->stream));
     unsigned long long *fm = first_mismatch ? g->counters.p + 14 : nullptr;
     if (fm) HIP_TRY(hipMemsetAsync(fm, 0xff, sizeof(unsigned long long), g->stream));
     hipLaunchKernelGGL(pw::draws_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
-                       g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p);
+                       g->d_hasnbr, d_starts, d_walks, L, n_jobs, g->tile_sums.p);
     hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, g->tile_sums.p, n_tiles);
     hipLaunchKernelGGL(pw::draws_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
-                       g->d_indptr, d_starts, d_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p,
+                       g->d_hasnbr, d_starts, d_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p,
                        track_changes ? g->changed.p : nullptr, cc, limit < n_jobs ? limit : n_jobs, fm);
     HIP_TRY(hipGetLastError());
     uint64_t tot = 0;
