@@ -439,11 +439,15 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     // lane_scatter_kernel copies them to their places once the offsets are known, so the intersection of the long rows runs
     // ONCE (the FILL pass streamed the same 50 GB of neighbour rows through LDS a second time: 61 of the index's 172 ms).
     // (The lists of the overflow lines keep their two lookup passes: a per-vertex scatter measured 15 ms against 6.4.)
-    // Only when the log fits a third of the free memory (PECANPY_AMD_INDEX_TWO_PASS=1 forces the two passes).
+    // OPT-IN (PECANPY_AMD_INDEX_LOGGED=1), and only when the log fits a third of the free memory: device memory that no process
+    // has used since the box started costs ~23 ms per GB of hipMalloc (the driver clears it on first use; measured on fresh
+    // MI355X boxes: 50 GB of log = 1.0-1.3 s, the lists' 5.2 GB = 121 ms), memory that has been used and freed microseconds.  On a
+    // fresh box the log costs twenty times what it saves; in a long-lived service whose device memory has been touched it saves
+    // 45 ms per graph.  The default is the two-pass build.
     uint64_t log_slots = 0;
     bool logged = false;
     const uint64_t nnz_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
-    if (!getenv("PECANPY_AMD_INDEX_TWO_PASS")) {
+    if (getenv("PECANPY_AMD_INDEX_LOGGED") && !getenv("PECANPY_AMD_INDEX_TWO_PASS")) {
         e = hipMalloc((void **)&d_logoff, sizeof(unsigned long long) * ((size_t)nnz + 1));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(pw::log_tile_sums_kernel, dim3((unsigned)nnz_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, g->d_indptr,

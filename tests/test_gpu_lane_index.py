@@ -160,9 +160,9 @@ def test_directed_entry_into_a_wide_row_without_reverse_edge():
 
 
 def test_logged_build_equals_the_two_pass_build(monkeypatch):
-    """Round 5: the COUNT pass logs its matches and lane_scatter_kernel copies lists and pivots to their places (one
+    """Round 5 (PECANPY_AMD_INDEX_LOGGED=1): the COUNT pass logs its matches and lane_scatter_kernel copies lists and pivots to their places (one
     intersection per pair instead of two).  The decoded index and the walks over it equal those of the COUNT + FILL build
-    (PECANPY_AMD_INDEX_TWO_PASS=1) -- on an R-MAT graph and on the hub graph with multi-segment rows and uint32 positions."""
+    (the default) -- on an R-MAT graph and on the hub graph with multi-segment rows and uint32 positions."""
     graphs = [rmat_csr(13, seed=3)[:2]]
     rng = np.random.default_rng(4)
     m, hub_deg = 90000, 70000                                # one row beyond 65536 entries (64-bit log words), rows beyond 8192 (segments)
@@ -175,12 +175,12 @@ def test_logged_build_equals_the_two_pass_build(monkeypatch):
         n = indptr.size - 1
         starts = np.random.default_rng(1).integers(0, n, 20000).astype(np.uint32)
         starts[:64] = 0
+        monkeypatch.setenv("PECANPY_AMD_INDEX_LOGGED", "1")
         logged = WalkEngine.from_csr(indptr, indices, None)
+        monkeypatch.delenv("PECANPY_AMD_INDEX_LOGGED")
         a = logged.lane_index()
         wa = logged.simulate("SparseOTF", 0.5, 2, False, starts, 30, seed=3)
-        monkeypatch.setenv("PECANPY_AMD_INDEX_TWO_PASS", "1")
         twopass = WalkEngine.from_csr(indptr, indices, None)
-        monkeypatch.delenv("PECANPY_AMD_INDEX_TWO_PASS")
         b = twopass.lane_index()
         wb = twopass.simulate("SparseOTF", 0.5, 2, False, starts, 30, seed=3)
         for x, y in zip(a, b):
