@@ -1390,10 +1390,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     la.wp1 = getenv("PECANPY_AMD_NO_WFIRST") ? nullptr : g->d_wp1;
     la.wl_pos = wa.q >= 1.0 ? 1u : 0u;
     la.tot_v = wa.tot_v;
-    // TAILS form (the rest of the edge line staged in LDS): for graphs whose edge lines stay cache resident -- there the
-    // probes of inline lists and pivots are L2 hits that LDS reads replace; beyond that the HBM probes of the long lists
-    // set the pace and the plain form is as fast (PECANPY_AMD_LANE_TAILS = 0 / 1 overrides the size rule)
-    bool tails = (uint64_t)g->nnz * sizeof(pw::ELine) <= (uint64_t)2 << 30;   // (RMAT-18 / -20: 15.0 -> 13.4 / 36.9 -> 34.1 ms; RMAT-22, 4.2 GB of lines: 138.8 -> 139.7)
+    // TAILS form (round 4: the rest of the edge line staged in LDS by the lane itself; picked for graphs whose lines stay cache
+    // resident): superseded by the QUAD form, which fetches the whole line by a quad of lanes -- RMAT-20, 10.5 M jobs: 34.1 ms
+    // (TAILS) vs 32.1 (QUAD); kept behind PECANPY_AMD_LANE_TAILS=1 for A/B runs.
+    bool tails = false;
     if (const char *te = getenv("PECANPY_AMD_LANE_TAILS")) tails = atoi(te) != 0;
     if (getenv("PECANPY_AMD_VERIFY_TIGHT") || weighted) tails = false;
     int occ = 0;

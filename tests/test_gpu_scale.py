@@ -150,7 +150,8 @@ def test_full_size_oracle_prefix(run, p, q):
 
 def test_c2_full_size_oracle_prefix():
     """BASELINE C2 as named (RMAT-18, 10 x 80, p = 0.5, q = 2): the whole job array in the form the engine picks for it -- ONE
-    in-place launch of the TAILS instantiation (edge-line tails staged in LDS) -- against the oracle on its first 20 000 jobs."""
+    launch of the CHAINS form (round 5: 2.6 M jobs = 13 per resident lane; float chains run from the pool inside the launch;
+    round 4: one in-place launch of the TAILS instantiation) -- against the oracle on its first 20 000 jobs."""
     import torch
 
     from oracle import pyoracle as orc
@@ -163,7 +164,7 @@ def test_c2_full_size_oracle_prefix():
     out = eng.simulate_device("SparseOTF", 0.5, 2, False, torch.from_numpy(starts.view(np.int32)).cuda(), L, seed=SEED)
     st = dict(eng.last_stats)
     assert st["lane_kernel"] == 1 and st["lane_rounds"] == 1 and st["redo_walks"] == 0, st
-    assert indices.size * 64 <= 2 << 30 and "PECANPY_AMD_LANE_TAILS" not in os.environ   # (launch_lane_walks' rule for the TAILS form)
+    assert "PECANPY_AMD_LANE_CHAINS" not in os.environ and "PECANPY_AMD_LANE_TAILS" not in os.environ   # (the engine's own choice of form)
     n = 20000
     want, ost = orc.walks_sparse_otf(indptr, indices, np.ones(indices.size, dtype=np.float32), 0.5, 2, starts[:n], L, SEED,
                                      return_stats=True)
