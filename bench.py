@@ -141,9 +141,9 @@ def er_bits_gpu(n, density, dev, seed=1):
 
 def load_pmc(key):
     """HBM-side traffic and issue counters of this exact workload from the committed rocprofv3 --pmc passes
-    (profiles/r05_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
+    (profiles/r06_traffic.json, written by tools/pmc_run.sh + tools/pmc_to_json.py); PMC cannot be collected
     inside a timed run."""
-    for name in ("r05_traffic.json", "r04_traffic.json"):   # (a workload not re-profiled this round keeps its last entry)
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):   # (a workload not re-profiled this round keeps its last entry)
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 w = json.load(f)["workloads"].get(key)
@@ -471,7 +471,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "declared_bytes_per_launch": int(declared), "declared_format": fmt,
         "avg_launch_ms": round(k_ms, 3), "rng_jump_and_expand_ms": round(float(np.mean(acc["rng_kernel_ms"])), 3),
-        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r05_traffic.json)"),
+        "traffic_note": ((pmc["note"] + wide_note) if pmc else "no PMC pass committed for this workload (profiles/r06_traffic.json)"),
         "random_sector_peak_GBps": RANDOM_SECTOR_GBS,
         "reference_format_bytes": ref_bytes,
     }
@@ -574,6 +574,8 @@ def main():
                                  "fresh pageable memory), new seed; the device-resident `value` excludes the two copies"}
         except MemoryError:
             host_call = {"note": "not measured: the host could not allocate the walk matrix"}
+        except Exception as exc:   # noqa: BLE001 (the headline line must be printed whatever this extra call does)
+            host_call = {"note": f"not measured: {exc!r}"}
 
     build_s = info["build_ms"] * 1e-3
     result = {

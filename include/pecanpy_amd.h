@@ -105,8 +105,9 @@ int pw_device_count(void);
  * indices uint32[nnz] ascending and duplicate-free per row, data float32[nnz].
  * data may be NULL: all weights 1.0 (the reference's unweighted graphs, graph.py:170,480).
  * Besides the three arrays the handle owns the membership index built here on the device (per-row
- * Bloom filters, adjacency hash index, key stream, vertex records and -- for unit-weight graphs without
- * self loops -- per-edge records with common-neighbour counts): about 55 bytes per CSR entry in total.
+ * Bloom filters, adjacency hash index, key stream, vertex records and the lane index: one 64-byte edge line per CSR entry
+ * with the common-neighbour list of the edge, longer lists in an overflow array; weighted graphs WITH self loops get
+ * none): about 180 bytes per CSR entry at RMAT-22.
  * Limits: the 32-bit offsets of the index allow about 2^33 hash slots, i.e. graphs up to ~2 * 10^9 CSR
  * entries (PW_ERR_INVALID "graph too large" beyond that; the reference's own limit is nnz < 2^32).
  * Environment: PECANPY_AMD_NO_LAZY=1 skips the per-edge records (every step then takes the eager path;
@@ -121,9 +122,10 @@ int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, const float *
  * of the lane kernel's common-neighbour lists (0: lane index not built).  Any pointer may be NULL. */
 int pw_graph_index_info(const pw_graph *g, double *build_ms, uint64_t *index_bytes, uint64_t *lane_list_entries);
 /* Test hook: the lane index decoded to flat arrays (any pointer may be NULL).  For every CSR entry e = (u -> v):
- * n_in[e] = |N(u) & N(v)|, rev_pos[e] = position of u in row v (0xffffffff: v -> u is not an edge); entries = the
+ * n_in[e] = |N(u) & N(v)| (less u itself when u has a self loop: the reference takes prev out of the common neighbours,
+ * sparse_rw.py:79-87), rev_pos[e] = position of u in row v (0xffffffff: v -> u is not an edge); entries = the
  * positions in row v of those common neighbours, ascending, concatenated in entry order (lane_list_entries values,
- * pw_graph_index_info).  PW_ERR_UNSUPPORTED when the graph has no lane index (weights, self loops). */
+ * pw_graph_index_info).  PW_ERR_UNSUPPORTED when the graph has no lane index (weighted graphs with self loops). */
 int pw_lane_index_export(pw_graph *g, uint32_t *n_in, uint32_t *rev_pos, uint32_t *entries);
 
 /* Dense adjacency in the reference's DenseGraph layout (graph.py:576-580): float64[n, n]
@@ -161,6 +163,34 @@ int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
                        const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
                        int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
                        pw_stats *stats);
+
+/* ---- several GPUs from ONE process -------------------------------------------------------
+ * The reference is one process: `pecanpy` reads a graph, calls simulate_walks() once and writes the result
+ * (src/pecanpy/cli.py:328-351); its parallelism is Numba's thread pool inside _random_walks (pecanpy.py:165, 189).  The
+ * counterpart here is one host thread per device inside one call -- no launcher, no torch.distributed:
+ *   pw_csr_create_multi   builds the handle on devices[0] and REPLICATES it to the other devices (pw_graph_replicate:
+ *                         CSR + the whole per-graph index copied device to device over xGMI, not rebuilt); a device may
+ *                         be named more than once (every entry is a replica with its own streams and scratch).
+ *                         out_handles[n_devices] receives the handles (destroy each with pw_graph_destroy).
+ *   pw_device_mask_to_list  bit d of device_mask set <=> device d; returns how many devices the mask names (negative
+ *                         pw_status when it names one that is not visible) and writes the first `cap` of them.
+ *   pw_simulate_multi     the walk operator over replicas of one graph: the job array is split into contiguous shards
+ *                         (the prange static chunking of pecanpy.py:189), shard i starts in the ONE random stream where
+ *                         the earlier shards' draws end (announced as by pw_count_stream_draws; on directed graphs with
+ *                         dead ends the later shards are walked again with the draws actually consumed), so the matrix
+ *                         is bit-identical to pw_simulate on one handle.  starts: host pointer.  out_on_device = 0: out
+ *                         is host memory, every device copies its rows out itself (its own PCIe link); 1: out is device
+ *                         memory on handles[0]'s GPU, the other devices' rows arrive by peer copies (xGMI).
+ *                         Alias / first-order modes (sequential stream) run on handles[0] alone.  pw_stats: sums; the
+ *                         kernel times are the maximum over the shards (they run side by side).
+ * Thresholds for extend != 0 are set per handle (pw_graph_set_thresholds; a replica inherits what its source had). */
+int pw_graph_replicate(const pw_graph *src, int device, pw_graph **out);
+int pw_device_mask_to_list(uint64_t device_mask, int *devices, int cap);
+int pw_csr_create_multi(const uint32_t *indptr, const uint32_t *indices, const float *data, uint32_t n_nodes, uint32_t nnz,
+                        const int *devices, int n_devices, pw_graph **out_handles);
+int pw_simulate_multi(pw_graph *const *handles, int n_handles, int mode, double p, double q, int extend,
+                      const uint32_t *starts, uint64_t n_jobs, uint32_t walk_length, int has_seed, uint32_t seed,
+                      uint64_t stream_skip, uint32_t *out, int out_on_device, pw_stats *stats);
 
 /* One transition of the on-the-fly modes for a given (cur, prev) -- the operator boundary of the reference's
  * callbacks: move_forward(cur, prev) (pecanpy.py:543-559 / 597-612) with the uniform draw r in [0, 1) supplied by the

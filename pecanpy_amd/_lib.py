@@ -72,6 +72,12 @@ SYMBOLS = {
     "pw_graph_destroy": (None, [C.c_void_p]),
     "pw_simulate": (C.c_int, _SIM_ARGS),
     "pw_simulate_device": (C.c_int, _SIM_ARGS),
+    "pw_graph_replicate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "pw_device_mask_to_list": (C.c_int, [C.c_uint64, C.POINTER(C.c_int), C.c_int]),
+    "pw_csr_create_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "pw_simulate_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_uint64,
+                                    C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(PwStats)]),
     "pw_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_double,
                           _u32p, _u32p]),
     "pw_probs": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p,

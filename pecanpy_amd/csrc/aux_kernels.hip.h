@@ -299,14 +299,15 @@ scan_tile_sums_kernel(uint64_t *tile_sums, uint64_t n_tiles) {
 }
 
 // stream_off[i] = skip + exclusive prefix of draws.  If changed_list != nullptr, jobs whose offset
-// changed are appended to it (repair passes re-run exactly those).  Block-wise repair (pw_simulate_device, sink-heavy
-// directed graphs): only jobs below `limit` are re-addressed and reported -- the others keep the offset they were last
-// walked with -- and *first_mismatch receives the smallest job index, over ALL jobs, whose offset differs.
+// changed are appended to it (repair passes re-run exactly those) and *first_mismatch (optional) receives the smallest such
+// job index.  Block-wise repair (pw_simulate_device, sink-heavy directed graphs): the arrays are those of a WINDOW of the
+// job array (starts / walks / stream_off advanced to its first job, n_jobs = its length, skip = the stream offset of its
+// first job); `job_base` = index of that first job, added to what is reported.
 __global__ void __launch_bounds__(SCAN_BLOCK)
 draws_offsets_kernel(const uint32_t *indptr, const uint32_t *starts, const uint32_t *walks,
                      uint32_t L, uint64_t n_jobs, const uint64_t *tile_sums, uint64_t skip,
                      uint64_t *stream_off, uint32_t *changed_list,
-                     unsigned long long *changed_count, uint64_t limit, unsigned long long *first_mismatch) {
+                     unsigned long long *changed_count, uint64_t job_base, unsigned long long *first_mismatch) {
     __shared__ uint64_t sh[SCAN_BLOCK];
     const int t = threadIdx.x;
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)t * SCAN_ITEMS;
@@ -331,14 +332,12 @@ draws_offsets_kernel(const uint32_t *indptr, const uint32_t *starts, const uint3
         if (i < n_jobs) {
             if (changed_list) {
                 if (stream_off[i] != run && loc[k] != 0) {
-                    if (i < first) first = i;
-                    if (i < limit) {
-                        unsigned long long slot = atomicAdd(changed_count, 1ull);
-                        changed_list[slot] = (uint32_t)i;
-                    }
+                    if (job_base + i < first) first = job_base + i;
+                    unsigned long long slot = atomicAdd(changed_count, 1ull);
+                    changed_list[slot] = (uint32_t)(job_base + i);
                 }
             }
-            if (i < limit) stream_off[i] = run;
+            stream_off[i] = run;
         }
         run += loc[k];
     }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <cmath>
 #include <string>
@@ -46,6 +47,12 @@ constexpr int N_COUNTERS = 48;   // ... [32] parked walks (lane kernel's chain q
 int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
+}
+
+// opt-in switches documented as NAME=1: on when set to a non-zero number (NAME=0 and an empty value leave them off)
+bool env_on(const char *name) {
+    const char *v = getenv(name);
+    return v != nullptr && atoi(v) != 0;
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -98,8 +105,10 @@ struct pw_graph {
     pw::ELine *d_lines = nullptr;                       // lane index (walk_lanes.hip.h): 64-byte edge line per CSR entry; its first 16 bytes
                                                         // {neighbour, common-neighbour count, reverse position, degree} also serve walk_kernel's lazy step
     uint8_t *d_clist = nullptr;                         // lane index: the lists too long for their edge line
-    uint64_t clist_bytes = 0;
+    uint64_t clist_bytes = 0, line_bytes = 0;
+    uint64_t fbits_words = 0, slot_words = 0;           // sizes of d_fbits / d_slots (pw_graph_replicate copies the buffers)
     bool vlines = false;                                // lines[nnz + v]: the line of vertex v's mirrored overflow read
+    bool has_loop = false;                              // the CSR has a self loop (unit graphs: lists fixed up, wave kernel's lazy step off)
     bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
                                                         // built (the wave kernel's lazy step reads it) but the lane kernel is not used
     float *d_tot_e = nullptr, *d_tot_v = nullptr;       // weighted CSR graphs: per-edge / per-vertex normalisers
@@ -332,12 +341,24 @@ struct LaneWorkItems {
     uint64_t segcnt_total = 0;
     std::vector<uint32_t> vm0;      // per vertex: base of its per-segment counts (rows longer than LB_SEG; 0 otherwise)
 };
-static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneWorkItems &w) {
+static void make_lane_work_items(const uint32_t *indptr, const uint32_t *indices, uint32_t n_nodes, LaneWorkItems &w) {
     const uint32_t JCHUNK = 16384;
     w.vm0.assign((size_t)n_nodes + 1, 0u);
     for (uint32_t h = 0; h < n_nodes; h++) {
         const uint32_t d = indptr[h + 1] - indptr[h];
-        if (d < 2) continue;   // one neighbour k: N(h) & N(k) = {k} & N(k) is empty without self loops
+        if (d < 2) {
+            // one neighbour k: N(h) & N(k) = {k} & N(k) is empty -- unless k has a SELF LOOP (then k's position in its own
+            // row is the one common neighbour of h and k; the pair is h's to take only when k -> h is no edge, but an item
+            // too many costs nothing).  (The indices are validated later, on the device: nothing is assumed of them here.)
+            if (d == 1 && indices) {
+                const uint32_t k = indices[indptr[h]];
+                if (k != h && k < n_nodes) {
+                    const uint32_t *row = indices + indptr[k], *end = indices + indptr[k + 1];
+                    if (std::binary_search(row, end, k)) w.small.push_back({h, 0u, 1u, 0u, 0u, d});
+                }
+            }
+            continue;
+        }
         if (d <= (uint32_t)pw::LB_SMALL) { w.small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
         const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
         uint32_t m0 = 0;
@@ -362,7 +383,7 @@ static void make_lane_work_items(const uint32_t *indptr, uint32_t n_nodes, LaneW
         }                                                                                                        \
     } while (0)
 
-static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d_edge_row) {
+static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d_edge_row, bool has_loop) {
     if (!g->nnz) return 0;
     const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
     const bool dbg = getenv("PECANPY_AMD_CREATE_DEBUG") != nullptr;
@@ -447,7 +468,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     uint64_t log_slots = 0;
     bool logged = false;
     const uint64_t nnz_tiles = ((uint64_t)nnz + pw::CL_TILE - 1) / pw::CL_TILE;
-    if (getenv("PECANPY_AMD_INDEX_LOGGED") && !getenv("PECANPY_AMD_INDEX_TWO_PASS")) {
+    if (env_on("PECANPY_AMD_INDEX_LOGGED") && !getenv("PECANPY_AMD_INDEX_TWO_PASS") && !has_loop) {   // (self loops: the two-pass build)
         e = hipMalloc((void **)&d_logoff, sizeof(unsigned long long) * ((size_t)nnz + 1));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(pw::log_tile_sums_kernel, dim3((unsigned)nnz_tiles), dim3(pw::CL_BLOCK), 0, g->stream, g->d_lines, g->d_indptr,
@@ -555,6 +576,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     }
     const uint64_t list_bytes = units * 16 + 64;
     if (units >= 0xffffffffull || list_bytes > free_b - free_b / 8) return drop(0);
+    if (has_loop && max_len != 0xffffffffu) return drop(0);   // (loop_fix_kernel edits stored lists: no partial index with self loops)
     e = hipMalloc((void **)&g->d_clist, list_bytes);
     if (e != hipSuccess) return drop(e == hipErrorOutOfMemory ? 0 : fail(PW_ERR_HIP, std::string("lane index (lists): ") + hipGetErrorString(e)));
     stamp("hipMalloc of the lists");
@@ -567,6 +589,27 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
         if (vlines) hipLaunchKernelGGL(pw::vline_lists_kernel<true>, dim3(vgrid), dim3(256), 0, g->stream, c, g->d_lines, g->d_clist);
     } else
     lists(true);
+    unsigned long long loop_removed = 0;
+    if (has_loop) {   // self loops: prev's own position leaves the lists of the entries whose source has one (walk_lanes.hip.h)
+        uint32_t *d_self = nullptr;
+        unsigned long long *d_removed = nullptr;
+        const size_t words = ((size_t)n_nodes + 31) / 32 + 1;
+        e = hipMalloc((void **)&d_self, sizeof(uint32_t) * words);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_removed, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(d_self, 0, sizeof(uint32_t) * words, g->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_removed, 0, sizeof(unsigned long long), g->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pw::self_loop_bits_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, g->stream, g->d_indptr, g->d_indices, n_nodes, d_self);
+            hipLaunchKernelGGL(pw::loop_fix_kernel, dim3((unsigned)(((uint64_t)nnz + 255) / 256)), dim3(256), 0, g->stream, d_edge_row,
+                               (const uint32_t *)d_self, g->d_lines, g->d_clist, nnz, d_removed);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&loop_removed, d_removed, sizeof(loop_removed), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (d_self) (void)hipFree(d_self);
+        if (d_removed) (void)hipFree(d_removed);
+        if (e != hipSuccess) return drop(fail(PW_ERR_HIP, std::string("lane index (self loops): ") + hipGetErrorString(e)));
+    }
     {   // (logged build: lane_scatter_kernel wrote the pivots of the CSR entries' lists with the lists; the overflow lines are left)
         const uint32_t first = logged ? nnz : 0u;
         if (n_lines > first)
@@ -580,10 +623,11 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     stamp("fill pass + pivots");
     cleanup();
     stamp("hipFree of the scratch");
-    g->n_clist = entries;
+    g->n_clist = entries - loop_removed;
     g->list_max_len = max_len;
     g->vlines = vlines;
     g->clist_bytes = list_bytes;
+    g->line_bytes = line_bytes;
     g->index_bytes += line_bytes + list_bytes;
     return 0;
 }
@@ -611,9 +655,9 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (!monotone) return fail(PW_ERR_INVALID, "indptr not monotone");
     std::thread item_thread;
     try {
-        item_thread = std::thread([&]() { if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items); });
+        item_thread = std::thread([&]() { if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, indices, n_nodes, items); });
     } catch (const std::system_error &) {   // (thread limit of the process: the items are made on this thread)
-        if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, n_nodes, items);
+        if (nnz && !getenv("PECANPY_AMD_NO_LAZY")) make_lane_work_items(indptr, indices, n_nodes, items);
     }
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{item_thread};
     pw_graph *g = new pw_graph();
@@ -712,6 +756,8 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (e == hipSuccess) e = hipMemsetAsync(g->d_slots, 0xff, sizeof(uint64_t) * (trun ? trun : 1), g->stream);
     if (e != hipSuccess) return bail(PW_ERR_NOMEM, std::string("membership index: ") + hipGetErrorString(e));
     g->index_bytes = sizeof(uint64_t) * (frun + trun) + sizeof(uint2) * (uint64_t)nnz + sizeof(uint4) * ((uint64_t)n_nodes + 1);
+    g->fbits_words = frun;
+    g->slot_words = trun;
     INDEX_KERNELS_BEGIN(g);
     hipLaunchKernelGGL(pw::vrec_build_kernel, dim3((n_nodes + 256) / 256), dim3(256), 0, g->stream, g->d_indptr, g->d_foff,
                        g->d_tab_off, n_nodes, g->d_vrec);
@@ -724,12 +770,16 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     if (e != hipSuccess) return bail(PW_ERR_HIP, std::string("membership index build: ") + hipGetErrorString(e));
     stamp("membership index");
-    if (nnz && !has_loop && !getenv("PECANPY_AMD_NO_LAZY")) {   // (weighted graphs too: membership does not depend on the weights)
-        // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel); skipped for
-        // graphs with self loops, where "common neighbour" and the reference's prev handling differ
+    g->has_loop = has_loop;
+    if (nnz && (!has_loop || g->unit) && !getenv("PECANPY_AMD_NO_LAZY")) {   // (weighted graphs too: membership does not depend on the weights)
+        // per-edge records and common-neighbour lists (lane kernel; lazy membership of the wave kernel).  SELF LOOPS (round 6):
+        // unit-weight graphs keep the index -- prev's own position is taken out of the lists of the entries whose source has a
+        // loop (loop_fix_kernel) -- and only the wave kernel's LAZY step, which counts common neighbours while it classifies
+        // keys, stays off for them (launch_wave_walks); weighted graphs with self loops get no index, as before (the
+        // node2vec+ tables pair the two directions' lists entry by entry, and the fix makes their lengths differ).
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
         item_thread.join();
-        rc = build_lane_index(g, items, d_edge_row);
+        rc = build_lane_index(g, items, d_edge_row, has_loop);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
     (void)hipStreamSynchronize(g->stream);
@@ -891,31 +941,122 @@ PW_EXPORT int pw_graph_set_thresholds(pw_graph *g, const float *thr) {
     return PW_OK;
 }
 
-// exclusive prefix of per-job draw counts -> g->stream_off; returns total through *total
-// (block-wise repair: only jobs below `limit` are re-addressed / reported; *first_mismatch = smallest job index of ANY job
-//  whose offset differs from the one it was last walked with, ~0 when the addressing is consistent)
+// ---- in-process multi-device (round 6; SURVEY.md section 8(b)/(e): the reference is ONE process, cli.py:340-351) -----------
+// A replica of a graph handle on another device (or the same one again): the CSR and the whole per-graph index are COPIED
+// device to device (hipMemcpyPeer: xGMI between GPUs) instead of being built again -- RMAT-22: 12 GB at link speed against
+// 170 ms of index kernels + the host passes per device.  Per-(p, q) tables are built by each replica's first call.
+PW_EXPORT int pw_graph_replicate(const pw_graph *src, int device, pw_graph **out) {
+    if (!src || !out) return fail(PW_ERR_INVALID, "null pointer");
+    pw_graph *g = new pw_graph();
+    int rc = graph_common_init(g, device);
+    if (rc) { pw_graph_destroy(g); return rc; }
+    g->kind = src->kind; g->n_nodes = src->n_nodes; g->nnz = src->nnz; g->unit = src->unit; g->max_degree = src->max_degree;
+    g->bits_only = src->bits_only; g->words_per_row = src->words_per_row; g->has_loop = src->has_loop; g->lanes_off = src->lanes_off;
+    g->vlines = src->vlines; g->clist_bytes = src->clist_bytes; g->line_bytes = src->line_bytes; g->fbits_words = src->fbits_words;
+    g->slot_words = src->slot_words; g->n_clist = src->n_clist; g->list_max_len = src->list_max_len; g->index_bytes = src->index_bytes;
+    g->thr_version = src->d_thr ? 1 : 0;
+    const uint64_t n = src->n_nodes, nnz = src->nnz;
+    const bool rows = !src->bits_only;   // (dense graphs created from packed bits have no compressed rows)
+    struct Buf { void **dst; const void *from; uint64_t bytes; };
+    const Buf bufs[] = {
+        {(void **)&g->d_indptr, src->d_indptr, sizeof(uint32_t) * (n + 1)},
+        {(void **)&g->d_indices, src->d_indices, rows ? sizeof(uint32_t) * nnz : 0},
+        {(void **)&g->d_data, src->d_data, (src->kind == 0 ? sizeof(float) : sizeof(double)) * nnz},
+        {(void **)&g->d_thr, src->d_thr, sizeof(float) * n},
+        {(void **)&g->d_adjbits, src->d_adjbits, sizeof(uint64_t) * n * src->words_per_row},
+        {(void **)&g->d_deg, src->d_deg, sizeof(uint32_t) * n},
+        {(void **)&g->d_foff, src->d_foff, sizeof(uint32_t) * (n + 1)},
+        {(void **)&g->d_fbits, src->d_fbits, sizeof(uint64_t) * src->fbits_words},
+        {(void **)&g->d_kf, src->d_kf, sizeof(uint2) * nnz},
+        {(void **)&g->d_tab_off, src->d_tab_off, sizeof(uint64_t) * (n + 1)},
+        {(void **)&g->d_slots, src->d_slots, sizeof(uint64_t) * src->slot_words},
+        {(void **)&g->d_vrec, src->d_vrec, sizeof(uint4) * (n + 1)},
+        {(void **)&g->d_lines, src->d_lines, src->line_bytes},
+        {(void **)&g->d_clist, src->d_clist, src->clist_bytes},
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipSuccess;
+    for (const Buf &b : bufs) {
+        if (!b.from) continue;
+        e = hipMalloc(b.dst, b.bytes ? b.bytes : 8);
+        if (e == hipSuccess && b.bytes) e = hipMemcpyPeerAsync(*b.dst, device, b.from, src->device, b.bytes, g->stream);
+        if (e != hipSuccess) break;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) {
+        pw_graph_destroy(g);
+        return fail(e == hipErrorOutOfMemory ? PW_ERR_NOMEM : PW_ERR_HIP, std::string("pw_graph_replicate: ") + hipGetErrorString(e));
+    }
+    g->create_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g->index_build_ms = 0;     // (nothing was built here)
+    *out = g;
+    return PW_OK;
+}
+
+PW_EXPORT int pw_device_mask_to_list(uint64_t device_mask, int *devices, int cap) {
+    if (!devices && cap > 0) return fail(PW_ERR_INVALID, "null pointer");
+    const int nd = pw_device_count();
+    int k = 0;
+    for (int d = 0; d < 64; d++) {
+        if (!((device_mask >> d) & 1ull)) continue;
+        if (d >= nd) return fail(PW_ERR_INVALID, "device_mask names device " + std::to_string(d) + ", " + std::to_string(nd) + " visible");
+        if (k < cap) devices[k] = d;
+        k++;
+    }
+    return k;
+}
+
+PW_EXPORT int pw_csr_create_multi(const uint32_t *indptr, const uint32_t *indices, const float *data, uint32_t n_nodes, uint32_t nnz,
+                                  const int *devices, int n_devices, pw_graph **out_handles) {
+    if (!devices || !out_handles || n_devices < 1) return fail(PW_ERR_INVALID, "null pointer / no device named");
+    for (int i = 0; i < n_devices; i++) out_handles[i] = nullptr;
+    int rc = pw_csr_create(indptr, indices, data, n_nodes, nnz, devices[0], &out_handles[0]);
+    // the replicas: one helper thread per device, so that the copies run side by side (one xGMI link per destination)
+    std::vector<int> rcs((size_t)n_devices, 0);
+    std::vector<std::string> errs((size_t)n_devices);
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_devices && !rc; i++)
+        th.emplace_back([&, i]() {
+            rcs[i] = pw_graph_replicate(out_handles[0], devices[i], &out_handles[i]);
+            if (rcs[i]) errs[i] = g_err;
+        });
+    for (auto &t : th) t.join();
+    for (int i = 1; i < n_devices && !rc; i++)
+        if (rcs[i]) rc = fail(rcs[i], errs[i]);
+    if (rc)
+        for (int i = 0; i < n_devices; i++) { if (out_handles[i]) pw_graph_destroy(out_handles[i]); out_handles[i] = nullptr; }
+    return rc;
+}
+
+// exclusive prefix of per-job draw counts -> g->stream_off; returns total through *total.
+// Block-wise repair: a WINDOW of the job array -- jobs [j0, j0 + n_jobs), `skip` = the stream offset of job j0 (d_starts / d_walks
+// are the WHOLE arrays; the buffers are sized for n_all jobs) -- so that a round costs O(window), not O(job array).
+// *first_mismatch (optional) = smallest index of a job whose offset differs from the one it was last walked with (~0: none).
 static int compute_offsets(pw_graph *g, const uint32_t *d_starts, const uint32_t *d_walks, uint32_t L,
                            uint64_t n_jobs, uint64_t skip, bool track_changes, uint64_t *total,
-                           uint64_t *n_changed, uint64_t limit = ~0ull, uint64_t *first_mismatch = nullptr) {
+                           uint64_t *n_changed, uint64_t j0 = 0, uint64_t n_all = 0, uint64_t *first_mismatch = nullptr) {
+    if (n_all < j0 + n_jobs) n_all = j0 + n_jobs;
     uint64_t n_tiles = (n_jobs + pw::SCAN_TILE - 1) / pw::SCAN_TILE;
-    if (g->stream_off.ensure(n_jobs + 1)) return PW_ERR_NOMEM;
-    if (g->tile_sums.ensure(n_tiles + 1)) return PW_ERR_NOMEM;
-    if (track_changes && g->changed.ensure(n_jobs)) return PW_ERR_NOMEM;
+    if (g->stream_off.ensure(n_all + 1)) return PW_ERR_NOMEM;
+    if (g->tile_sums.ensure((n_all + pw::SCAN_TILE - 1) / pw::SCAN_TILE + 1)) return PW_ERR_NOMEM;
+    if (track_changes && g->changed.ensure(n_all)) return PW_ERR_NOMEM;
     if (!g->d_hasnbr) {
         const uint32_t words = (g->n_nodes + 31u) / 32u;
         HIP_TRY(hipMalloc((void **)&g->d_hasnbr, sizeof(uint32_t) * (size_t)(words ? words : 1)));
         hipLaunchKernelGGL(pw::has_nbr_bits_kernel, dim3((words + 255) / 256 ? (words + 255) / 256 : 1), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_hasnbr);
     }
+    const uint32_t *w_starts = d_starts + j0;
+    const uint32_t *w_walks = d_walks ? d_walks + j0 * ((uint64_t)L + 2) : nullptr;
     unsigned long long *cc = g->counters.p + 5;
     if (track_changes) HIP_TRY(hipMemsetAsync(cc, 0, sizeof(unsigned long long), g->stream));
     unsigned long long *fm = first_mismatch ? g->counters.p + 14 : nullptr;
     if (fm) HIP_TRY(hipMemsetAsync(fm, 0xff, sizeof(unsigned long long), g->stream));
     hipLaunchKernelGGL(pw::draws_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
-                       g->d_hasnbr, d_starts, d_walks, L, n_jobs, g->tile_sums.p);
+                       g->d_hasnbr, w_starts, w_walks, L, n_jobs, g->tile_sums.p);
     hipLaunchKernelGGL(pw::scan_tile_sums_kernel, dim3(1), dim3(pw::SCAN_BLOCK), 0, g->stream, g->tile_sums.p, n_tiles);
     hipLaunchKernelGGL(pw::draws_offsets_kernel, dim3((unsigned)n_tiles), dim3(pw::SCAN_BLOCK), 0, g->stream,
-                       g->d_hasnbr, d_starts, d_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p,
-                       track_changes ? g->changed.p : nullptr, cc, limit < n_jobs ? limit : n_jobs, fm);
+                       g->d_hasnbr, w_starts, w_walks, L, n_jobs, g->tile_sums.p, skip, g->stream_off.p + j0,
+                       track_changes ? g->changed.p : nullptr, cc, j0, fm);
     HIP_TRY(hipGetLastError());
     uint64_t tot = 0;
     HIP_TRY(hipMemcpyAsync(&tot, g->tile_sums.p + n_tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
@@ -1347,7 +1488,9 @@ static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa);
+    pw::WalkArgs wk = wa;
+    if (g->has_loop) wk.lazy_ok = 0;   // (self loops: the lazy step's key classification would meet prev among the common neighbours)
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wk);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2005,26 +2148,16 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     //    pw_stats.stream_addressing = 1.
     uint64_t dead = h[4];
     const uint64_t max_rounds = 32;
-    const bool nominal_ok = getenv("PECANPY_AMD_NOMINAL_STREAM") != nullptr;
-    const uint64_t blk = getenv("PECANPY_AMD_REPAIR_BLOCK") ? (uint64_t)strtoull(getenv("PECANPY_AMD_REPAIR_BLOCK"), nullptr, 10) : 4096ull;
-    uint64_t limit = ~0ull;          // block-wise phase: jobs below are being settled
-    while (dead > 0) {
-        uint64_t tot2 = 0, n_changed = 0, first = ~0ull;
-        const bool over = st.repair_rounds >= max_rounds;
-        const bool give_up = over && nominal_ok;
-        const bool blockwise = over && !nominal_ok;
-        if (blockwise && limit == ~0ull) limit = 0;     // (the first block-wise round only locates the first inconsistent job)
-        rc = compute_offsets(g, d_starts, give_up ? nullptr : d_out, walk_length, n_jobs, stream_skip, true, &tot2,
-                             &n_changed, blockwise ? limit : ~0ull, blockwise ? &first : nullptr);
+    const bool nominal_ok = env_on("PECANPY_AMD_NOMINAL_STREAM");
+    // (a) whole-array rounds
+    uint64_t first = ~0ull;          // smallest job whose offset changed in the last whole-array round (re-walked since: final)
+    bool consistent = dead == 0;
+    while (!consistent && st.repair_rounds < max_rounds) {
+        uint64_t tot2 = 0, n_changed = 0;
+        rc = compute_offsets(g, d_starts, d_out, walk_length, n_jobs, stream_skip, true, &tot2, &n_changed, 0, n_jobs, &first);
         if (rc) return rc;
-        if (give_up) st.stream_addressing = 1;
-        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu: %llu jobs re-addressed%s\n", (unsigned long long)st.repair_rounds, (unsigned long long)n_changed, give_up ? " (nominal slots)" : (blockwise ? " (block-wise)" : ""));
-        if (blockwise) {
-            if (first == ~0ull) break;                                   // consistent from the first job to the last
-            const uint64_t want = first + (blk ? blk : 1) < n_jobs ? first + (blk ? blk : 1) : n_jobs;
-            if (n_changed == 0) { limit = want; continue; }              // (nothing inside the window: move it, look again)
-            if (want > limit) limit = want;
-        } else if (n_changed == 0) break;
+        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu: %llu jobs re-addressed\n", (unsigned long long)st.repair_rounds, (unsigned long long)n_changed);
+        if (n_changed == 0) { consistent = true; break; }
         st.repair_rounds++;
         wa.job_list = g->changed.p;
         wa.n_list = n_changed;
@@ -2036,7 +2169,83 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
         HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
         st.walk_kernel_ms += ms;
         st.walk_kernel_launches++;
-        if (give_up) break;
+    }
+    if (!consistent && nominal_ok) {
+        // (b) opt-in: every walk owns a fixed slot of walk_length draws
+        uint64_t tot2 = 0, n_changed = 0;
+        rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, true, &tot2, &n_changed);
+        if (rc) return rc;
+        st.stream_addressing = 1;
+        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] %llu jobs re-addressed (nominal slots)\n", (unsigned long long)n_changed);
+        if (n_changed) {
+            st.repair_rounds++;
+            wa.job_list = g->changed.p;
+            wa.n_list = n_changed;
+            HIP_TRY(hipEventRecord(g->ev[2], g->stream));
+            rc = launch_walks(g, wa, extend != 0, &redo_total);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(g->ev[3], g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
+            st.walk_kernel_ms += ms;
+            st.walk_kernel_launches++;
+        }
+    } else if (!consistent) {
+        // (c) BLOCK-WISE, exact.  Invariant: every job below `first` is final and off_first is the stream offset of job `first`.
+        // A round addresses the WINDOW [first, first + blk) from off_first (three small launches over the window, not the
+        // array), re-walks the jobs of the window whose offset differs from the one they were last walked with, and moves
+        // `first` to the first of them -- that job has now been walked with its final offset, everything before it was
+        // consistent -- or to the end of a window in which nothing differed.  At least one job per round, O(window) work per
+        // round; the window grows while rounds clear most of it and shrinks while they do not.  A time budget bounds the
+        // whole (PECANPY_AMD_REPAIR_SECONDS, default 600; 0: none): the error names the alternatives.
+        uint64_t blk = 4096;
+        const char *blk_env = getenv("PECANPY_AMD_REPAIR_BLOCK");
+        if (blk_env) blk = (uint64_t)strtoull(blk_env, nullptr, 10);
+        if (blk < 1) blk = 1;
+        const double budget_s = getenv("PECANPY_AMD_REPAIR_SECONDS") ? atof(getenv("PECANPY_AMD_REPAIR_SECONDS")) : 600.0;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_begin = now();
+        if (first == ~0ull || first >= n_jobs) first = 0;
+        uint64_t off_first = stream_skip;
+        if (first) HIP_TRY(hipMemcpy(&off_first, g->stream_off.p + first, sizeof(uint64_t), hipMemcpyDeviceToHost));   // (last whole-array scan)
+        while (first < n_jobs) {
+            const uint64_t n_win = first + blk < n_jobs ? blk : n_jobs - first;
+            uint64_t tot2 = 0, n_changed = 0, fm = ~0ull;
+            rc = compute_offsets(g, d_starts, d_out, walk_length, n_win, off_first, true, &tot2, &n_changed, first, n_jobs, &fm);
+            if (rc) return rc;
+            if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[repair] round %llu (block-wise): window [%llu, +%llu): %llu jobs re-addressed\n",
+                                                   (unsigned long long)st.repair_rounds, (unsigned long long)first, (unsigned long long)n_win, (unsigned long long)n_changed);
+            if (n_changed == 0) {           // the whole window is consistent: final
+                first += n_win;
+                off_first += tot2;
+                if (!blk_env && blk < (1ull << 20)) blk *= 2;
+                continue;
+            }
+            st.repair_rounds++;
+            wa.job_list = g->changed.p;
+            wa.n_list = n_changed;
+            HIP_TRY(hipEventRecord(g->ev[2], g->stream));
+            rc = launch_walks(g, wa, extend != 0, &redo_total);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(g->ev[3], g->stream));
+            HIP_TRY(hipMemcpyAsync(&off_first, g->stream_off.p + fm, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            HIP_TRY(hipEventElapsedTime(&ms, g->ev[2], g->ev[3]));
+            st.walk_kernel_ms += ms;
+            st.walk_kernel_launches++;
+            if (!blk_env) {
+                const uint64_t adv = fm - first;
+                if (adv >= n_win / 2 && blk < (1ull << 20)) blk *= 2;
+                else if (adv < n_win / 16 && blk > 256) blk /= 2;
+            }
+            first = fm;                     // (walked with its final offset just now; the next window starts on it)
+            if (budget_s > 0 && now() - t_begin > budget_s)
+                return fail(PW_ERR_UNSUPPORTED, "dead-end repair: " + std::to_string(first) + " of " + std::to_string(n_jobs) + " walks final after " +
+                                                std::to_string((long long)budget_s) + " s of block-wise re-addressing (a directed graph full of sinks makes the "
+                                                "reference's single random stream sequential, pecanpy.py:198-206).  PECANPY_AMD_REPAIR_SECONDS=0 lifts the "
+                                                "limit; PECANPY_AMD_NOMINAL_STREAM=1 gives every walk a fixed slot of the stream instead (seeded, not the "
+                                                "reference's assignment)");
+        }
     }
     if (st.repair_rounds) {
         // statistics of the final, self-consistent matrix
@@ -2225,7 +2434,7 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     // (nominal addressing -- the opt-in fallback of the dead-end repair -- must be decided ONCE for the whole array: a part that
     //  fell back would own slots up to skip + nominal while the next part started at skip + actual; exact addressing, the
     //  default, makes the walks those of one call whatever the split)
-    if (getenv("PECANPY_AMD_NOMINAL_STREAM")) n_parts = 1;
+    if (env_on("PECANPY_AMD_NOMINAL_STREAM")) n_parts = 1;
     if (!has_seed && n_parts > 1) { seed = os_seed(); has_seed = 1; }   // (every part walks the same stream)
     pw_stats total;
     memset(&total, 0, sizeof(total));
@@ -2307,6 +2516,139 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     if (dbg) fprintf(stderr, "[pw_simulate] alloc %.1f ms, starts in %.1f, walks %.1f, matrix out %.1f, free %.1f\n", (t1 - t0) * 1e3,
                      (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
     return rc;
+}
+
+// ---- the walk operator over SEVERAL handles (replicas of one graph, pw_csr_create_multi), one host thread per handle -----------
+// The job array is split into contiguous shards (the walks are independent, the graph is replicated);
+// shard i is addressed into the ONE random stream by the draws the earlier shards consume -- announced by
+// pw_count_stream_draws' rule (exact on undirected graphs) and, when dead ends made a shard consume fewer (directed graphs),
+// corrected by walking the later shards again with the draws actually consumed: the matrix is that of one pw_simulate call
+// whatever the number of handles.  out: host memory (out_on_device = 0: every device copies its rows out itself, one PCIe
+// link each) or device memory of handles[0]'s GPU (1: the other devices' rows land there by peer copies over xGMI).
+PW_EXPORT int pw_simulate_multi(pw_graph *const *handles, int n_handles, int mode, double p, double q, int extend,
+                                const uint32_t *starts, uint64_t n_jobs, uint32_t walk_length, int has_seed, uint32_t seed,
+                                uint64_t stream_skip, uint32_t *out, int out_on_device, pw_stats *stats) {
+    if (!handles || n_handles < 1 || (n_jobs && (!starts || !out))) return fail(PW_ERR_INVALID, "null pointer / no handle");
+    for (int i = 0; i < n_handles; i++)
+        if (!handles[i]) return fail(PW_ERR_INVALID, "null handle");
+    for (int i = 1; i < n_handles; i++)
+        if (handles[i]->n_nodes != handles[0]->n_nodes || handles[i]->nnz != handles[0]->nnz || handles[i]->kind != handles[0]->kind)
+            return fail(PW_ERR_INVALID, "pw_simulate_multi: the handles are not replicas of one graph");
+    if (!has_seed) { seed = os_seed(); has_seed = 1; }   // (every shard walks the same stream)
+    const size_t W = (size_t)walk_length + 2;
+    int n_sh = n_handles;
+    if (mode >= PW_MODE_PRECOMP || n_jobs < (uint64_t)n_handles * 64) n_sh = 1;   // (alias modes: a sequential stream; tiny arrays: one device)
+    if (n_sh == 1 && !out_on_device) return pw_simulate(handles[0], mode, p, q, extend, starts, n_jobs, walk_length, has_seed, seed, stream_skip, out, stats);
+    struct Shard {
+        uint64_t lo = 0, hi = 0, skip = 0, nominal = 0;
+        uint32_t *d_starts = nullptr, *d_tmp = nullptr;
+        pw_stats st;
+        int rc = 0;
+        std::string err;
+        bool final_ = false;
+    };
+    std::vector<Shard> sh((size_t)n_sh);
+    for (int i = 0; i < n_sh; i++) {
+        sh[i].lo = (uint64_t)i * n_jobs / n_sh;
+        sh[i].hi = (uint64_t)(i + 1) * n_jobs / n_sh;
+        memset(&sh[i].st, 0, sizeof(pw_stats));
+    }
+    auto for_shards = [&](const std::function<void(int)> &fn, int first) {
+        std::vector<std::thread> th;
+        for (int i = first + 1; i < n_sh; i++) {
+            try { th.emplace_back(fn, i); } catch (const std::system_error &) { fn(i); }
+        }
+        fn(first);
+        for (auto &t : th) t.join();
+    };
+    // 1. the draws every shard announces (device resident copies of the starts for the device-output form)
+    for_shards([&](int i) {
+        Shard &S = sh[i];
+        pw_graph *g = handles[i];
+        if (S.hi == S.lo) return;
+        if (mode >= PW_MODE_PRECOMP) return;
+        S.rc = pw_count_stream_draws(g, starts + S.lo, S.hi - S.lo, walk_length, &S.nominal);
+        if (S.rc) S.err = g_err;
+    }, 0);
+    for (auto &S : sh) if (S.rc) return fail(S.rc, S.err);
+    { uint64_t run = stream_skip; for (auto &S : sh) { S.skip = run; run += S.nominal; } }
+    // 2. walk; shards whose address turns out wrong (an earlier shard consumed fewer draws: dead ends) walk again
+    int first_open = 0;
+    for (int round = 0; round <= n_sh && first_open < n_sh; round++) {
+        for_shards([&](int i) {
+            Shard &S = sh[i];
+            pw_graph *g = handles[i];
+            if (S.hi == S.lo) return;
+            const uint64_t n = S.hi - S.lo;
+            if (!out_on_device) {
+                S.rc = pw_simulate(g, mode, p, q, extend, starts + S.lo, n, walk_length, 1, seed, S.skip, out + S.lo * W, &S.st);
+                if (S.rc) S.err = g_err;
+                return;
+            }
+            // device output on handles[0]'s GPU: walk into local memory, then one peer copy (in place when it IS that GPU)
+            hipError_t e = hipSetDevice(g->device);
+            const bool local = g->device == handles[0]->device;
+            if (e == hipSuccess && !S.d_starts) {
+                e = hipMalloc((void **)&S.d_starts, sizeof(uint32_t) * n);
+                if (e == hipSuccess) e = hipMemcpy(S.d_starts, starts + S.lo, sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+                if (e == hipSuccess && !local) e = hipMalloc((void **)&S.d_tmp, sizeof(uint32_t) * n * W);
+            }
+            if (e != hipSuccess) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi: ") + hipGetErrorString(e); return; }
+            uint32_t *dst = local ? out + S.lo * W : S.d_tmp;
+            S.rc = pw_simulate_device(g, mode, p, q, extend, S.d_starts, n, walk_length, 1, seed, S.skip, dst, &S.st);
+            if (S.rc) { S.err = g_err; return; }
+            if (!local) {
+                e = hipMemcpyPeerAsync(out + S.lo * W, handles[0]->device, S.d_tmp, g->device, sizeof(uint32_t) * n * W, g->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+                if (e != hipSuccess) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi (peer copy): ") + hipGetErrorString(e); }
+            }
+        }, first_open);
+        int bad = -1;
+        for (int i = first_open; i < n_sh; i++) if (sh[i].rc) { bad = i; break; }
+        if (bad >= 0) break;
+        // shard i is final once every earlier shard is and its address equals what they consumed
+        uint64_t run = sh[first_open].skip;
+        int i = first_open;
+        for (; i < n_sh; i++) {
+            if (sh[i].skip != run) break;
+            sh[i].final_ = true;
+            run += sh[i].st.total_steps;
+        }
+        first_open = i;
+        for (int j = i; j < n_sh; j++) { sh[j].skip = run; run += sh[j].st.total_steps; }   // (their own counts as the next estimate)
+    }
+    int rc = 0;
+    for (auto &S : sh) {
+        if (S.rc && !rc) rc = fail(S.rc, S.err);
+    }
+    for (int i = 0; i < n_sh; i++) {
+        if (sh[i].d_starts || sh[i].d_tmp) {
+            (void)hipSetDevice(handles[i]->device);
+            if (sh[i].d_starts) (void)hipFree(sh[i].d_starts);
+            if (sh[i].d_tmp) (void)hipFree(sh[i].d_tmp);
+        }
+    }
+    if (!rc && first_open < n_sh) rc = fail(PW_ERR_HIP, "pw_simulate_multi: shard addressing did not settle");
+    if (rc) return rc;
+    if (stats) {
+        pw_stats total = sh[0].st;
+        for (int i = 1; i < n_sh; i++) {
+            const pw_stats &st = sh[i].st;
+            total.total_steps += st.total_steps; total.overflow_reads += st.overflow_reads; total.clamped_reads += st.clamped_reads;
+            total.dead_end_walks += st.dead_end_walks; total.repair_rounds += st.repair_rounds;
+            total.walk_kernel_ms = std::max(total.walk_kernel_ms, st.walk_kernel_ms);     // (the shards run side by side)
+            total.rng_kernel_ms = std::max(total.rng_kernel_ms, st.rng_kernel_ms);
+            total.lane_kernel_ms = std::max(total.lane_kernel_ms, st.lane_kernel_ms);
+            total.walk_kernel_launches += st.walk_kernel_launches;
+            total.stream_addressing |= st.stream_addressing; total.lane_rounds = std::max(total.lane_rounds, st.lane_rounds);
+            total.redo_walks += st.redo_walks; total.list_entries_read += st.list_entries_read; total.ambiguous_steps += st.ambiguous_steps;
+            total.wave_chain_steps += st.wave_chain_steps; total.param_index_ms = std::max(total.param_index_ms, st.param_index_ms);
+            total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch; total.verify_dropped += st.verify_dropped;
+            total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
+        }
+        *stats = total;
+    }
+    return PW_OK;
 }
 
 PW_EXPORT int pw_mt_random_sample(uint32_t seed, uint64_t offset, uint64_t n, double *out) {

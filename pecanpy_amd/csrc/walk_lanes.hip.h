@@ -1446,6 +1446,11 @@ wlist_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const float *__res
     const double inv_q = 1.0 / q;
     const float thr_cur = EXTEND ? g.thr[v] : 0.0f;
     double run = 0.0;
+    // WeightedRow::margin (seqscan.h) relies on every difference below having the sign of q - 1 (value >= base for q >= 1:
+    // rounding is monotone).  That holds for the positive finite weights the reference's reader keeps (graph.py:181-215); an
+    // entry that breaks it (negative or NaN weights handed in through pw_csr_create) gets no table: its steps take the exact scan.
+    const bool want_pos = q >= 1.0;
+    bool sign_ok = true;
     for (uint32_t j = 0; j < n_in; j++) {
         const uint32_t pos = P.at(j);
         const float w = data[s_v + pos];
@@ -1459,9 +1464,12 @@ wlist_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const float *__res
                 val = Arith<float>::bias_mul(w, alpha);
             }
         }
-        run += (double)val - (double)wb[s_v + pos];
+        const double diff = (double)val - (double)wb[s_v + pos];
+        if (want_pos ? !(diff >= 0.0) : !(diff <= 0.0)) sign_ok = false;
+        run += diff;
         dl[off + j] = run;
     }
+    if (!sign_ok) wl_off[e] = ~0ull;
 }
 
 // ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------
@@ -1619,7 +1627,9 @@ vline_lists_kernel(CsrDev g, ELine *lines, uint8_t *clist) {
         const bool valid = i < d_v;
         const uint32_t w = valid ? g.indices[s_v + i] : 0u;
         const uint32_t gpos = adj_lookup(g.slots + tb, tmask, w, valid);
-        const bool hit = valid && gpos != NOT_FOUND;
+        // (w == v -- a self loop at v that x0 is adjacent to -- is prev's own position in row x0: the reference takes prev out
+        //  of the common neighbours, sparse_rw.py:79-87; see loop_fix_kernel)
+        const bool hit = valid && gpos != NOT_FOUND && w != v;
         const uint64_t m = ballot(hit);
         if (FILL && hit) {
             const uint32_t rk = run + (uint32_t)__popcll(m & lane_lt);
@@ -1683,7 +1693,9 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             const uint32_t e2 = s_h + j;
             const uint4 r0 = *(const uint4 *)(a.lines + e2);          // { k, n_in, position of h in row k, degree(k) }
             const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);    // { indptr[k], coff }
-            const uint32_t k = r0.x, rev = r0.z, d_k = r0.w, s_k = r1.x;
+            // (a SELF LOOP h -> h is a pair of its own: its list -- positions in row h of N(h) & N(h) -- has one direction only,
+            //  so it is written like an entry without a reverse edge)
+            const uint32_t k = r0.x, rev = r0.x == h ? NOT_FOUND : r0.z, d_k = r0.w, s_k = r1.x;
             const bool mine = rev == NOT_FOUND || d_h > d_k || (d_h == d_k && h > k);
             // single-segment rows: the COUNT pass already wrote the lists that fit their lines (below) -- nothing to fill.
             // "Fits its line" includes the row of k being narrow (uint16 positions): a DIRECTED entry h -> k into a row of
@@ -1769,7 +1781,7 @@ lane_lists_kernel(LaneBuildArgs a, const LaneBuildItem *__restrict__ items) {
             const uint32_t e2 = s_h + jq;
             const uint4 r0 = *(const uint4 *)(a.lines + e2);
             const uint2 r1 = *((const uint2 *)(a.lines + e2) + 2);
-            const uint32_t rev = r0.z, d_k = r0.w, s_k = r1.x;
+            const uint32_t rev = r0.x == h ? NOT_FOUND : r0.z, d_k = r0.w, s_k = r1.x;   // (self loop: as above)
             uint32_t run = 0;
             uint8_t *p2 = nullptr, *p1 = nullptr;
             bool k_narrow = true;
@@ -1999,6 +2011,60 @@ lane_scatter_kernel(LaneBuildArgs a, const uint32_t *__restrict__ edge_row, cons
             }
         }
     }
+}
+
+// ---- SELF LOOPS (round 6) --------------------------------------------------------------------------------------------
+// The reference accepts them (graph.py:238-268: no check).  For a walker that stands on v having come from u the reference
+// classes are disjoint: prev's own position in row v gets 1/p and is taken OUT of the common neighbours
+// (`non_com_nbr[prev_ptr] = False; ... unnormalized_probs[prev_ptr] /= p`, sparse_rw.py:79-87) -- but when u has a self loop
+// (u in N(u)) and v -> u is an edge, u IS a member of N(u) & N(v), and the symmetric intersection above puts its position
+// into the list of (u -> v).  Every consumer of a list (lane_decide / lane_tight / lane_chain, the float64-bounded forms, the
+// wave kernel's mask scatter) assumes the three classes disjoint, so the build REMOVES that one entry afterwards:
+// list(u -> v) = positions in row v of (N(u) & N(v)) \ {u}.  A self loop at v needs nothing: v's position in its own row is
+// an ordinary common neighbour whenever v is adjacent to prev.  selfbits: bit u = vertex u has a self loop.
+__global__ void __launch_bounds__(256)
+self_loop_bits_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices, uint32_t n_nodes, uint32_t *bits) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    const uint32_t s0 = indptr[v], d = indptr[v + 1] - s0;
+    const uint32_t i = lower_bound_u32(indices + s0, d, v);
+    if (i < d && indices[s0 + i] == v) atomicOr(bits + (v >> 5), 1u << (v & 31u));
+}
+// One thread per CSR entry e = (u -> v) whose source has a self loop and whose reverse entry exists: the entry rev_pos leaves
+// the list, the tail moves up, n_in drops by one (a list that now fits the line moves into it).  After the FILL pass, before
+// the pivots.  removed[0] counts the entries taken out.  (Lists must be stored: a partial index is not built for such graphs.)
+__global__ void __launch_bounds__(256)
+loop_fix_kernel(const uint32_t *__restrict__ edge_row, const uint32_t *__restrict__ selfbits, ELine *lines, uint8_t *clist, uint32_t nnz,
+                unsigned long long *removed) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const uint32_t u = edge_row[e];
+    if (!((selfbits[u >> 5] >> (u & 31u)) & 1u)) return;
+    const uint4 r0 = *(const uint4 *)(lines + e);
+    const uint32_t n_in = r0.y, rev = r0.z, d_v = r0.w;
+    if (rev == NOT_FOUND || n_in == 0u) return;
+    const uint32_t coff = lines[e].coff;
+    const bool narrow = d_v <= 65536u, old_inl = narrow && n_in <= EL_INLINE;
+    if (!old_inl && coff == EL_NO_LIST) return;
+    uint8_t *src = old_inl ? (uint8_t *)(lines + e) + 24 : clist + (uint64_t)coff * 16u;
+    auto get = [&](uint32_t i) -> uint32_t { return narrow ? (uint32_t)((const uint16_t *)src)[i] : ((const uint32_t *)src)[i]; };
+    uint32_t lo = 0, hi = n_in;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (get(mid) < rev) lo = mid + 1u; else hi = mid; }
+    if (lo >= n_in || get(lo) != rev) return;             // (prev is not among the common neighbours: nothing to take out)
+    const uint32_t n = n_in - 1u;
+    const bool new_inl = narrow && n <= EL_INLINE;
+    if (!old_inl && new_inl) {                            // 21 -> 20 entries: the list moves into its line
+        uint16_t *dst = (uint16_t *)((uint8_t *)(lines + e) + 24);
+        for (uint32_t i = 0, o = 0; i < n_in; i++)
+            if (i != lo) dst[o++] = (uint16_t)get(i);
+    } else {
+        for (uint32_t i = lo; i < n; i++) {
+            if (narrow) ((uint16_t *)src)[i] = ((const uint16_t *)src)[i + 1u];
+            else ((uint32_t *)src)[i] = ((const uint32_t *)src)[i + 1u];
+        }
+    }
+    lines[e].n_in = n;
+    atomicAdd(removed, 1ull);
 }
 
 // 16-byte units the list of entry e takes in the overflow array (0: it lives inside the edge line)

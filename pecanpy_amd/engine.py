@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from ._lib import MODE_IDS, PwError, PwStats
 
-__all__ = ["WalkEngine", "shard_bounds", "auto_rank0_share", "tapered_bounds", "PwError"]
+__all__ = ["WalkEngine", "MultiWalkEngine", "visible_devices", "shard_bounds", "auto_rank0_share", "tapered_bounds", "PwError"]
 
 
 def _np_ptr(a):
@@ -241,3 +241,118 @@ class WalkEngine:
         _lib.check(self._lib.pw_count_stream_draws(self._h, _np_ptr(starts), starts.size,
                                                    int(walk_length), C.byref(n)))
         return int(n.value)
+
+
+def visible_devices(spec=None):
+    """Device list from a spec: ``None`` / ``"all"`` = every visible GPU, an int = that many (0 = all), a bit mask given as
+    ``"mask:0x0f"``, or a comma list ``"0,1,2"`` (a device may be named twice: every entry is a replica)."""
+    lib = _lib.load()
+    n = int(lib.pw_device_count())
+    if spec is None or spec == "all" or spec == 0:
+        return list(range(n))
+    if isinstance(spec, int):
+        return list(range(min(spec, n)))
+    if isinstance(spec, str) and spec.startswith("mask:"):
+        buf = (C.c_int * 64)()
+        k = lib.pw_device_mask_to_list(int(spec[5:], 0), buf, 64)
+        if k < 0:
+            _lib.check(k)
+        return [int(buf[i]) for i in range(k)]
+    if isinstance(spec, str):
+        return [int(t) for t in spec.split(",") if t.strip() != ""]
+    return [int(d) for d in spec]
+
+
+class MultiWalkEngine:
+    """Replicas of one graph on several GPUs, driven from THIS process by one host thread per device inside one C-ABI call
+    (``pw_csr_create_multi`` / ``pw_simulate_multi``): what the reference's single process with its Numba thread pool is to
+    the CPU (src/pecanpy/cli.py:340-351, pecanpy.py:165-189).  The index is built once and copied device to device.  The
+    walk matrix equals a one-device run bit for bit (one random stream, shards addressed by the draws of the earlier ones)."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self._lib = self.engines[0]._lib
+        self.kind = self.engines[0].kind
+        self.n_nodes = self.engines[0].n_nodes
+        self.devices = [e.device for e in self.engines]
+        self.last_stats = None
+
+    @classmethod
+    def from_csr(cls, indptr, indices, data=None, devices=None):
+        lib = _lib.load()
+        devices = visible_devices(devices)
+        if not devices:
+            raise PwError("no HIP device visible (libpecanpy_amd needs a GPU; there is no CPU fallback)")
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=np.float32)
+        dev = (C.c_int * len(devices))(*devices)
+        hs = (C.c_void_p * len(devices))()
+        _lib.check(lib.pw_csr_create_multi(_np_ptr(indptr), _np_ptr(indices), _np_ptr(data), indptr.size - 1, indices.size,
+                                           dev, len(devices), hs))
+        engines = []
+        for h, d in zip(hs, devices):
+            eng = WalkEngine(C.c_void_p(h), lib, "csr", indptr.size - 1, int(d))
+            eng._max_degree = int(np.diff(indptr.astype(np.int64)).max()) if indptr.size > 1 else 0
+            eng._nnz = int(indices.size)
+            engines.append(eng)
+        return cls(engines)
+
+    @classmethod
+    def from_engine(cls, engine, devices):
+        """Replicate an existing one-device engine onto ``devices`` (entries equal to its own device become replicas too)."""
+        lib = engine._lib
+        engines = [engine]
+        for d in list(devices)[1:]:
+            h = C.c_void_p()
+            _lib.check(lib.pw_graph_replicate(engine._h, int(d), C.byref(h)))
+            rep = WalkEngine(h, lib, engine.kind, engine.n_nodes, int(d))
+            rep._max_degree, rep._nnz = engine._max_degree, engine._nnz
+            engines.append(rep)
+        return cls(engines)
+
+    def set_thresholds(self, thr):
+        for e in self.engines:
+            e.set_thresholds(thr)
+
+    def index_info(self):
+        return self.engines[0].index_info()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    def _handles(self):
+        return (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+
+    def simulate(self, mode, p, q, extend, starts, walk_length, seed=None, stream_skip=0):
+        """Host-buffer variant: ``uint32[n_jobs, walk_length + 2]`` (NumPy), every device writing its own rows."""
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        out = np.empty((starts.size, walk_length + 2), dtype=np.uint32)
+        st = PwStats()
+        _lib.check(self._lib.pw_simulate_multi(
+            self._handles(), len(self.engines), MODE_IDS[mode], float(p), float(q), int(bool(extend)), _np_ptr(starts),
+            starts.size, int(walk_length), int(seed is not None), int(seed or 0) & 0xFFFFFFFF, int(stream_skip),
+            _np_ptr(out), 0, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out
+
+    def simulate_to_device(self, mode, p, q, extend, starts, walk_length, seed=None, stream_skip=0, out=None):
+        """The matrix assembled in the memory of the FIRST device (torch int32 tensor): the other devices' rows arrive by
+        peer copies over xGMI ("gathered once at the end", BASELINE north star) -- without RCCL, from one process."""
+        import torch
+
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        dev = torch.device("cuda", self.devices[0])
+        if out is None:
+            out = torch.empty((starts.size, walk_length + 2), dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        st = PwStats()
+        _lib.check(self._lib.pw_simulate_multi(
+            self._handles(), len(self.engines), MODE_IDS[mode], float(p), float(q), int(bool(extend)), _np_ptr(starts),
+            starts.size, int(walk_length), int(seed is not None), int(seed or 0) & 0xFFFFFFFF, int(stream_skip),
+            C.c_void_p(out.data_ptr()), 1, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out

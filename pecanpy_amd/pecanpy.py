@@ -71,6 +71,7 @@ class Base(BaseGraph):
         self.random_state = random_state
         self._preprocessed = False
         self._engine = None
+        self._multi = None       # replicas on the other GPUs of this process (_multi_engine)
         self._engine_key = None
         self._thr_key = None
         self._run_seed = None
@@ -94,15 +95,57 @@ class Base(BaseGraph):
     def _get_engine(self):
         key = (self._graph_key(), self._device_index())
         if self._engine is None or self._engine_key != key:
+            if self._multi is not None:
+                for rep in self._multi.engines[1:]:
+                    rep.close()
+                self._multi = None
             if self._engine is not None:
                 self._engine.close()
             self._engine = self._make_engine(self._device_index())
             self._engine_key = key
             self._thr_key = None
         if self.extend and self._thr_key != (self.gamma,):   # gamma may change between calls
-            self._engine.set_thresholds(self.get_noise_thresholds())
+            thr = self.get_noise_thresholds()
+            self._engine.set_thresholds(thr)
+            if self._multi is not None:
+                for rep in self._multi.engines[1:]:
+                    rep.set_thresholds(thr)
             self._thr_key = (self.gamma,)
         return self._engine
+
+    #: nominal steps (jobs x walk_length) from which a call spreads over every visible GPU when PECANPY_AMD_DEVICES is unset
+    MULTI_DEVICE_MIN_STEPS = 200_000_000
+
+    def _multi_engine(self, n_jobs, walk_length):
+        """In-process multi-GPU (round 6): replicas of the engine's graph on the other visible devices, driven by one host
+        thread per device inside ONE C-ABI call (``pw_simulate_multi``) -- what the reference's single process with its Numba
+        thread pool is on the CPU (cli.py:340-351).  ``PECANPY_AMD_DEVICES`` = ``all`` | a count | ``0,1,2`` | ``mask:0x0f``;
+        unset: every visible GPU once the call is large enough to pay for the replication.  ``None``: one device."""
+        import os
+
+        if self._mode not in ("SparseOTF", "DenseOTF") or self.device is not None or "LOCAL_RANK" in os.environ:
+            return None
+        if self._engine is None or self._engine.kind != "csr":
+            return None
+        spec = os.environ.get("PECANPY_AMD_DEVICES")
+        from .engine import MultiWalkEngine, visible_devices
+
+        if spec is None:
+            if n_jobs * walk_length < self.MULTI_DEVICE_MIN_STEPS:
+                return None
+            devices = visible_devices(None)
+        else:
+            devices = visible_devices(int(spec) if spec.strip().isdigit() else spec.strip())
+        if len(devices) < 2:
+            return None
+        if devices[0] != self._engine.device:
+            devices = [self._engine.device] + [d for d in devices if d != self._engine.device]
+        if self._multi is None or self._multi.devices != devices:
+            if self._multi is not None:
+                for rep in self._multi.engines[1:]:
+                    rep.close()
+            self._multi = MultiWalkEngine.from_engine(self._engine, devices)
+        return self._multi
 
     # ---- reference API ---------------------------------------------------------------------
     def _map_walk(self, walk_idx_ary):
@@ -184,6 +227,9 @@ class Base(BaseGraph):
                     f"{self._mode} draws a variable number of random words per step; its seeded "
                     "stream cannot be sharded across GPUs -- run it in a single process")
             return self._random_walks_sharded(eng, starts, walk_length, seed, gather)
+        multi = self._multi_engine(starts.size, walk_length)
+        if multi is not None:
+            eng = multi
         mat = eng.simulate(self._mode, self.p, self.q, self.extend, starts, walk_length, seed=seed)
         self._note_stats(eng.last_stats)
         return mat

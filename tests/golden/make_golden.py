@@ -225,6 +225,36 @@ def main():
         walk_case(f"{tag}_SparseOTF_n2vplus_g0.0_p0.7_q0.4", "SparseOTF", wg.indptr, wg.indices, wg.data,
                   0.7, 0.4, True, 0.0, 13, 4, 30, n_prob_samples=30)
 
+    # (vi) self loops (round 6; the reference accepts them, graph.py:238-268): a walker may step u -> u, and a looped prev
+    #      is a member of N(prev) & N(cur) that the reference takes out again (sparse_rw.py:79-87, dense_rw.py:57-60)
+    rng = np.random.default_rng(77)
+    n = 150
+    adj = np.triu(rng.random((n, n)) < 0.08, 1)
+    adj = (adj | adj.T).astype(float)
+    adj[np.arange(0, n, 4), np.arange(0, n, 4)] = 1.0          # every 4th vertex has a self loop
+    hub = 7                                                     # ... and a looped hub adjacent to half of the graph
+    adj[hub, ::2] = 1.0
+    adj[::2, hub] = 1.0
+    adj[hub, hub] = 1.0
+    lg = ref.SparseOTF.from_mat(adj, [str(i) for i in range(n)])
+    assert (lg.indices[lg.indptr[hub]:lg.indptr[hub + 1]] == hub).any()
+    for mode in ["SparseOTF", "DenseOTF"]:
+        walk_case(f"selfloop_{mode}_p0.5_q2", mode, lg.indptr, lg.indices, lg.data, 0.5, 2, False, 0, 21, 4, 30,
+                  n_prob_samples=40)
+    walk_case("selfloop_SparseOTF_p0.3_q1.7", "SparseOTF", lg.indptr, lg.indices, lg.data, 0.3, 1.7, False, 0, 22, 3, 30,
+              n_prob_samples=40)
+
+    # (vi-b) a sink-heavy directed graph (the dead-end bookkeeping of App. A.6 pinned at more than six nodes):
+    #        400 vertices, 40 % without out-edges, so that most walks end early and shift the stream of every later walk
+    rng = np.random.default_rng(78)
+    n = 400
+    dm = (rng.random((n, n)) < 0.02).astype(float)
+    np.fill_diagonal(dm, 0.0)
+    dm[rng.random(n) < 0.4, :] = 0.0
+    sg = ref.SparseOTF.from_mat(dm, [str(i) for i in range(n)])
+    walk_case("sinkheavy_SparseOTF_p0.5_q2", "SparseOTF", sg.indptr, sg.indices, sg.data, 0.5, 2, False, 0, 9, 4, 20)
+    walk_case("sinkheavy_SparseOTF_p0.3_q1.7", "SparseOTF", sg.indptr, sg.indices, sg.data, 0.3, 1.7, False, 0, 10, 3, 20)
+
     # (vii) MT19937 known answers straight from NumPy's legacy generator
     offs = np.array([0, 311, 312, 623, 624, 10**6, 5 * 10**6], dtype=np.int64)
     seeds = np.array([0, 1, 12345, 2**32 - 1], dtype=np.int64)

@@ -2,7 +2,8 @@
 LDS, both lists written at once; lists of up to 20 uint16 positions inside the 64-byte edge line, longer ones and rows
 beyond 65536 entries in the overflow array), decoded by pw_lane_index_export and compared with a NumPy restatement of
 its definition: for every CSR entry e = (u -> v), the ascending positions in row v of N(u) & N(v) -- the set the
-reference's isnotin() recomputes on every step (src/pecanpy/rw/sparse_rw.py:142-230)."""
+reference's isnotin() recomputes on every step (src/pecanpy/rw/sparse_rw.py:142-230) -- less u's own position when u has a
+self loop (the reference takes prev out of the common neighbours, sparse_rw.py:79-87)."""
 import numpy as np
 import pytest
 
@@ -24,6 +25,9 @@ def expected_lists(indptr, indices, entries):
         pos = np.flatnonzero(np.isin(rv, ru, assume_unique=True))
         k = np.searchsorted(rv, u)
         rev = int(k) if k < rv.size and rv[k] == u else NOT_FOUND
+        # (self loop at u: prev's own position in row v is not a common neighbour -- the reference takes it out,
+        #  `non_com_nbr[prev_ptr] = False`, sparse_rw.py:79-87)
+        pos = pos[pos != rev]
         out.append((pos.size, rev, pos.astype(np.uint32)))
     return out
 
@@ -92,6 +96,56 @@ def test_rows_split_into_segments_and_rows_with_uint32_positions():
     for e, (cnt, rv, pos) in zip(np.concatenate([hub_entries, into_hub0, into_hub1]),
                                  expected_lists(indptr, indices, np.concatenate([hub_entries, into_hub0, into_hub1]))):
         assert n_in2[e] == cnt and rev[e] == rv and np.array_equal(ent[off[e]:off[e + 1]], pos), e
+
+
+def test_self_loops_keep_the_index_and_lose_prev(monkeypatch):
+    """Round 6: graphs with self loops (the reference accepts them, graph.py:238-268) keep the lane index.  u in N(u) makes u a
+    member of N(u) & N(v) for every neighbour v: its position leaves the list of (u -> v); a loop at v is an ordinary common
+    neighbour; the self entry (u -> u) lists the whole row but u.  Ring lattices with a loop on EVERY vertex sweep the list
+    lengths through the inline capacity (21 -> 20 entries: the list moves into its line), a hub with a loop gives uint32
+    lists and segments, a directed graph gives rows of ONE entry that point at a looped vertex."""
+    rng = np.random.default_rng(12)
+    for k in (3, 11, 12):
+        indptr, indices, _ = ring_lattice_csr(400, k)
+        n = indptr.size - 1
+        rows = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+        loops = np.arange(n) if k != 3 else np.arange(0, n, 3)
+        indptr, indices, _ = csr_from_edges(np.concatenate([rows, loops]), np.concatenate([indices.astype(np.int64), loops]), n)
+        _, n_in = check(indptr, indices)
+        if k == 12:
+            assert (n_in == 20).any() and (n_in == 21).any()
+    indptr, indices, _ = rmat_csr(12, seed=5)
+    n = indptr.size - 1
+    rows = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+    loops = rng.choice(n, 400, replace=False)
+    loops[:3] = np.argsort(np.diff(indptr.astype(np.int64)))[-3:]             # ... the three largest hubs among them
+    indptr, indices, _ = csr_from_edges(np.concatenate([rows, loops]), np.concatenate([indices.astype(np.int64), loops]), n)
+    check(indptr, indices)
+    # a 70 000-entry hub with a loop (uint32 positions, nine segments), a 20 000-entry one (uint16, three segments)
+    m = 90000
+    a = np.arange(2, 70002)
+    b = rng.choice(np.arange(2, m), 20000, replace=False)
+    bg_s, bg_d = rng.integers(2, m, 250000), rng.integers(2, m, 250000)
+    s = np.concatenate([np.zeros(a.size, np.int64), np.ones(b.size, np.int64), [0], bg_s])
+    d = np.concatenate([a, b, [1], bg_d])
+    keep = s != d
+    s, d = s[keep], d[keep]
+    lp = np.concatenate([[0, 1], rng.choice(np.arange(2, m), 500, replace=False)])
+    indptr, indices, _ = csr_from_edges(np.concatenate([s, d, lp]), np.concatenate([d, s, lp]), m)
+    ip = indptr.astype(np.int64)
+    eng, _ = check(indptr, indices, sample=3000, seed=3)
+    n_in, rev, off, ent = eng.lane_index()
+    sel = np.concatenate([np.arange(ip[0], ip[0] + 200), np.arange(ip[1], ip[1] + 200), np.flatnonzero(indices == 0)[:200],
+                          np.flatnonzero((indices == np.repeat(np.arange(m), np.diff(ip))))[:300]])     # (incl. the self entries)
+    for e, (cnt, rv, pos) in zip(sel, expected_lists(indptr, indices, sel)):
+        assert n_in[e] == cnt and rev[e] == rv and np.array_equal(ent[off[e]:off[e + 1]], pos), int(e)
+    # directed: h -> k only (rows of one entry), k looped
+    src = np.concatenate([np.arange(100, 400), np.arange(0, 100), rng.integers(0, 100, 600)])
+    dst = np.concatenate([np.arange(100, 400) % 100, np.arange(0, 100), rng.integers(0, 100, 600)])
+    indptr, indices, _ = csr_from_edges(src, dst, 400)
+    assert (np.diff(indptr.astype(np.int64))[100:] == 1).all()
+    _, n_in = check(indptr, indices)
+    assert (n_in[indptr[100]:] == 1).all()       # (h -> k: k's own position in row k is the one common neighbour)
 
 
 def test_directed_graph_entries_without_reverse_edge():

@@ -161,9 +161,19 @@ def test_hub_rows_longer_than_mask_segment(weighted):
     assert eng.last_stats["overflow_reads"] == ost.overflow_reads
 
 
-def test_self_loops_take_the_eager_step():
-    """Graphs with self loops get no common-neighbour counts (prev would be its own common neighbour):
-    every step runs the eager path and still matches the oracle."""
+def _with_loops(indptr, indices, loops):
+    from pecanpy_amd.synth import csr_from_edges
+
+    n = indptr.size - 1
+    rows = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
+    return csr_from_edges(np.concatenate([rows, loops]), np.concatenate([indices.astype(np.int64), loops]), n)
+
+
+@pytest.mark.parametrize("p,q,lane", [(0.5, 2, 1), (0.25, 4, 1), (2, 0.5, 1), (0.3, 1.7, 2)])
+def test_self_loops_stay_on_the_lane_kernel(p, q, lane):
+    """Self loops (the reference accepts them, graph.py:238-268; a walker may step u -> u and then has prev == cur): unit
+    graphs keep the lane index (round 6: prev's own position is taken out of the lists whose source has a loop, as the
+    reference takes it out of the common neighbours, sparse_rw.py:79-87) -- same kernels, no 25x cliff -- and match the oracle."""
     from pecanpy_amd.synth import csr_from_edges
 
     rng = np.random.default_rng(3)
@@ -173,7 +183,55 @@ def test_self_loops_take_the_eager_step():
     indptr, indices, data = csr_from_edges(np.concatenate([s, d, loops]), np.concatenate([d, s, loops]), n)
     rows = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
     assert (rows == indices).sum() >= 300
-    _check_vs_oracle(indptr, indices, data, 0.5, 2, 2, 30, seed=8)
+    st = _check_vs_oracle(indptr, indices, data, p, q, 2, 30, seed=8)
+    assert st["lane_kernel"] == lane, st
+    # R-MAT with loops on its hubs (long lists, overflow reads through looped vertices) and on every 7th vertex
+    indptr, indices, _ = rmat_csr(13, seed=13)
+    deg = np.diff(indptr.astype(np.int64))
+    loops = np.unique(np.concatenate([np.argsort(deg)[-40:], np.arange(0, indptr.size - 1, 7)]))
+    indptr, indices, data = _with_loops(indptr, indices, loops)
+    st = _check_vs_oracle(indptr, indices, data, p, q, 4, 60, seed=5)
+    assert st["lane_kernel"] == lane and st["total_steps"] > 10**6, st
+
+
+def test_self_loops_on_every_vertex_and_in_directed_graphs():
+    """A loop on EVERY vertex of a ring lattice (every arrival has prev among the raw common neighbours; the lists sweep
+    the inline capacity), and a directed graph with loops, sinks and rows of one entry."""
+    from pecanpy_amd.synth import csr_from_edges, ring_lattice_csr
+
+    for k in (5, 12):
+        indptr, indices, _ = ring_lattice_csr(600, k)
+        indptr, indices, data = _with_loops(indptr, indices, np.arange(600))
+        for p, q in ((0.5, 2), (4, 0.25), (1, 1)):
+            st = _check_vs_oracle(indptr, indices, data, p, q, 3, 40, seed=2)
+            assert st["lane_kernel"] == 1
+    rng = np.random.default_rng(9)
+    m = 2500
+    src, dst = rng.integers(0, m, 30000), rng.integers(0, m, 30000)
+    keep = (src % 40 != 0)                                   # vertices 0, 40, ... have no out-edges
+    lp = rng.choice(np.arange(m)[np.arange(m) % 40 != 0], 400, replace=False)
+    indptr, indices, data = csr_from_edges(np.concatenate([src[keep], lp]), np.concatenate([dst[keep], lp]), m)
+    st = _check_vs_oracle(indptr, indices, data, 0.5, 2, 2, 30, seed=4)
+    assert st["lane_kernel"] == 1 and st["dead_end_walks"] > 0 and st["stream_addressing"] == 0
+
+
+def test_self_loops_weighted_graphs_take_the_wave_kernel():
+    """Weighted graphs with self loops get no lane index (the node2vec+ tables pair the two directions' lists entry by
+    entry): the wave-per-walk kernel's eager step serves them, exact as before."""
+    indptr, indices, _ = rmat_csr(11, seed=4)
+    indptr, indices, _ = _with_loops(indptr, indices, np.arange(0, indptr.size - 1, 5))
+    from pecanpy_amd.synth import hash_edge_weights
+
+    data = hash_edge_weights(indptr, indices, 3)
+    st = _check_vs_oracle(indptr, indices, data, 0.5, 2, 2, 30, seed=6)
+    assert st["lane_kernel"] == 0
+    thr = np.nan_to_num(_thresholds(indptr, data, 0.0), nan=0.0)
+    starts = orc.shuffled_starts(indptr.size - 1, 2, 5)
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 30, 5, thr=thr)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    eng.set_thresholds(thr)
+    got = eng.simulate("SparseOTF", 0.5, 2, True, starts, 30, seed=5)
+    assert np.array_equal(got, want), _diff_report(got, want)
 
 
 def test_overflow_reads_are_mirrored():

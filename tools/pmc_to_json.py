@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r05_traffic.json, the file
+"""Fold the text summaries of tools/pmc_run.sh (gpurun_out/<tag>/pass*.txt) into profiles/r06_traffic.json, the file
 bench.py reads the HBM-side traffic and the issue counters of a workload from.
 usage: pmc_to_json.py <dir with pass*.txt> <workload key> <kernel substring[+substring...]> <steps per pass> [note]"""
 import glob
@@ -56,7 +56,7 @@ def main(d, key, kernel, steps, note=""):
                          "scattered <= 64-byte accesses: FETCH_SIZE is exact at one 64-byte sector per access "
                          "(profiles/r02_fetch_calibration.txt)"),
     }
-    path = os.path.join(REPO, "profiles", "r05_traffic.json")
+    path = os.path.join(REPO, "profiles", "r06_traffic.json")
     try:
         doc = json.load(open(path))
     except (OSError, ValueError):
