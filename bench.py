@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weighted", action="store_true", help="hashed U(0,1] edge weights (RMAT configs)")
     ap.add_argument("--extend", action="store_true", help="node2vec+ (weighted graphs)")
+    ap.add_argument("--self-loops", type=int, default=0, help="add this many random self loops to the RMAT graph (the reference "
+                    "accepts them, graph.py:238-268; round 6: they keep the lane kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-call", action="store_true", help="skip the host-pointer call (config.host_call)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -205,6 +207,13 @@ def main():
     if cfg["graph"] == "rmat":
         indptr, indices, data = rmat_csr(cfg["scale"], seed=1, weighted=cfg["weighted"])
         n_nodes = indptr.size - 1
+        if args.self_loops and not cfg["weighted"]:
+            from pecanpy_amd.synth import csr_from_edges
+
+            lp = np.random.default_rng(7).choice(n_nodes, args.self_loops, replace=False).astype(np.int64)
+            rows = np.repeat(np.arange(n_nodes, dtype=np.int64), np.diff(indptr.astype(np.int64)))
+            indptr, indices, data = csr_from_edges(np.concatenate([rows, lp]), np.concatenate([indices.astype(np.int64), lp]), n_nodes)
+            del rows
         t_graph = time.time() - t0
         t_create = time.perf_counter()
         eng = WalkEngine.from_csr(indptr, indices, data, device=local_rank)
@@ -218,8 +227,9 @@ def main():
         has_nbr = indptr[1:] != indptr[:-1]
         nnz = int(indices.size)
         gdesc = (f"RMAT-{cfg['scale']} (Graph500 a,b,c=.57,.19,.19, edge factor 8, symmetrised"
-                 f"{', hashed U(0,1] weights' if cfg['weighted'] else ', unweighted'})")
-        key_graph = f"rmat{cfg['scale']}{'w' if cfg['weighted'] else ''}"
+                 f"{', hashed U(0,1] weights' if cfg['weighted'] else ', unweighted'}"
+                 f"{', + %d random self loops' % args.self_loops if args.self_loops else ''})")
+        key_graph = f"rmat{cfg['scale']}{'w' if cfg['weighted'] else ''}{'_loops%d' % args.self_loops if args.self_loops else ''}"
     else:
         n_nodes = cfg["n"]
         bits, deg_t = er_bits_gpu(n_nodes, cfg["density"], dev)

@@ -224,6 +224,13 @@ int pw_precomp_export(pw_graph *g, uint64_t *alias_indptr, uint32_t *alias_j, fl
 int pw_count_stream_draws(pw_graph *g, const uint32_t *starts, uint64_t n_jobs,
                           uint32_t walk_length, uint64_t *out_draws);
 
+/* The draws [stream_skip, stream_skip + n_draws) of `seed`'s MT19937 stream, expanded once and KEPT in the handle:
+ * pw_simulate_device calls with that seed whose draws lie inside use them in place (no jump-ahead, no expansion) until
+ * pw_stream_release, the next pw_stream_hold or a pw_simulate call that walks in parts.  For a shard walked in several
+ * calls (chunks that travel while the next is walked): one jump tree per shard instead of one per chunk. */
+int pw_stream_hold(pw_graph *g, uint32_t seed, uint64_t stream_skip, uint64_t n_draws);
+int pw_stream_release(pw_graph *g);
+
 /* ---- skip-gram training over a walk matrix (the stage after the walks) ------------------- */
 /* Word2Vec(walks, sg=1, negative, window, epochs) of Base.embed / cli.learn_embeddings (pecanpy.py:276-290,
  * cli.py:307-325) as a HIP kernel: skip-gram with negative sampling, word2vec.c's update rule, unigram^0.75 negative

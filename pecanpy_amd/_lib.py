@@ -86,6 +86,8 @@ SYMBOLS = {
     "pw_precomp_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "pw_count_stream_draws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.POINTER(C.c_uint64)]),
+    "pw_stream_hold": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "pw_stream_release": (C.c_int, [C.c_void_p]),
     "pw_sgns_train": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pw_mt_random_sample": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),

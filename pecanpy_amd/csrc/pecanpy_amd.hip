@@ -149,7 +149,7 @@ struct pw_graph {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // pw_simulate() walks a large job array in parts: the stream of the WHOLE array is expanded once, and while this is
     // set expand_stream() serves the parts' sub-ranges from g->rng as it stands (never kept across API calls)
-    struct { bool valid = false; uint32_t seed = 0; uint64_t first_block = 0, n_blocks = 0; } rng_hold;
+    struct { bool valid = false, user = false; uint32_t seed = 0; uint64_t first_block = 0, n_blocks = 0; } rng_hold;   // (user: pw_stream_hold)
     hipStream_t copy_stream = nullptr;     // pw_simulate: the D2H of one part of the walk matrix runs here, under the walks of the next
     static constexpr int N_STAGE = 12;
     hipEvent_t ev_copy[N_STAGE] = {};
@@ -163,6 +163,7 @@ struct pw_graph {
     DevBuf<uint32_t> mt_state, changed, redo;
     DevBuf<pw::SuspRec> susp[2];      // lane kernel: walks parked for the float chain (two queues, swapped per round)
     uint32_t lane_rounds = 0;         // lane kernel launches of the last call
+    uint64_t call_runnable = 0;       // whole-array call: jobs whose start has neighbours (the stream's nominal draws / walk_length)
     // generator states of recent calls, keyed by (seed, first block, blocks per generator, generators): a repeated
     // call (every pass of a benchmark, every chunk of a sharded run) skips the ~20 sequential jump-ahead launches
     struct MtCache { bool valid = false; uint32_t seed = 0, n_gen = 0; uint64_t first_block = 0; int per_gen_log = 0; uint64_t stamp = 0;
@@ -170,6 +171,7 @@ struct pw_graph {
     uint64_t mt_stamp = 0;
     // verification mode of the lane kernel (PECANPY_AMD_VERIFY_TIGHT=1): steps the interval decision settled
     DevBuf<pw::VerRec> ver, ver_bad;
+    DevBuf<uint32_t> ver_jobs;        // sampled verification (production): walks of mismatching records, redone by walk_kernel
     uint64_t ver_checked = 0, ver_mismatch = 0, ver_dropped = 0, ver_ties = 0;   // ... of the current call
     DevBuf<uint64_t> jump_table;  // MtJump::pow2_table() on the device
     DevBuf<uint32_t> jump_tmp;    // partial results of jumps whose taps are split over several workgroups (kept zeroed)
@@ -278,6 +280,7 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     g->susp[1].release();
     g->ver.release();
     g->ver_bad.release();
+    g->ver_jobs.release();
     g->stream_off.release();
     g->tile_sums.release();
     g->rng.release();
@@ -1592,22 +1595,39 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
                        g->list_max_len == 0xffffffffu && n_work >= lanes_resident_c && n_work <= 32 * lanes_resident_c;
     if (const char *ce = getenv("PECANPY_AMD_LANE_CHAINS")) chains_form = atoi(ce) != 0 && !weighted && !getenv("PECANPY_AMD_VERIFY_TIGHT");
     if (chains_form) use_queue = true;      // (a step that finds the pool full is still parked: the round loop below takes care of it)
+    // Queue capacities (round 6: from what CAN be parked, not from the job array -- device memory a fresh box has not handed out
+    // before costs ~23 ms per GB, and two queues of n_jobs records were 5.4 GB at RMAT-22): only walks whose start has neighbours
+    // are ever parked (g->call_runnable of them in a whole-array call: the stream's draws / walk_length), and the second queue
+    // only ever holds walks that were in the first -- it is allocated after round 0, for the walks that round parked.
     // + the void slots of every wavefront's LAST reservation (< 128 each; leftovers of earlier ones are used up)
-    const size_t q_cap = (size_t)n_work + 2 * (size_t)lanes_resident;
-    if (use_queue && (g->susp[0].ensure(q_cap) || g->susp[1].ensure(q_cap))) {
+    const uint64_t can_park = (!wa.job_list && g->call_runnable && g->call_runnable < n_work) ? g->call_runnable : n_work;
+    const size_t q_cap = (size_t)can_park + 2 * (size_t)lanes_resident;
+    if (use_queue && g->susp[0].ensure(q_cap)) {
         (void)hipGetLastError();
         use_queue = false;              // no room for the queues: chains run in place
         chains_form = false;
     }
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
-    // verification mode: every step the interval decision settles is recorded and decided again by the float chain
+    // VERIFICATION of the interval decision (lane_tight: its inflation constants are argued, not proved -- DESIGN.md section 3).
+    //  * test mode (PECANPY_AMD_VERIFY_TIGHT=1): EVERY step it settles is recorded and decided again by the float chain.
+    //  * production (round 6, default): a SAMPLE of them -- the steps with ((job + 7919 j) & (N - 1)) == 0, N = 1024, or
+    //    PECANPY_AMD_VERIFY_SAMPLE=N (a power of two; 0: off) -- is re-decided the same way, in the same call, counted in
+    //    pw_stats.verify_checked / verify_mismatch; a walk with a mismatching record is walked AGAIN by the complete kernel
+    //    (walk_kernel: membership searched, the float chain itself) and the host layer warns.  ~1e-4 of the steps: no cost.
     const char *ver_env = getenv("PECANPY_AMD_VERIFY_TIGHT");
-    const bool verify = ver_env != nullptr && !weighted;
-    la.ver_poison = (verify && strcmp(ver_env, "poison") == 0) ? 1u : 0u;
+    const bool verify_full = ver_env != nullptr && !weighted;
+    uint32_t sample_n = 1024;
+    if (const char *se = getenv("PECANPY_AMD_VERIFY_SAMPLE")) sample_n = (uint32_t)strtoul(se, nullptr, 10);
+    if (sample_n & (sample_n - 1)) { uint32_t pw2 = 1; while (pw2 * 2 <= sample_n) pw2 *= 2; sample_n = pw2; }
+    const bool verify_sample = !verify_full && !weighted && !tails && sample_n > 0;
+    const bool verify = verify_full || verify_sample;
+    la.ver_poison = ((verify_full && strcmp(ver_env, "poison") == 0) || (verify_sample && getenv("PECANPY_AMD_VERIFY_SAMPLE_POISON"))) ? 1u : 0u;
+    la.ver_mask = verify_full ? 0u : sample_n - 1u;
     la.ver = nullptr;
     la.ver_count = g->counters.p + 40;
     la.ver_cap = 0;
-    if (verify) {
+    const uint32_t VER_JOBS_CAP = 65536;
+    if (verify_full) {
         const char *cap_env = getenv("PECANPY_AMD_VERIFY_CAP");
         // room for every step of the launch (on hub-heavy graphs most steps are ambiguous), within half of the free memory
         size_t free_b = 0, total_b = 0;
@@ -1621,12 +1641,23 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         if (g->ver.ensure(cap) || g->ver_bad.ensure(16)) return PW_ERR_NOMEM;
         la.ver = g->ver.p;
         la.ver_cap = cap;
+    } else if (verify_sample) {
+        // (a round records at most its settled steps / N; a full buffer drops the excess and counts it: verify_dropped)
+        const uint64_t cap = n_work * (uint64_t)wa.L / sample_n / 2 + 65536;
+        if (g->ver.ensure(cap) || g->ver_bad.ensure(16) || g->ver_jobs.ensure(VER_JOBS_CAP)) return PW_ERR_NOMEM;
+        la.ver = g->ver.p;
+        la.ver_cap = cap;
+        HIP_TRY(hipMemsetAsync(g->counters.p + 44, 0, 4 * sizeof(unsigned long long), g->stream));
     }
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
     for (int round = 0;; round++) {
         const bool chains_now = chains_form && round == 0;
-        const bool queue_out = chains_now || (use_queue && todo > tail && round < (weighted ? 512 : 64));
+        bool queue_out = chains_now || (use_queue && todo > tail && round < (weighted ? 512 : 64));
+        if (queue_out && round >= 1 && g->susp[round & 1].ensure((size_t)todo + 2 * (size_t)lanes_resident)) {
+            (void)hipGetLastError();
+            queue_out = false;          // (no room for the other queue: this round runs its chains in place and is the last)
+        }
         la.susp = queue_out ? g->susp[round & 1].p : nullptr;
         la.susp_count = g->counters.p + 32;
         la.susp_chunk = todo > 32 * lanes_resident ? 128u : 1u;   // (void slots: < 128 per wavefront)
@@ -1646,9 +1677,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipMemsetAsync(g->counters.p + 32, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-        if (verify) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
+        if (verify_full || (verify_sample && round == 0)) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
         const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
-        if (chains_now) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        if (chains_now && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
+        else if (chains_now) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (weighted && queue_out) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (weighted) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else if (queue_out && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true>), lgrid, lblock, 0, g->stream, la);
@@ -1658,7 +1690,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         else if (tails) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, false, true>), lgrid, lblock, 0, g->stream, la);
         else hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false>), lgrid, lblock, 0, g->stream, la);
         HIP_TRY(hipGetLastError());
-        if (verify) {   // the chain decides this round's recorded steps again
+        if (verify_full) {   // the chain decides this round's recorded steps again
             unsigned long long n_rec = 0;
             HIP_TRY(hipMemcpyAsync(&n_rec, g->counters.p + 40, sizeof(n_rec), hipMemcpyDeviceToHost, g->stream));
             HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1681,7 +1713,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
                     HIP_TRY(hipMemcpy(bad, g->ver_bad.p, sizeof(pw::VerRec) * nb, hipMemcpyDeviceToHost));
                     for (unsigned i = 0; i < nb; i++)
                         fprintf(stderr, "[verify] MISMATCH d=%u n_in=%u pp=%u kmax=%u tot=%.9g wo=%g r=%.17g: interval decision %u, float chain %u\n",
-                                bad[i].d, bad[i].n_in, bad[i].pp, bad[i].kmax, (double)bad[i].tot, (double)bad[i].wo, bad[i].r, bad[i].choice, bad[i].pad);
+                                bad[i].d, bad[i].n_in, bad[i].pp, bad[i].kmax, (double)bad[i].tot, (double)bad[i].wo, bad[i].r, bad[i].choice, bad[i].job);
                 }
             }
         }
@@ -1720,9 +1752,49 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         if (!parked) break;
         todo = parked;
     }
+    unsigned long long vs[4] = {0, 0, 0, 0}, n_rec_s = 0;
+    if (verify_sample) HIP_TRY(hipMemcpyAsync(&n_rec_s, g->counters.p + 40, sizeof(n_rec_s), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    if (verify) g->ver.release();   // (test mode: up to half of the free memory -- not kept in the handle)
+    if (verify_sample && n_rec_s) {   // the sample of ALL rounds (the records accumulate across them): re-decided by the chain, one launch
+        const unsigned long long n_chk = n_rec_s < la.ver_cap ? n_rec_s : la.ver_cap;
+        g->ver_dropped += n_rec_s - n_chk;
+        HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+        hipLaunchKernelGGL(pw::lanes_verify_kernel, dim3((unsigned)((n_chk + 255) / 256)), dim3(256), 0, g->stream, g->ver.p,
+                           (uint64_t)n_chk, g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 44, g->ver_bad.p, 16u, g->ver_jobs.p, VER_JOBS_CAP);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(g->ev[5], g->stream));
+        HIP_TRY(hipMemcpyAsync(vs, g->counters.p + 44, sizeof(vs), hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        float vms = 0;
+        HIP_TRY(hipEventElapsedTime(&vms, g->ev[4], g->ev[5]));
+        g->lane_ms += vms;              // (part of the lane path's time: the roofline's kernel time includes it)
+    }
+    if (verify_full) g->ver.release();   // (test mode: up to half of the free memory -- not kept in the handle)
+    if (verify_sample) {
+        g->ver_checked += vs[0];
+        g->ver_mismatch += vs[1];
+        g->ver_ties += vs[2];
+        if (vs[1]) {
+            // A sampled interval decision disagrees with the float chain.  Never seen (1e9 decisions re-decided
+            // on the device, 6e9 fuzzed on the host) -- but the bound is argued, not proved, so: say so, and walk the affected
+            // walks again with the complete kernel, whose steps are the reference's float chain over a searched membership mask.
+            pw::VerRec bad[16];
+            const unsigned nb = vs[3] < 16 ? (unsigned)vs[3] : 16u;
+            HIP_TRY(hipMemcpy(bad, g->ver_bad.p, sizeof(pw::VerRec) * nb, hipMemcpyDeviceToHost));
+            for (unsigned i = 0; i < nb && getenv("PW_DEBUG_ROUNDS"); i++)
+                fprintf(stderr, "[verify] MISMATCH d=%u n_in=%u pp=%u kmax=%u tot=%.9g wo=%g r=%.17g: interval decision %u, float chain %u\n",
+                        bad[i].d, bad[i].n_in, bad[i].pp, bad[i].kmax, (double)bad[i].tot, (double)bad[i].wo, bad[i].r, bad[i].choice, bad[i].job);
+            pw::WalkArgs wr = wa;
+            wr.job_list = g->ver_jobs.p;
+            wr.n_list = vs[3] < VER_JOBS_CAP ? vs[3] : VER_JOBS_CAP;
+            wr.resume = 0;
+            wr.stats = g->counters.p + 20;      // (their transitions were counted by the lane kernel already)
+            int rcw = launch_wave_walks(g, wr, false);
+            if (rcw) return rcw;
+            HIP_TRY(hipStreamSynchronize(g->stream));
+        }
+    }
 #ifdef PW_LANES_WATCHDOG
     {
         unsigned long long wd[32], zero[32] = {0};
@@ -1903,6 +1975,8 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
         *rng_base = g->rng_hold.first_block * 312;
         return 0;
     }
+    g->rng_hold.valid = false;      // (g->rng is about to be overwritten: whatever was held is gone)
+    g->rng_hold.user = false;
     if (g->rng.ensure(n_blocks * 312)) return PW_ERR_NOMEM;
     uint64_t per_gen = 1;
     int per_gen_log = 0;
@@ -1985,6 +2059,34 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
     return 0;
 }
 
+// The draws [stream_skip, stream_skip + n_draws) of `seed`'s stream expanded ONCE and kept: pw_simulate_device calls with that
+// seed whose range lies inside find their draws in place (no jump-ahead tree, no expansion) until pw_stream_release or the
+// next pw_stream_hold -- for a shard walked in chunks (every chunk would pay ~3 ms of sequential jump launches otherwise).
+PW_EXPORT int pw_stream_hold(pw_graph *g, uint32_t seed, uint64_t stream_skip, uint64_t n_draws) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    if (set_device(g)) return PW_ERR_HIP;
+    if (g->counters.ensure(N_COUNTERS)) return PW_ERR_NOMEM;
+    g->rng_hold.valid = false;
+    g->rng_hold.user = false;
+    if (!n_draws) return PW_OK;
+    uint64_t base = 0;
+    int rc = expand_stream(g, seed, true, stream_skip, n_draws, &base);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->rng_hold.valid = true;
+    g->rng_hold.user = true;
+    g->rng_hold.seed = seed;
+    g->rng_hold.first_block = base / 312;
+    g->rng_hold.n_blocks = (stream_skip + n_draws + 311) / 312 > base / 312 ? (stream_skip + n_draws + 311) / 312 - base / 312 : 1;
+    return PW_OK;
+}
+PW_EXPORT int pw_stream_release(pw_graph *g) {
+    if (!g) return fail(PW_ERR_INVALID, "null pointer");
+    g->rng_hold.valid = false;
+    g->rng_hold.user = false;
+    return PW_OK;
+}
+
 // Test hook: doubles #offset .. #offset + n of RandomState(seed).random_sample as the DEVICE produces them (jump tree +
 // expansion kernels of a walk call), copied to the host.
 PW_EXPORT int pw_stream_sample_device(pw_graph *g, uint32_t seed, uint64_t offset, uint64_t n, double *out) {
@@ -2032,6 +2134,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     int rc = compute_offsets(g, d_starts, nullptr, walk_length, n_jobs, stream_skip, false, &total, nullptr);
     if (rc) return rc;
 
+    g->call_runnable = total / walk_length;
     const bool lanes_pre = g->kind == 0 && g->unit && g->d_lines && !g->lanes_off && mode == PW_MODE_SPARSE_OTF;
     // (zero-fill of the walk matrix for the lane kernel: on the side stream, overlapped with the stream expansion.  No
     //  return path may leave that write to the CALLER's buffer in flight: the guard waits for the side stream.)
@@ -2448,9 +2551,13 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     // than their nominal share -- lies inside): one jump tree instead of one per part
     struct HoldGuard {
         pw_graph *g;
-        ~HoldGuard() { g->rng_hold.valid = false; }
-    } hold_guard{g};
+        bool mine;
+        ~HoldGuard() { if (mine) g->rng_hold.valid = false; }
+    } hold_guard{g, false};
     if (!rc && n_parts > 1) {
+        g->rng_hold.valid = false;        // (a caller's pw_stream_hold ends here: this call expands the stream of its own array)
+        g->rng_hold.user = false;
+        hold_guard.mine = true;
         if (g->counters.ensure(N_COUNTERS)) rc = PW_ERR_NOMEM;
         if (!rc) rc = check_starts(g, d_starts, n_jobs);
         uint64_t nominal = 0, base = 0;
@@ -2587,7 +2694,8 @@ PW_EXPORT int pw_simulate_multi(pw_graph *const *handles, int n_handles, int mod
             }
             // device output on handles[0]'s GPU: walk into local memory, then one peer copy (in place when it IS that GPU)
             hipError_t e = hipSetDevice(g->device);
-            const bool local = g->device == handles[0]->device;
+            // (PECANPY_AMD_MULTI_FORCE_PEER=1, tests on a one-GPU box: replicas on the first device take the peer-copy path too)
+            const bool local = g->device == handles[0]->device && !(i > 0 && env_on("PECANPY_AMD_MULTI_FORCE_PEER"));
             if (e == hipSuccess && !S.d_starts) {
                 e = hipMalloc((void **)&S.d_starts, sizeof(uint32_t) * n);
                 if (e == hipSuccess) e = hipMemcpy(S.d_starts, starts + S.lo, sizeof(uint32_t) * n, hipMemcpyHostToDevice);
@@ -2595,12 +2703,52 @@ PW_EXPORT int pw_simulate_multi(pw_graph *const *handles, int n_handles, int mod
             }
             if (e != hipSuccess) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi: ") + hipGetErrorString(e); return; }
             uint32_t *dst = local ? out + S.lo * W : S.d_tmp;
-            S.rc = pw_simulate_device(g, mode, p, q, extend, S.d_starts, n, walk_length, 1, seed, S.skip, dst, &S.st);
-            if (S.rc) { S.err = g_err; return; }
+            // A shard on another GPU is walked in three chunks of decreasing size (3 : 2 : 1) and chunk c travels -- peer copy on
+            // the handle's copy stream, one xGMI link -- while chunk c + 1 is walked: what stays exposed at the end is the
+            // smallest chunk's transfer (the tapered chunks of bench.py's RCCL gather).  Chunk c + 1 is
+            // addressed by the draws chunk c actually consumed.  PECANPY_AMD_MULTI_CHUNKS overrides (1: one piece).
+            int n_ch = (!local && n >= (1ull << 20)) ? 3 : 1;
+            if (const char *ce = getenv("PECANPY_AMD_MULTI_CHUNKS")) { n_ch = atoi(ce); if (n_ch < 1) n_ch = 1; if (n_ch > 16) n_ch = 16; }
+            if ((uint64_t)n_ch > n) n_ch = 1;
+            const uint64_t wsum = (uint64_t)n_ch * (n_ch + 1) / 2;
+            uint64_t a = 0, acc = 0, skip_c = S.skip;
+            pw_stats tot;
+            memset(&tot, 0, sizeof(tot));
+            if (n_ch > 1 && mode < PW_MODE_PRECOMP) {   // one jump-ahead tree for the shard, not one per chunk
+                S.rc = pw_stream_hold(g, seed, S.skip, S.nominal);
+                if (S.rc) { S.err = g_err; return; }
+            }
+            for (int c = 0; c < n_ch && !S.rc; c++) {
+                acc += (uint64_t)(n_ch - c);
+                const uint64_t b = c + 1 == n_ch ? n : acc * n / wsum;
+                if (b == a) continue;
+                pw_stats st;
+                memset(&st, 0, sizeof(st));
+                S.rc = pw_simulate_device(g, mode, p, q, extend, S.d_starts + a, b - a, walk_length, 1, seed, skip_c, dst + a * W, &st);
+                if (S.rc) { S.err = g_err; break; }
+                skip_c += st.total_steps;
+                if (c == 0) tot = st;
+                else {
+                    tot.total_steps += st.total_steps; tot.overflow_reads += st.overflow_reads; tot.clamped_reads += st.clamped_reads;
+                    tot.dead_end_walks += st.dead_end_walks; tot.repair_rounds += st.repair_rounds; tot.walk_kernel_ms += st.walk_kernel_ms;
+                    tot.rng_kernel_ms += st.rng_kernel_ms; tot.walk_kernel_launches += st.walk_kernel_launches;
+                    tot.stream_addressing |= st.stream_addressing; tot.lane_rounds += st.lane_rounds; tot.redo_walks += st.redo_walks;
+                    tot.list_entries_read += st.list_entries_read; tot.ambiguous_steps += st.ambiguous_steps; tot.lane_kernel_ms += st.lane_kernel_ms;
+                    tot.wave_chain_steps += st.wave_chain_steps; tot.param_index_ms += st.param_index_ms; tot.verify_checked += st.verify_checked;
+                    tot.verify_mismatch += st.verify_mismatch; tot.verify_dropped += st.verify_dropped; tot.verify_ties += st.verify_ties;
+                    tot.eager_steps += st.eager_steps;
+                }
+                if (!local) {   // (the walks of this chunk are complete: pw_simulate_device returns after its stream has drained)
+                    e = hipMemcpyPeerAsync(out + (S.lo + a) * W, handles[0]->device, S.d_tmp + a * W, g->device, sizeof(uint32_t) * (b - a) * W, g->copy_stream);
+                    if (e != hipSuccess) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi (peer copy): ") + hipGetErrorString(e); }
+                }
+                a = b;
+            }
+            S.st = tot;
+            (void)pw_stream_release(g);
             if (!local) {
-                e = hipMemcpyPeerAsync(out + S.lo * W, handles[0]->device, S.d_tmp, g->device, sizeof(uint32_t) * n * W, g->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-                if (e != hipSuccess) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi (peer copy): ") + hipGetErrorString(e); }
+                e = hipStreamSynchronize(g->copy_stream);
+                if (e != hipSuccess && !S.rc) { S.rc = PW_ERR_HIP; S.err = std::string("pw_simulate_multi (peer copy): ") + hipGetErrorString(e); }
             }
         }, first_open);
         int bad = -1;

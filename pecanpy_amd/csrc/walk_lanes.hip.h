@@ -69,7 +69,7 @@ static_assert(sizeof(SuspRec) == 64, "queue record is four 16-byte accesses");
 // A step the interval decision (lane_tight) settled, kept for verification: what lane_chain needs to decide it again.
 struct VerRec {
     uint32_t kmax, n_in, pp, choice;
-    uint32_t e, coff, d, pad;
+    uint32_t e, coff, d, job;                // (job: the walk this step belongs to -- a mismatch sends it to walk_kernel)
     float tot, wo;
     double r;
 };
@@ -114,6 +114,9 @@ struct LanesArgs {
     uint64_t ver_cap;
     uint32_t ver_poison;                      // PECANPY_AMD_VERIFY_TIGHT=poison: every 1024th RECORD (not the walk) gets a wrong
                                               // position, which the check must report -- proves the check is live
+    uint32_t ver_mask;                        // a settled step of (job, j) is recorded when ((job + 7919 j) & ver_mask) == 0: 0 = every
+                                              // step (test mode), 1023 = the production sample (round 6: a safety net under the argued
+                                              // bounds of lane_tight, ~1e-3 of the interval decisions re-decided by the float chain)
     // WEIGHTED form (weighted CSR graphs; per (p, q, extend, thresholds) tables built by wbase / wprefix / wlist kernels)
     const PrefixPair *wpq;                    // [nnz] per-row inclusive float64 prefix sums of the base values (+ their running sums)
     const double *wdl;                        // per-entry lists of delta prefix sums (entry e: wdl + wl_off[e], n_in values)
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, CHAINS ? PW_LANES_MIN_W
                                          : (PW_LANES_DEFER ? PW_LANES_MIN_WAVES_D : PW_LANES_MIN_WAVES_Q)))
 walk_lanes_kernel(LanesArgs a) {
     constexpr bool DEFER = PW_LANES_DEFER && !INPLACE && !FLOATS && !WEIGHTED;
-    static_assert(!CHAINS || (DEFER && !VERIFY && !TAILS), "the CHAINS form is the deferred queueing form plus in-kernel chain passes");
+    static_assert(!CHAINS || (DEFER && !TAILS), "the CHAINS form is the deferred queueing form plus in-kernel chain passes");
     // QUAD (round 5; the dyadic forms): what a step reads of the graph comes in WHOLE 64-byte sectors, fetched by quads of
     // lanes straight into LDS (global_load_lds, 16 bytes per lane: lane l moves piece l & 3 of the sector wanted by lane
     // 16 k + (l >> 2), k = 0..3 -- the 64 bytes of lane w's sector land contiguously at byte 64 w of the wavefront's buffer):
@@ -533,7 +536,8 @@ walk_lanes_kernel(LanesArgs a) {
                     if (ch != LANE_AMBIGUOUS) *(uint32_t *)&pool[2][lane] = ch;   // settled: the choice takes kmax's place
                 }
                 if (VERIFY) {   // keep what the float chain needs to decide this step again (lanes_verify_kernel)
-                    const bool rec = mine && ch != LANE_AMBIGUOUS;
+                    bool rec = mine && ch != LANE_AMBIGUOUS;
+                    if (rec && a.ver_mask) { const uint2 pj = *(const uint2 *)&pool[0][lane]; rec = ((pj.x + pj.y * 7919u) & a.ver_mask) == 0u; }
                     const uint64_t vm = ballot(rec);
                     if (vm) {
                         unsigned long long vb = 0;
@@ -545,7 +549,7 @@ walk_lanes_kernel(LanesArgs a) {
                             const float wo_s = p0.y >= 2u ? w_out : 1.0f;
                             uint4 *vp = (uint4 *)(a.ver + slot);
                             vp[0] = make_uint4(kmax_s, p1.x, p1.y, (a.ver_poison && (slot & 1023u) == 0u) ? ch ^ 1u : ch);
-                            vp[1] = make_uint4(p1.z, p1.w, p0.w, 0u);
+                            vp[1] = make_uint4(p1.z, p1.w, p0.w, p0.x);
                             vp[2] = make_uint4(__float_as_uint((float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev)), __float_as_uint(wo_s), p4.x, p4.y);
                         }
                     }
@@ -1003,7 +1007,7 @@ walk_lanes_kernel(LanesArgs a) {
             if (amb0) choice = lane_tight(A.d, A.pp, r, wo, w_prev, ls);
             if (VERIFY) {
                 // keep what the float chain needs to decide this step again (lanes_verify_kernel)
-                const bool rec = amb0 && choice != LANE_AMBIGUOUS;
+                const bool rec = amb0 && choice != LANE_AMBIGUOUS && ((A.job + A.j * 7919u) & a.ver_mask) == 0u;
                 const uint64_t vm = ballot(rec);
                 if (vm) {
                     unsigned long long vb = 0;
@@ -1013,7 +1017,7 @@ walk_lanes_kernel(LanesArgs a) {
                     if (rec && slot < a.ver_cap) {
                         uint4 *vp = (uint4 *)(a.ver + slot);
                         vp[0] = make_uint4(ls.kmax, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
-                        vp[1] = make_uint4(A.e, A.coff, A.d, 0u);
+                        vp[1] = make_uint4(A.e, A.coff, A.d, A.job);
                         vp[2] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                            (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
                     }
@@ -1475,9 +1479,10 @@ wlist_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const float *__res
 // ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------// ---- verification of the interval decision: the float32 chain decides every recorded step again ------------------------
 // counts: [0] records checked [1] MISMATCHES (lane_tight's position != the chain's) [2] chains that declined (tie budget)
 // bad: the first few mismatching records, for the error message
+// bad_jobs (optional, cap entries): the walks of the mismatching records -- the production sample hands them to walk_kernel
 __global__ void __launch_bounds__(256)
 lanes_verify_kernel(const VerRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
-                    unsigned long long *counts, VerRec *bad, uint32_t bad_cap) {
+                    unsigned long long *counts, VerRec *bad, uint32_t bad_cap, uint32_t *bad_jobs = nullptr, uint32_t bad_jobs_cap = 0) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long chk = 0, mis = 0, tie = 0;
     if (i < n) {
@@ -1494,7 +1499,8 @@ lanes_verify_kernel(const VerRec *q, uint64_t n, const ELine *__restrict__ lines
         else if (res != q0.w) {
             mis = 1;
             const unsigned long long slot = atomicAdd(counts + 3, 1ull);
-            if (slot < bad_cap) { bad[slot] = q[i]; bad[slot].pad = res; }
+            if (bad_jobs && slot < bad_jobs_cap) bad_jobs[slot] = q[i].job;
+            if (slot < bad_cap) { bad[slot] = q[i]; bad[slot].job = res; }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {

@@ -235,6 +235,14 @@ class WalkEngine:
         _lib.check(self._lib.pw_stream_sample_device(self._h, int(seed) & 0xFFFFFFFF, int(offset), int(n), _np_ptr(out)))
         return out
 
+    def stream_hold(self, seed, stream_skip, n_draws):
+        """Expand the draws ``[stream_skip, stream_skip + n_draws)`` of ``seed``'s stream once; ``simulate_device`` calls inside
+        that range (same seed) use them in place until ``stream_release`` -- one jump-ahead tree for a shard walked in chunks."""
+        _lib.check(self._lib.pw_stream_hold(self._h, int(seed) & 0xFFFFFFFF, int(stream_skip), int(n_draws)))
+
+    def stream_release(self):
+        _lib.check(self._lib.pw_stream_release(self._h))
+
     def count_stream_draws(self, starts, walk_length):
         starts = np.ascontiguousarray(starts, dtype=np.uint32)
         n = C.c_uint64(0)

@@ -208,6 +208,16 @@ class Base(BaseGraph):
 
     def _note_stats(self, stats):
         self.last_stats = stats
+        if stats and stats.get("verify_mismatch", 0) > 0:
+            import os
+            import warnings
+
+            if not os.environ.get("PECANPY_AMD_VERIFY_TIGHT"):
+                warnings.warn(
+                    f"{stats['verify_mismatch']} of {stats['verify_checked']} sampled interval decisions of the lane kernel disagreed "
+                    "with the sequential float32 chain; the affected walks were generated again by the complete kernel.  This has "
+                    "never been observed (DESIGN.md section 3) -- please report the graph and parameters.  "
+                    "PECANPY_AMD_NO_LANES=1 avoids the lane kernel altogether.", RuntimeWarning, stacklevel=3)
         if stats and stats.get("stream_addressing") == 1:
             import warnings
 

@@ -65,6 +65,26 @@ def test_three_replicas_device_output_and_uneven_shards():
     torch.cuda.synchronize()
 
 
+def test_peer_copy_path_in_tapered_chunks(monkeypatch):
+    """The path a replica on ANOTHER GPU takes (walk into local memory in 3 : 2 : 1 chunks, chunk c copied to the first device
+    while chunk c + 1 is walked, chunk c + 1 addressed by the draws chunk c consumed), forced for replicas on the one device a
+    test box has (PECANPY_AMD_MULTI_FORCE_PEER=1: hipMemcpyPeerAsync device 0 -> device 0) -- on a directed graph with sinks."""
+    rng = np.random.default_rng(6)
+    m = 6000
+    src, dst = rng.integers(0, m, 80000), rng.integers(0, m, 80000)
+    keep = (src != dst) & (src % 30 != 0)
+    indptr, indices, data = csr_from_edges(src[keep], dst[keep], m)
+    starts = orc.shuffled_starts(m, 6, 2)
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, 25, 2)
+    multi = MultiWalkEngine.from_csr(indptr, indices, data, devices=[0, 0, 0])
+    monkeypatch.setenv("PECANPY_AMD_MULTI_FORCE_PEER", "1")
+    for chunks in ("1", "3", "5"):
+        monkeypatch.setenv("PECANPY_AMD_MULTI_CHUNKS", chunks)
+        got = multi.simulate_to_device("SparseOTF", 0.5, 2, False, starts, 25, seed=2)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want), chunks
+        assert multi.last_stats["dead_end_walks"] > 0
+
+
 def test_dead_ends_shift_the_later_shards():
     """Directed graph with sinks: a shard consumes fewer draws than it announced, so the shards behind it are walked again
     from the draws actually consumed -- the matrix is the oracle's (one sequential stream, pecanpy.py:198-206)."""

@@ -35,7 +35,8 @@ def verified_run(monkeypatch, indptr, indices, p, q, num_walks, L, seed, eng=Non
     st = dict(eng.last_stats)
     monkeypatch.delenv("PECANPY_AMD_VERIFY_TIGHT")
     b = eng.simulate_device("SparseOTF", p, q, False, d_starts, L, seed=seed)
-    assert eng.last_stats["verify_checked"] == 0                       # (off by default)
+    sb = eng.last_stats                                                 # (default: the production SAMPLE, ~1/1024 of them)
+    assert sb["verify_checked"] <= st["verify_checked"] // 256 + 64 and sb["verify_mismatch"] == 0 and sb["verify_dropped"] == 0, sb
     assert torch.equal(a, b)
     assert st["lane_kernel"] == 1
     assert st["verify_mismatch"] == 0, st
@@ -114,3 +115,51 @@ def test_verification_is_live(monkeypatch):
     st = eng.last_stats
     assert st["verify_checked"] <= 1000 * st["lane_rounds"]
     assert st["verify_dropped"] > 0 and st["verify_mismatch"] == 0
+
+
+def test_sampled_verification_in_production(monkeypatch):
+    """Round 6: WITHOUT any switch, ~1/1024 of the steps the interval decision settles are decided
+    again by the float chain inside the same call (pw_stats.verify_checked); a mismatch sends the walk to the complete
+    kernel and is reported.  PECANPY_AMD_VERIFY_SAMPLE_POISON falsifies every 1024th record (the first included): the check must
+    see it, the walk is redone (same result: the lane kernel's walk was right), and the host layer warns."""
+    import torch
+
+    from pecanpy_amd import pecanpy as node2vec
+
+    indptr, indices, _ = ring_lattice_csr(1 << 12, 256)
+    eng = WalkEngine.from_csr(indptr, indices, None)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 32)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_TIGHT", "1")
+    full = eng.simulate_device("SparseOTF", 0.5, 2.0, False, d_starts, 80, seed=1)
+    settled = eng.last_stats["verify_checked"]
+    monkeypatch.delenv("PECANPY_AMD_VERIFY_TIGHT")
+    clean = eng.simulate_device("SparseOTF", 0.5, 2.0, False, d_starts, 80, seed=1)
+    st = dict(eng.last_stats)
+    assert torch.equal(full, clean)
+    assert settled // 2048 <= st["verify_checked"] <= settled // 512 + 8, (settled, st)     # the sample: ~1/1024
+    assert st["verify_mismatch"] == 0 and st["verify_dropped"] == 0 and st["redo_walks"] == 0
+    for form_env in ({}, {"PECANPY_AMD_LANE_CHAINS": "1"}, {"PECANPY_AMD_NO_CHAIN_QUEUE": "1"}):      # rounds / CHAINS / in place
+        for k, v in form_env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("PECANPY_AMD_VERIFY_SAMPLE_POISON", "1")
+        out = eng.simulate_device("SparseOTF", 0.5, 2.0, False, d_starts, 80, seed=1)
+        sp = dict(eng.last_stats)
+        monkeypatch.delenv("PECANPY_AMD_VERIFY_SAMPLE_POISON")
+        assert sp["verify_checked"] > 0 and 1 <= sp["verify_mismatch"] <= sp["verify_checked"] // 1024 + 1, (form_env, sp)
+        assert torch.equal(out, clean)                                  # (the redone walks equal the lane kernel's)
+        assert sp["total_steps"] == st["total_steps"]                   # ... and are not counted twice
+        out = eng.simulate_device("SparseOTF", 0.5, 2.0, False, d_starts, 80, seed=1)
+        assert eng.last_stats["verify_mismatch"] == 0 and torch.equal(out, clean)
+        for k in form_env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_SAMPLE", "0")              # off
+    eng.simulate_device("SparseOTF", 0.5, 2.0, False, d_starts, 80, seed=1)
+    assert eng.last_stats["verify_checked"] == 0
+    monkeypatch.delenv("PECANPY_AMD_VERIFY_SAMPLE")
+    # the host layer says so
+    g = node2vec.SparseOTF.from_csr(indptr, indices, None, p=0.5, q=2, random_state=1)
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_SAMPLE_POISON", "1")
+    with pytest.warns(RuntimeWarning, match="sampled interval decisions"):
+        g.simulate_walks_array(32, 80)

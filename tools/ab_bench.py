@@ -27,7 +27,15 @@ def child(args):
     n = indptr.size - 1
     starts = np.concatenate([np.arange(n, dtype=np.uint32)] * args.num_walks)
     np.random.RandomState(0).shuffle(starts)
-    if args.jobs:
+    skip = 0
+    if args.shard:                       # "i/N": the i-th of N contiguous shards, addressed into the stream like a rank of a multi-GPU run
+        i, nsh = (int(t) for t in args.shard.split("/"))
+        lo, hi = i * starts.size // nsh, (i + 1) * starts.size // nsh
+        has = (indptr[1:] != indptr[:-1])
+        skip = int(has[starts[:lo]].sum()) * args.walk_length
+        starts = starts[lo:hi]
+        has_sh = has[starts]
+    elif args.jobs:
         starts = starts[: args.jobs]
     torch.cuda.init()
     torch.cuda.synchronize()
@@ -48,7 +56,28 @@ def child(args):
     for k in range(args.passes + 1):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        eng.simulate_device("SparseOTF", args.p, args.q, args.extend, d_starts, args.walk_length, seed=k, out=out)
+        if args.chunks > 1:              # tapered chunks, each its own call (what a rank does while chunk c travels): sum of the calls
+            from pecanpy_amd.engine import tapered_bounds
+
+            csum = np.concatenate([[0], np.cumsum(has_sh if args.shard else (indptr[1:] != indptr[:-1])[starts], dtype=np.int64)])
+            if args.hold:
+                eng.stream_hold(k, skip, int(csum[-1]) * args.walk_length)
+            agg = None
+            for a, b in tapered_bounds(starts.size, args.chunks):
+                eng.simulate_device("SparseOTF", args.p, args.q, args.extend, d_starts[a:b], args.walk_length, seed=k, out=out[a:b],
+                                    stream_skip=skip + int(csum[a]) * args.walk_length)
+                cs = dict(eng.last_stats)
+                if agg is None:
+                    agg = cs
+                else:
+                    for key in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "lane_rounds", "total_steps", "ambiguous_steps",
+                                "wave_chain_steps", "list_entries_read", "redo_walks"):
+                        agg[key] += cs[key]
+            if args.hold:
+                eng.stream_release()
+            eng.last_stats = agg
+        else:
+            eng.simulate_device("SparseOTF", args.p, args.q, args.extend, d_starts, args.walk_length, seed=k, out=out, stream_skip=skip)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) * 1e3
         st = eng.last_stats
@@ -69,6 +98,9 @@ def main():
     ap.add_argument("--q", type=float, default=2.0)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--jobs", type=int, default=0)
+    ap.add_argument("--shard", default="", help="i/N: walk the i-th of N contiguous shards of the job array at its stream offset")
+    ap.add_argument("--chunks", type=int, default=1, help="walk the job array in this many tapered chunks (one call each)")
+    ap.add_argument("--hold", action="store_true", help="with --chunks: expand the stream of the whole array once (pw_stream_hold)")
     ap.add_argument("--num-walks", type=int, default=10)
     ap.add_argument("--walk-length", type=int, default=80)
     ap.add_argument("--weighted", action="store_true")
@@ -93,7 +125,8 @@ def main():
         env = dict(os.environ, PECANPY_AMD_LIB=os.path.join(REPO, "pecanpy_amd", lib))
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--graph", path, "--scale", str(args.scale), "--p", str(args.p),
                "--q", str(args.q), "--passes", str(args.passes), "--jobs", str(args.jobs), "--num-walks", str(args.num_walks),
-               "--walk-length", str(args.walk_length)] + (["--extend"] if args.extend else []) + (["--weighted"] if args.weighted else [])
+               "--walk-length", str(args.walk_length), "--chunks", str(args.chunks)] + (["--extend"] if args.extend else []) + \
+              (["--weighted"] if args.weighted else []) + (["--shard", args.shard] if args.shard else []) + (["--hold"] if args.hold else [])
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
