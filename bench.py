@@ -315,6 +315,10 @@ def main():
         tot = {k: 0 for k in acc}
         if do_gather and rank == 0:
             gather.prefill()   # the rows rank 0 writes itself (isolated starts of the other shards): part of every pass
+        if len(chunk_bounds) > 1 and mode in ("SparseOTF", "DenseOTF"):
+            # round 6: the stream of the rank's WHOLE shard is expanded once (one MT19937 jump-ahead tree, ~3 ms of sequential
+            # launches plus one per set bit of the shard's first block) and the chunks find their draws in place
+            eng.stream_hold(seed, skip, int(csum[-1]) * L)
         for c, (a, b) in enumerate(chunk_bounds):
             eng.simulate_device(mode, p, q, extend, d_starts[a:b], L, seed=seed,
                                 stream_skip=chunk_skip[c], out=d_out[a:b])
@@ -329,6 +333,8 @@ def main():
                                    for r in range(1, world)])
                 else:
                     gather.post(lo + a, lo + b, d_out[a:b])
+        if len(chunk_bounds) > 1 and mode in ("SparseOTF", "DenseOTF"):
+            eng.stream_release()
         if do_gather:
             gather.finish()                     # rank 0: the contiguous [n_jobs, L + 2] matrix is complete
         for k in tot:

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <cmath>
 #include <string>
@@ -108,6 +109,12 @@ struct pw_graph {
     uint64_t clist_bytes = 0, line_bytes = 0;
     uint64_t fbits_words = 0, slot_words = 0;           // sizes of d_fbits / d_slots (pw_graph_replicate copies the buffers)
     bool vlines = false;                                // lines[nnz + v]: the line of vertex v's mirrored overflow read
+    // TWIN (round 6): a second call context on the SAME device that aliases this handle's graph, index and per-(p, q) tables
+    // (own streams, counters, queues, stream buffers): the weighted lane form walks the two halves of a job array on the two
+    // contexts side by side, so that one half's eager kernel runs beside the other half's lane round (simulate_twin)
+    pw_graph *twin = nullptr;
+    bool alias = false;                                 // this handle IS such a twin: the shared buffers are not its to free
+    std::function<void()> on_tables_ready;              // simulate_twin: called once the call's per-(p, q) tables are in place
     bool has_loop = false;                              // the CSR has a self loop (unit graphs: lists fixed up, wave kernel's lazy step off)
     bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
                                                         // built (the wave kernel's lazy step reads it) but the lane kernel is not used
@@ -253,7 +260,15 @@ PW_EXPORT int pw_device_count(void) {
 
 PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (!g) return;
+    if (g->twin) { pw_graph_destroy(g->twin); g->twin = nullptr; }
     (void)hipSetDevice(g->device);
+    if (g->alias) {   // the graph, its index and the per-(p, q) tables belong to the handle this one aliases
+        g->d_indptr = g->d_indices = nullptr; g->d_data = nullptr; g->d_thr = nullptr; g->d_adjbits = nullptr; g->d_deg = nullptr;
+        g->d_foff = nullptr; g->d_fbits = nullptr; g->d_kf = nullptr; g->d_tab_off = nullptr; g->d_slots = nullptr; g->d_vrec = nullptr;
+        g->d_lines = nullptr; g->d_clist = nullptr; g->d_tot_e = nullptr; g->d_tot_v = nullptr; g->d_utot = nullptr; g->d_hasnbr = nullptr;
+        g->d_wb = nullptr; g->d_wpq = nullptr; g->d_wdl = nullptr; g->d_wl_dprev = nullptr; g->d_wl_off = nullptr; g->d_wedge_row = nullptr;
+        g->d_wp1 = nullptr; g->d_wck_off = nullptr; g->d_wck = nullptr;
+    }
     if (g->d_indptr) (void)hipFree(g->d_indptr);
     if (g->d_indices) (void)hipFree(g->d_indices);
     if (g->d_data) (void)hipFree(g->d_data);
@@ -2101,10 +2116,10 @@ PW_EXPORT int pw_stream_sample_device(pw_graph *g, uint32_t seed, uint64_t offse
     return PW_OK;
 }
 
-PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
-                                 const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
-                                 int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
-                                 pw_stats *stats) {
+static int simulate_device_impl(pw_graph *g, int mode, double p, double q, int extend,
+                                const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
+                                int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
+                                pw_stats *stats) {
     if (!g || (n_jobs && (!d_starts || !d_out))) return fail(PW_ERR_INVALID, "null pointer");
     if (mode < PW_MODE_SPARSE_OTF || mode > PW_MODE_PRECOMP_FIRST_ORDER) return fail(PW_ERR_INVALID, "unknown mode");
     if (mode == PW_MODE_SPARSE_OTF && g->kind != 0) return fail(PW_ERR_UNSUPPORTED, "SparseOTF needs a CSR graph handle");
@@ -2198,6 +2213,7 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
             HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint32_t) * (size_t)n_jobs * ((size_t)walk_length + 2), g->stream));
         }
     }
+    if (g->on_tables_ready) { auto cb = g->on_tables_ready; g->on_tables_ready = nullptr; cb(); }
     uint64_t redo_total = 0;
     const bool lanes = lanes_eligible(g, wa) || lanes_float_eligible(g, wa);
     g->lane_ms = 0;
@@ -2387,6 +2403,116 @@ PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int 
     st.index_max_list = g->kind == 0 && g->d_lines ? g->list_max_len : 0u;
     if (stats) *stats = st;
     return PW_OK;
+}
+
+// ---- TWIN contexts: the two halves of a weighted job array side by side on one GPU (round 6) --------------------------------
+// The weighted lane form alternates two kernels that leave most of the GPU idle in turn: a lane round (one lane per walk) and
+// the eager kernel that decides what the round parked (one wavefront per record, bound by the latency of its row scans) --
+// 51 % + 48 % of a C5 pass.  Walked as two independent halves on two call contexts (own streams, counters and queues; graph,
+// index and per-(p, q) tables shared), one half's eager kernel runs beside the other half's lane round: C5 417 -> ~330 ms per
+// pass with two plain replicas (tools/replica_bench.py), without a second copy of anything here.  The walks are those of one
+// call: the second half is addressed into the stream by the draws of the first (walked again if dead ends made them fewer).
+static pw_graph *make_twin(pw_graph *g) {
+    pw_graph *t = new pw_graph();
+    if (graph_common_init(t, g->device)) { pw_graph_destroy(t); return nullptr; }
+    t->alias = true;
+    return t;
+}
+// everything the twin reads of the graph: pointers and the keys that say which (p, q) the tables were built for
+static void twin_share(pw_graph *t, const pw_graph *g) {
+    t->kind = g->kind; t->n_nodes = g->n_nodes; t->nnz = g->nnz; t->unit = g->unit; t->max_degree = g->max_degree;
+    t->d_indptr = g->d_indptr; t->d_indices = g->d_indices; t->d_hasnbr = g->d_hasnbr; t->d_data = g->d_data; t->d_thr = g->d_thr;
+    t->d_adjbits = g->d_adjbits; t->d_deg = g->d_deg; t->bits_only = g->bits_only; t->d_foff = g->d_foff; t->d_fbits = g->d_fbits;
+    t->d_kf = g->d_kf; t->d_tab_off = g->d_tab_off; t->d_slots = g->d_slots; t->d_vrec = g->d_vrec; t->d_lines = g->d_lines;
+    t->d_clist = g->d_clist; t->clist_bytes = g->clist_bytes; t->line_bytes = g->line_bytes; t->vlines = g->vlines;
+    t->has_loop = g->has_loop; t->lanes_off = g->lanes_off; t->n_clist = g->n_clist; t->list_max_len = g->list_max_len;
+    t->words_per_row = g->words_per_row;
+    t->d_tot_e = g->d_tot_e; t->d_tot_v = g->d_tot_v; t->tot_p = g->tot_p; t->tot_q = g->tot_q; t->tot_extend = g->tot_extend;
+    t->tot_thr_version = g->tot_thr_version; t->thr_version = g->thr_version; t->tot_failed = g->tot_failed;
+    t->d_utot = g->d_utot; t->utot_wo = g->utot_wo; t->utot_wp = g->utot_wp; t->utot_failed = g->utot_failed;
+    t->d_wb = g->d_wb; t->d_wpq = g->d_wpq; t->d_wdl = g->d_wdl; t->d_wl_dprev = g->d_wl_dprev; t->d_wl_off = g->d_wl_off;
+    t->d_wedge_row = g->d_wedge_row; t->d_wp1 = g->d_wp1; t->d_wck_off = g->d_wck_off; t->d_wck = g->d_wck; t->wdl_cap = g->wdl_cap;
+    t->wck_cap = g->wck_cap; t->wl_p = g->wl_p; t->wl_q = g->wl_q; t->wl_extend = g->wl_extend; t->wl_thr_version = g->wl_thr_version;
+    t->wl_failed = g->wl_failed;
+}
+
+static void add_stats(pw_stats &total, const pw_stats &st, bool side_by_side) {
+    total.total_steps += st.total_steps; total.overflow_reads += st.overflow_reads; total.clamped_reads += st.clamped_reads;
+    total.dead_end_walks += st.dead_end_walks; total.repair_rounds += st.repair_rounds;
+    if (side_by_side) {
+        total.walk_kernel_ms = std::max(total.walk_kernel_ms, st.walk_kernel_ms); total.rng_kernel_ms = std::max(total.rng_kernel_ms, st.rng_kernel_ms);
+        total.lane_kernel_ms = std::max(total.lane_kernel_ms, st.lane_kernel_ms); total.lane_rounds = std::max(total.lane_rounds, st.lane_rounds);
+        total.param_index_ms = std::max(total.param_index_ms, st.param_index_ms);
+    } else {
+        total.walk_kernel_ms += st.walk_kernel_ms; total.rng_kernel_ms += st.rng_kernel_ms; total.lane_kernel_ms += st.lane_kernel_ms;
+        total.lane_rounds += st.lane_rounds; total.param_index_ms += st.param_index_ms;
+    }
+    total.walk_kernel_launches += st.walk_kernel_launches; total.stream_addressing |= st.stream_addressing;
+    total.redo_walks += st.redo_walks; total.list_entries_read += st.list_entries_read; total.ambiguous_steps += st.ambiguous_steps;
+    total.wave_chain_steps += st.wave_chain_steps; total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch;
+    total.verify_dropped += st.verify_dropped; total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
+}
+
+static int simulate_twin(pw_graph *g, int mode, double p, double q, int extend, const uint32_t *d_starts, uint64_t n_jobs,
+                         uint32_t walk_length, uint32_t seed, uint64_t stream_skip, uint32_t *d_out, pw_stats *stats) {
+    if (set_device(g)) return PW_ERR_HIP;
+    if (!g->twin) g->twin = make_twin(g);
+    pw_graph *t = g->twin;
+    if (!t) return simulate_device_impl(g, mode, p, q, extend, d_starts, n_jobs, walk_length, 1, seed, stream_skip, d_out, stats);
+    if (g->counters.ensure(N_COUNTERS)) return PW_ERR_NOMEM;
+    { int rcs = check_starts(g, d_starts, n_jobs); if (rcs) return rcs; }
+    const uint64_t half = n_jobs / 2;
+    const size_t W = (size_t)walk_length + 2;
+    uint64_t nominal_a = 0;
+    int rc = compute_offsets(g, d_starts, nullptr, walk_length, half, stream_skip, false, &nominal_a, nullptr);
+    if (rc) return rc;
+    pw_stats sa, sb;
+    memset(&sa, 0, sizeof(sa));
+    memset(&sb, 0, sizeof(sb));
+    std::promise<bool> ready;
+    std::future<bool> ready_f = ready.get_future();
+    bool signalled = false;
+    g->on_tables_ready = [&]() { twin_share(t, g); signalled = true; ready.set_value(true); };
+    int rc_b = 0;
+    std::string err_b;
+    std::thread tb;
+    auto run_b = [&](uint64_t skip_b) {
+        (void)hipSetDevice(t->device);
+        rc_b = simulate_device_impl(t, mode, p, q, extend, d_starts + half, n_jobs - half, walk_length, 1, seed, skip_b, d_out + half * W, &sb);
+        if (rc_b) err_b = g_err;
+    };
+    bool threaded = true;
+    try {
+        tb = std::thread([&]() { if (ready_f.get()) run_b(stream_skip + nominal_a); });
+    } catch (const std::system_error &) { threaded = false; }
+    rc = simulate_device_impl(g, mode, p, q, extend, d_starts, half, walk_length, 1, seed, stream_skip, d_out, &sa);
+    g->on_tables_ready = nullptr;
+    if (!signalled) ready.set_value(false);     // (the first half failed before its tables were in place: the second is not walked)
+    if (threaded) tb.join();
+    else if (!rc) { twin_share(t, g); run_b(stream_skip + nominal_a); }   // (no thread to be had: one half after the other)
+    if (rc) return rc;
+    if (rc_b) return fail(rc_b, err_b);
+    if (sa.total_steps != nominal_a && !sa.stream_addressing) {   // dead ends in the first half: the second starts earlier in the stream
+        twin_share(t, g);
+        run_b(stream_skip + sa.total_steps);
+        if (rc_b) return fail(rc_b, err_b);
+    }
+    if (stats) { *stats = sa; add_stats(*stats, sb, true); }
+    return PW_OK;
+}
+
+PW_EXPORT int pw_simulate_device(pw_graph *g, int mode, double p, double q, int extend,
+                                 const uint32_t *d_starts, uint64_t n_jobs, uint32_t walk_length,
+                                 int has_seed, uint32_t seed, uint64_t stream_skip, uint32_t *d_out,
+                                 pw_stats *stats) {
+    // weighted CSR graphs on the lane index, whole job arrays of a million walks or more: two halves side by side (above)
+    if (g && !g->alias && g->kind == 0 && !g->unit && g->d_lines && !g->lanes_off && mode == PW_MODE_SPARSE_OTF && n_jobs >= (1ull << 20) &&
+        d_starts && d_out && walk_length >= 1 && p > 0 && q > 0 && (!extend || g->d_thr) && !getenv("PECANPY_AMD_NO_TWIN") &&
+        !getenv("PECANPY_AMD_NO_LANES") && !getenv("PECANPY_AMD_NO_WLANES") && !getenv("PECANPY_AMD_NO_CHAIN_QUEUE")) {
+        if (!has_seed) seed = os_seed();
+        return simulate_twin(g, mode, p, q, extend, d_starts, n_jobs, walk_length, seed, stream_skip, d_out, stats);
+    }
+    return simulate_device_impl(g, mode, p, q, extend, d_starts, n_jobs, walk_length, has_seed, seed, stream_skip, d_out, stats);
 }
 
 // Device -> pageable host copy through a ring of pinned staging buffers (a plain hipMemcpy to pageable memory runs at

@@ -460,3 +460,64 @@ def test_weighted_lane_form_on_a_directed_graph_with_dead_ends(monkeypatch):
             assert eng.last_stats["lane_kernel"] == 0 and eng.last_stats["stream_addressing"] == st["stream_addressing"]
             monkeypatch.delenv("PECANPY_AMD_NO_WLANES")
             assert np.array_equal(got, wave), (sinks, p, q)
+
+
+def test_weighted_halves_on_twin_contexts_equal_one_context(monkeypatch):
+    """Round 6: weighted job arrays of a million walks or more are walked as two halves on two call contexts of the same
+    handle (graph, index and per-(p, q) tables shared), so that one half's eager kernel runs beside the other half's lane
+    round.  Same walks as one context (PECANPY_AMD_NO_TWIN=1) and as the oracle -- node2vec and node2vec+, and on a DIRECTED
+    weighted graph whose dead ends in the first half move the second half's place in the stream."""
+    import torch
+
+    from oracle import pyoracle as orc
+    from pecanpy_amd import pecanpy as node2vec
+    from pecanpy_amd.synth import csr_from_edges, hash_edge_weights
+
+    indptr, indices, data = rmat_csr(16, seed=6, weighted=True)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 17)           # 1.1 M jobs
+    np.random.RandomState(3).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    g = node2vec.SparseOTF.from_csr(indptr, indices, data, extend=True, gamma=0)
+    with np.errstate(all="ignore"):
+        thr = np.nan_to_num(g.get_noise_thresholds(), nan=0.0)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    eng.set_thresholds(thr)
+    for extend in (False, True):
+        a = eng.simulate_device("SparseOTF", 0.5, 2.0, extend, d_starts, 40, seed=4)
+        sa = dict(eng.last_stats)
+        monkeypatch.setenv("PECANPY_AMD_NO_TWIN", "1")
+        b = eng.simulate_device("SparseOTF", 0.5, 2.0, extend, d_starts, 40, seed=4)
+        sb = dict(eng.last_stats)
+        monkeypatch.delenv("PECANPY_AMD_NO_TWIN")
+        assert torch.equal(a, b), extend
+        assert sa["lane_kernel"] == 3 and sb["lane_kernel"] == 3
+        assert (sa["total_steps"], sa["overflow_reads"], sa["eager_steps"]) == (sb["total_steps"], sb["overflow_reads"], sb["eager_steps"])
+        want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2.0, starts[:1500], 40, 4, thr=thr if extend else None)
+        assert np.array_equal(a[:1500].cpu().numpy().view(np.uint32), want), extend
+    # the last rows (second half, second context) against the oracle at their stream offset
+    full_steps = (a[:, -1].long() - 1).cumsum(0)
+    k = starts.size - 800
+    skip = int(full_steps[k - 1].item())
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2.0, starts[k:], 40, 4, thr=thr, stream_skip=skip)
+    assert np.array_equal(a[k:].cpu().numpy().view(np.uint32), want)
+    # directed + weighted, sinks
+    rng = np.random.default_rng(2)
+    m = 1 << 16
+    src, dst = rng.integers(0, m, 1 << 20), rng.integers(0, m, 1 << 20)
+    keep = (src != dst) & (src % 64 != 0)
+    ip, ix, _ = csr_from_edges(src[keep], dst[keep], m)
+    w = hash_edge_weights(ip, ix, 5)
+    st2 = np.concatenate([np.arange(m, dtype=np.uint32)] * 17)
+    np.random.RandomState(1).shuffle(st2)
+    d2 = torch.from_numpy(st2.view(np.int32)).cuda()
+    e2 = WalkEngine.from_csr(ip, ix, w)
+    a = e2.simulate_device("SparseOTF", 0.5, 2.0, False, d2, 20, seed=7)
+    sa = dict(e2.last_stats)
+    monkeypatch.setenv("PECANPY_AMD_NO_TWIN", "1")
+    b = e2.simulate_device("SparseOTF", 0.5, 2.0, False, d2, 20, seed=7)
+    monkeypatch.delenv("PECANPY_AMD_NO_TWIN")
+    assert torch.equal(a, b) and sa["dead_end_walks"] > 0 and sa["stream_addressing"] == 0
+    assert sa["total_steps"] == e2.last_stats["total_steps"]
+    want = orc.walks_sparse_otf(ip, ix, w, 0.5, 2.0, st2[:1500], 20, 7)
+    assert np.array_equal(a[:1500].cpu().numpy().view(np.uint32), want)

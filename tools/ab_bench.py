@@ -53,13 +53,14 @@ def child(args):
     out = torch.empty((starts.size, args.walk_length + 2), dtype=torch.int32, device="cuda")
     res = {"lib": os.path.basename(os.environ.get("PECANPY_AMD_LIB", "libpecanpy_amd.so")), "create_wall_ms": round(create_wall, 1),
            "index_build_ms": round(info["build_ms"], 1), "index_GB": round(info["index_bytes"] / 1e9, 2), "passes": []}
+    if args.chunks > 1:
+        from pecanpy_amd.engine import tapered_bounds
+
+        csum = np.concatenate([[0], np.cumsum(has_sh if args.shard else (indptr[1:] != indptr[:-1])[starts], dtype=np.int64)])
     for k in range(args.passes + 1):
         torch.cuda.synchronize()
         t = time.perf_counter()
         if args.chunks > 1:              # tapered chunks, each its own call (what a rank does while chunk c travels): sum of the calls
-            from pecanpy_amd.engine import tapered_bounds
-
-            csum = np.concatenate([[0], np.cumsum(has_sh if args.shard else (indptr[1:] != indptr[:-1])[starts], dtype=np.int64)])
             if args.hold:
                 eng.stream_hold(k, skip, int(csum[-1]) * args.walk_length)
             agg = None
