@@ -337,6 +337,11 @@ int pw_selftest_lane_floats(int on_device, int device, const uint8_t *cls, uint3
  * reference's position (n: never reached).  Fails when a k_safe lies beyond the reference's position. */
 int pw_selftest_lane_unit_bounded(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
                                   uint32_t *chain, uint32_t *lane);
+/* ... with the interval decision of round 6 in front of the chain (csrc/seqscan.h: lane_tight_values -- the float32 chain's
+ * systematic drift bounded from the class counts the bounded decision already has, for arbitrary float32 values):
+ * tight[i] = lane[i] when that is a verdict, else the interval decision's position or 0xfffffffd (left to the float chain). */
+int pw_selftest_lane_unit_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                                uint32_t *chain, uint32_t *lane, uint32_t *tight);
 /* The lane kernel's decision for WEIGHTED rows (csrc/seqscan.h: lane_decide_weighted: float64 prefix sums of the step's
  * values with a rigorous bound on the float32 chain's drift), host only.  vals[k] = the step's value of neighbour k
  * before normalisation (what get_normalized_probs holds at sparse_rw.py:87 / :126), base[k] = its value as a plain

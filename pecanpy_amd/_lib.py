@@ -106,6 +106,7 @@ SYMBOLS = {
     "pw_selftest_lane_floats": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "pw_selftest_lane_unit_bounded": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pw_selftest_lane_unit_tight": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pw_selftest_lane_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pw_selftest_exact_decision_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p,
                                                  C.c_uint32, C.c_void_p, C.c_void_p]),

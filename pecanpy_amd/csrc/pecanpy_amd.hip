@@ -1910,6 +1910,30 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
     la.ver_count = g->counters.p + 40;
     la.susp_chunk = 1;
     if (g->d_utot && g->utot_wo == wa.w_out && g->utot_wp == wa.w_prev && !getenv("PECANPY_AMD_NO_UTOT")) la.tot_e = g->d_utot;   // (ensure_unit_tot)
+    // verification of the interval decision (round 6: lane_tight_values), as in launch_lane_walks: every settled step in test
+    // mode (PECANPY_AMD_VERIFY_TIGHT=1), a sample of them in production (PECANPY_AMD_VERIFY_SAMPLE=N, default 1024, 0 = off)
+    const char *ver_env = getenv("PECANPY_AMD_VERIFY_TIGHT");
+    const bool verify_full = ver_env != nullptr && la.tot_e != nullptr;
+    uint32_t sample_n = 1024;
+    if (const char *se = getenv("PECANPY_AMD_VERIFY_SAMPLE")) sample_n = (uint32_t)strtoul(se, nullptr, 10);
+    if (sample_n & (sample_n - 1)) { uint32_t pw2 = 1; while (pw2 * 2 <= sample_n) pw2 *= 2; sample_n = pw2; }
+    const bool verify_sample = !verify_full && la.tot_e != nullptr && sample_n > 0;
+    const bool verify = verify_full || verify_sample;
+    const uint32_t VER_JOBS_CAP = 65536;
+    if (verify) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        uint64_t cap = verify_full ? n_work * (uint64_t)wa.L + 4096 : n_work * (uint64_t)wa.L / sample_n / 2 + 65536;
+        const uint64_t lim = free_b / 2 / sizeof(pw::VerRec);
+        if (cap > g->ver.cap && cap > lim) cap = lim > g->ver.cap ? lim : g->ver.cap;
+        if (const char *cap_env = getenv("PECANPY_AMD_VERIFY_CAP")) cap = (uint64_t)strtoull(cap_env, nullptr, 10);
+        if (g->ver.ensure(cap) || g->ver_bad.ensure(16) || g->ver_jobs.ensure(VER_JOBS_CAP)) return PW_ERR_NOMEM;
+        la.ver = g->ver.p;
+        la.ver_cap = cap;
+        la.ver_mask = verify_full ? 0u : sample_n - 1u;
+        la.ver_poison = ((verify_full && strcmp(ver_env, "poison") == 0) || (verify_sample && getenv("PECANPY_AMD_VERIFY_SAMPLE_POISON"))) ? 1u : 0u;
+        HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 8 * sizeof(unsigned long long), g->stream));
+    }
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)pw::walk_lanes_kernel<true, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ < 1) occ = 1;
@@ -1926,16 +1950,52 @@ static int launch_lane_float_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_re
     HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
     HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
     HIP_TRY(hipEventRecord(g->ev[4], g->stream));
-    hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, true>), dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+    if (verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<true, true, true>), dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
+    else hipLaunchKernelGGL((pw::walk_lanes_kernel<true, false, true>), dim3((unsigned)grid), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, la);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
-    unsigned long long nr = 0;
+    unsigned long long nr = 0, n_rec = 0;
+    if (verify) HIP_TRY(hipMemcpyAsync(&n_rec, g->counters.p + 40, sizeof(n_rec), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    unsigned long long vs[4] = {0, 0, 0, 0};
+    if (verify && n_rec) {   // the recorded steps, decided again by the float chain over the whole row
+        const unsigned long long n_chk = n_rec < la.ver_cap ? n_rec : la.ver_cap;
+        g->ver_dropped += n_rec - n_chk;
+        hipLaunchKernelGGL(pw::lanes_verify_kernel, dim3((unsigned)((n_chk + 255) / 256)), dim3(256), 0, g->stream, g->ver.p, (uint64_t)n_chk,
+                           g->d_lines, g->d_clist, wa.w_prev, g->counters.p + 44, g->ver_bad.p, 16u, g->ver_jobs.p, VER_JOBS_CAP, 1u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(vs, g->counters.p + 44, sizeof(vs), hipMemcpyDeviceToHost, g->stream));
+    }
+    HIP_TRY(hipEventRecord(g->ev[5], g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, g->ev[4], g->ev[5]));
     g->lane_ms += ms;
     g->lane_rounds++;
+    if (verify_full) g->ver.release();
+    if (verify) {
+        g->ver_checked += vs[0];
+        g->ver_mismatch += vs[1];
+        g->ver_ties += vs[2];
+        if (vs[1]) {
+            pw::VerRec bad[16];
+            const unsigned nb = vs[3] < 16 ? (unsigned)vs[3] : 16u;
+            HIP_TRY(hipMemcpy(bad, g->ver_bad.p, sizeof(pw::VerRec) * nb, hipMemcpyDeviceToHost));
+            for (unsigned i = 0; i < nb && (verify_full || getenv("PW_DEBUG_ROUNDS")); i++)
+                fprintf(stderr, "[verify] MISMATCH (FLOATS) d=%u n_in=%u pp=%u tot=%.9g wo=%g r=%.17g: interval decision %u, float chain %u\n",
+                        bad[i].d, bad[i].n_in, bad[i].pp, (double)bad[i].tot, (double)bad[i].wo, bad[i].r, bad[i].choice, bad[i].job);
+            if (verify_sample) {   // the affected walks again, by the complete kernel (as in launch_lane_walks)
+                pw::WalkArgs wr = wa;
+                wr.job_list = g->ver_jobs.p;
+                wr.n_list = vs[3] < VER_JOBS_CAP ? vs[3] : VER_JOBS_CAP;
+                wr.resume = 0;
+                wr.stats = g->counters.p + 20;
+                int rcw = launch_wave_walks(g, wr, false);
+                if (rcw) return rcw;
+                HIP_TRY(hipStreamSynchronize(g->stream));
+            }
+        }
+    }
     *n_redo = nr;
     return 0;
 }
@@ -2636,24 +2696,16 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     if (!g || (n_jobs && (!starts || !out))) return fail(PW_ERR_INVALID, "null pointer");
     if (set_device(g)) return PW_ERR_HIP;
     uint32_t *d_starts = nullptr, *d_out = nullptr;
-    size_t out_elems = (size_t)n_jobs * ((size_t)walk_length + 2);
     const bool dbg = getenv("PECANPY_AMD_COPY_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
-    hipError_t e = hipMalloc((void **)&d_out, sizeof(uint32_t) * (out_elems ? out_elems : 1));
-    if (e != hipSuccess) { (void)hipFree(d_starts); return fail(PW_ERR_NOMEM, hipGetErrorString(e)); }
-    int rc = 0;
-    const double t1 = now();
-    e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
-    const double t2 = now();
     // The matrix leaves the device at the PCIe rate (RMAT-18: 17 ms for 0.86 GB against 13 ms of walks): large job arrays
     // are walked in PARTS and the copy of part k (helper thread, copy stream, pinned staging) runs under the kernels of
-    // part k + 1 (the copy is the longer of the two: one chunked copy follows the parts, the link stays busy throughout).  Part k + 1's
+    // part k + 1 (the copy is the longer of the two: the link stays busy throughout).  Part k + 1's
     // stream address = draws the earlier parts ACTUALLY consumed; every part's addressing is exact (the block-wise repair of
     // pw_simulate_device), so the walks are those of one call whatever the split (dead ends included).  Alias modes consume a variable number of words per step: one part.
-    const size_t row_bytes = sizeof(uint32_t) * ((size_t)walk_length + 2);
+    const size_t W = (size_t)walk_length + 2;
+    const size_t row_bytes = sizeof(uint32_t) * W;
     int n_parts = 1;
     // (the first part's walks are the only ones the copy does not hide: more parts while a part stays a launch worth making --
     //  RMAT-18, 0.86 GB: 4 / 8 / 16 parts -> 22.7 / 21.5 / 29.0 ms per call)
@@ -2664,23 +2716,42 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     //  fell back would own slots up to skip + nominal while the next part started at skip + actual; exact addressing, the
     //  default, makes the walks those of one call whatever the split)
     if (env_on("PECANPY_AMD_NOMINAL_STREAM")) n_parts = 1;
+    if ((uint64_t)n_parts > n_jobs) n_parts = 1;
     if (!has_seed && n_parts > 1) { seed = os_seed(); has_seed = 1; }   // (every part walks the same stream)
+    // RING (round 6): from 8 parts on the device never holds the whole matrix -- three part-sized buffers take the parts in turn
+    // (part k walks into buffer k % 3 once part k - 3 has left it) and every part expands its own stretch of the stream: an RMAT-22
+    // call touches 5.2 + 1.6 GB of device memory instead of 13.8 + 12.9 GB.  On a fresh box, where memory nobody has used costs
+    // ~23 ms per GB of hipMalloc, that is the difference between 690 and ~450 ms for a call whose floor is 250 ms of PCIe; the
+    // per-part jump-ahead trees (~3 ms each) run under the copy, which is the longer leg.  PECANPY_AMD_NO_RING=1: whole matrix.
+    const bool ring = n_parts >= 8 && !getenv("PECANPY_AMD_NO_RING");
+    constexpr int R = 3;
+    const uint64_t part_rows = (n_jobs + (uint64_t)n_parts - 1) / (uint64_t)n_parts + 1;
+    const size_t out_elems = ring ? (size_t)R * part_rows * W : (size_t)n_jobs * W;
+    HIP_TRY(hipMalloc((void **)&d_starts, sizeof(uint32_t) * (n_jobs ? n_jobs : 1)));
+    hipError_t e = hipMalloc((void **)&d_out, sizeof(uint32_t) * (out_elems ? out_elems : 1));
+    if (e != hipSuccess) { (void)hipFree(d_starts); return fail(PW_ERR_NOMEM, hipGetErrorString(e)); }
+    int rc = 0;
+    const double t1 = now();
+    e = hipMemcpy(d_starts, starts, sizeof(uint32_t) * n_jobs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(PW_ERR_HIP, hipGetErrorString(e));
+    const double t2 = now();
     pw_stats total;
     memset(&total, 0, sizeof(total));
-    CopyFeed feed;
+    CopyFeed feed, drained;            // feed: parts walked (ring) / bytes final (whole matrix); drained: parts copied out (ring)
     std::thread copier;
     bool copy_inline = false;
     int copy_rc = 0;
     std::string copy_err;
     uint64_t skip = stream_skip;
-    // the draws of the whole array, expanded once (a part's range -- offset by what the earlier parts consumed, never more
-    // than their nominal share -- lies inside): one jump tree instead of one per part
+    auto part_lo = [&](int part) { return (uint64_t)part * n_jobs / (uint64_t)n_parts; };
+    // whole-matrix form: the draws of the whole array, expanded once (a part's range -- offset by what the earlier parts
+    // consumed, never more than their nominal share -- lies inside): one jump tree instead of one per part
     struct HoldGuard {
         pw_graph *g;
         bool mine;
         ~HoldGuard() { if (mine) g->rng_hold.valid = false; }
     } hold_guard{g, false};
-    if (!rc && n_parts > 1) {
+    if (!rc && n_parts > 1 && !ring) {
         g->rng_hold.valid = false;        // (a caller's pw_stream_hold ends here: this call expands the stream of its own array)
         g->rng_hold.user = false;
         hold_guard.mine = true;
@@ -2698,47 +2769,54 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
             g->rng_hold.n_blocks = (stream_skip + nominal + 311) / 312 > base / 312 ? (stream_skip + nominal + 311) / 312 - base / 312 : 1;
         }
     }
+    const bool held = g->rng_hold.valid && hold_guard.mine;
+    auto copy_job = [&]() {
+        (void)hipSetDevice(g->device);
+        if (!ring) {
+            copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
+        } else {
+            for (int part = 0; part < n_parts && !copy_rc; part++) {
+                if (!feed.have((size_t)part + 1, true)) break;             // (the walker gave up: its error is the call's)
+                const uint64_t lo = part_lo(part), hi = part_lo(part + 1);
+                copy_rc = copy_out_staged(g, out + lo * W, d_out + (size_t)(part % R) * part_rows * W, (size_t)(hi - lo) * row_bytes, nullptr);
+                if (!copy_rc) drained.announce((size_t)part + 1);
+            }
+        }
+        if (copy_rc) { copy_err = g_err; drained.stop(); }     // (g_err is thread local: carried over below)
+    };
     for (int part = 0; part < n_parts && !rc; part++) {
-        const uint64_t lo = (uint64_t)part * n_jobs / n_parts, hi = (uint64_t)(part + 1) * n_jobs / n_parts;
+        const uint64_t lo = part_lo(part), hi = part_lo(part + 1);
+        if (ring && part >= R && !copy_inline && !drained.have((size_t)(part - R) + 1, true)) break;   // (the copy failed: its error is the call's)
         pw_stats st;
         memset(&st, 0, sizeof(st));
-        rc = pw_simulate_device(g, mode, p, q, extend, d_starts + lo, hi - lo, walk_length, has_seed, seed, skip,
-                                d_out + lo * ((size_t)walk_length + 2), &st);
+        uint32_t *dst = ring ? d_out + (size_t)(part % R) * part_rows * W : d_out + lo * W;
+        rc = pw_simulate_device(g, mode, p, q, extend, d_starts + lo, hi - lo, walk_length, has_seed, seed, skip, dst, &st);
         if (rc) break;
         skip += st.total_steps;
         if (part == 0) total = st;
-        else {
-            total.total_steps += st.total_steps; total.overflow_reads += st.overflow_reads; total.clamped_reads += st.clamped_reads;
-            total.dead_end_walks += st.dead_end_walks; total.repair_rounds += st.repair_rounds; total.walk_kernel_ms += st.walk_kernel_ms;
-            total.rng_kernel_ms += st.rng_kernel_ms; total.walk_kernel_launches += st.walk_kernel_launches;
-            total.stream_addressing |= st.stream_addressing; total.lane_rounds += st.lane_rounds; total.redo_walks += st.redo_walks;
-            total.list_entries_read += st.list_entries_read; total.ambiguous_steps += st.ambiguous_steps;
-            total.lane_kernel_ms += st.lane_kernel_ms; total.wave_chain_steps += st.wave_chain_steps; total.param_index_ms += st.param_index_ms;
-            total.verify_checked += st.verify_checked; total.verify_mismatch += st.verify_mismatch; total.verify_dropped += st.verify_dropped;
-            total.verify_ties += st.verify_ties; total.eager_steps += st.eager_steps;
-        }
-        if (!copier.joinable() && !copy_inline) {      // (ONE copy for all parts: it follows the rows announced below)
+        else add_stats(total, st, false);
+        if (!copier.joinable() && !copy_inline) {      // (ONE copy thread for all parts: it follows what is announced below)
             try {
-                copier = std::thread([&]() {
-                    (void)hipSetDevice(g->device);
-                    copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
-                    if (copy_rc) copy_err = g_err;     // (g_err is thread local: carried over below)
-                });
-            } catch (const std::system_error &) {      // (thread limit of the process: the copy runs on this thread, after the parts)
+                copier = std::thread(copy_job);
+            } catch (const std::system_error &) {      // (thread limit of the process: the copy runs on this thread)
                 copy_inline = true;
             }
         }
-        feed.announce((size_t)hi * row_bytes);
+        feed.announce(ring ? (size_t)part + 1 : (size_t)hi * row_bytes);
+        if (ring && copy_inline) {                     // (no thread: every part is copied out before the next one is walked)
+            const int c = copy_out_staged(g, out + lo * W, dst, (size_t)(hi - lo) * row_bytes, nullptr);
+            if (c) rc = c;
+        }
     }
     if (rc) feed.stop();
     const double t3 = now();
     if (copier.joinable()) copier.join();
-    else if (!rc && copy_inline) {
+    else if (!rc && copy_inline && !ring) {
         copy_rc = copy_out_staged(g, out, d_out, (size_t)n_jobs * row_bytes, &feed);
         if (copy_rc) copy_err = g_err;
     }
     if (!rc && copy_rc) rc = fail(copy_rc, copy_err);
-    if (!rc && g->rng_hold.valid) {   // (the parts found their draws in place: the one expansion is the call's generator time)
+    if (!rc && held) {   // (the parts found their draws in place: the one expansion is the call's generator time)
         float ms = 0;
         if (hipEventElapsedTime(&ms, g->ev[7], g->ev[6]) == hipSuccess) total.rng_kernel_ms += ms;
     }
@@ -2746,8 +2824,8 @@ PW_EXPORT int pw_simulate(pw_graph *g, int mode, double p, double q, int extend,
     const double t4 = now();
     (void)hipFree(d_starts);
     (void)hipFree(d_out);
-    if (dbg) fprintf(stderr, "[pw_simulate] alloc %.1f ms, starts in %.1f, walks %.1f, matrix out %.1f, free %.1f\n", (t1 - t0) * 1e3,
-                     (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
+    if (dbg) fprintf(stderr, "[pw_simulate] alloc %.1f ms, starts in %.1f, walks %.1f, matrix out %.1f, free %.1f (%d parts%s)\n", (t1 - t0) * 1e3,
+                     (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3, n_parts, ring ? ", ring of 3 buffers" : "");
     return rc;
 }
 
@@ -3429,6 +3507,42 @@ PW_EXPORT int pw_selftest_lane_unit_bounded(const uint8_t *cls, uint32_t n, floa
         if (lane[i] > n && lane[i] != pw::LANE_AMBIGUOUS) return fail(PW_ERR_INVALID, "unexpected verdict");
         if (ks > lo) return fail(PW_ERR_INVALID, "k_safe beyond the reference's position");
     }
+    return PW_OK;
+}
+
+// The FLOATS step with the interval decision in front of the chain (round 6): lane[i] = lane_decide_unit_bounded's verdict,
+// tight[i] = that verdict when it is one, else lane_tight_values' (position, or 0xfffffffd: left to the float chain).
+PW_EXPORT int pw_selftest_lane_unit_tight(const uint8_t *cls, uint32_t n, float w_out, float w_prev, const double *r, uint32_t n_r,
+                                          uint32_t *chain, uint32_t *lane, uint32_t *tight) {
+    if (!cls || !r || !chain || !lane || !tight || n == 0) return fail(PW_ERR_INVALID, "bad argument");
+    LaneRow row;
+    int rc = lane_row_setup(cls, n, w_out, w_prev, row, false);
+    if (rc) return rc;
+    float tot = 0.0f;
+    for (uint32_t k = 0; k < n; k++) tot = tot + (cls[k] == 1 ? 1.0f : (cls[k] == 0 ? w_out : w_prev));
+    const float x_in = 1.0f / tot, x_out = w_out / tot, x_prev = w_prev / tot;
+    std::vector<float> c(n);
+    float acc = 0.0f;
+    for (uint32_t k = 0; k < n; k++) { acc = acc + (cls[k] == 1 ? x_in : (cls[k] == 0 ? x_out : x_prev)); c[k] = acc; }
+    for (uint32_t i = 0; i < n_r; i++) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((double)c[mid] >= r[i]) hi = mid; else lo = mid + 1; }
+        chain[i] = lo;
+        uint32_t probes = 0, ks = 0;
+        pw::BoundedAmb amb;
+        lane[i] = pw::lane_decide_unit_bounded(n, row.n_cl, row.pp, r[i], tot, w_out, w_prev, row.view(), probes, ks, &amb);
+        if (lane[i] > n && lane[i] != pw::LANE_AMBIGUOUS) return fail(PW_ERR_INVALID, "unexpected verdict");
+        if (ks > lo) return fail(PW_ERR_INVALID, "k_safe beyond the reference's position");
+        tight[i] = lane[i];
+        if (lane[i] == pw::LANE_AMBIGUOUS && ks > 0) tight[i] = pw::lane_tight_values(n, row.pp, r[i], x_in, x_out, x_prev, ks, amb.f, amb.p_next, amb.z_abs);
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (getenv("PW_TIGHT_STATS")) {
+        fprintf(stderr, "tight bail reasons:");
+        for (int k = 1; k < 24; k++) if (pw::g_tight_reason[k]) fprintf(stderr, " [%d]=%llu", k, (unsigned long long)pw::g_tight_reason[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return PW_OK;
 }
 

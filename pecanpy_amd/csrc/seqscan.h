@@ -641,12 +641,20 @@ struct BoundedEval {   // upper bound of the chain at the common neighbour i (po
 };
 typedef BoundedEval<WeightedRow> WeightedEval;
 
+// What a step left open by the bound knows about itself (round 6: input of the interval decision lane_tight_values):
+// f = common neighbours at positions below k_safe, p_next = position of the first common neighbour at or after k_safe
+// (0xffffffff: none), z_abs = bound on | c_{k_safe - 1} - (real sum of the chain's values before k_safe) |.
+struct BoundedAmb {
+    uint32_t f, p_next;
+    double z_abs;
+};
 // k_safe (out): every partial sum before element k_safe is known to stay below r -- a step left open can start its exact
 // scan there (from the recorded chain value before it: walk_sparse.hip.h, CHAIN_CKPT) instead of at element 0.
 template <class Row>
 PW_HD uint32_t lane_decide_bounded(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const Row &wr,
-                                   const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+                                   const ListView &cl, uint32_t &probes, uint32_t &k_safe, BoundedAmb *amb = nullptr) {
     k_safe = 0;
+    if (amb) { amb->f = 0; amb->p_next = 0xffffffffu; amb->z_abs = 0.0; }
     if (!(tot > 0.0f) || d == 0u) return LANE_REDO;
     const double inv = 1.0 / (double)tot;
     const uint64_t tbits = FloatTraits<double>::bits(r > 0.0 ? r : 0.0);
@@ -682,7 +690,18 @@ PW_HD uint32_t lane_decide_bounded(uint32_t d, uint32_t n_in, uint32_t pp, doubl
     k_safe = k1;                                           // (c_j <= c_{k1 - 1} < r for every j < k1: the chain is monotone)
     if (k1 >= d) return d;                                 // never reached: the mirrored overflow read (choice == degree)
     const uint32_t commons = (k1 == ke && f < n_in) ? f + 1u : f;
-    if (!(lo_of(k1, sum_at(k1, commons), commons) >= r)) return LANE_AMBIGUOUS;
+    if (!(lo_of(k1, sum_at(k1, commons), commons) >= r)) {
+        if (amb && k1 > 0u) {
+            // c_{k1 - 1} lies within margin / tot of S(k1 - 1) / tot, and the real sum of the chain's VALUES fl32(w / tot) within
+            // 2^-24 relative of that quotient (every value is rounded once, all are positive)
+            const uint32_t kp = k1 - 1u;
+            const double S = sum_at(kp, f);
+            amb->f = f;
+            amb->p_next = f < n_in ? ke : 0xffffffffu;
+            amb->z_abs = (wr.margin(kp, f, pp, S) + S * (1.001 / 16777216.0)) * inv + 3e-45 * ((double)kp + 1.0);
+        }
+        return LANE_AMBIGUOUS;
+    }
     return k1;
 }
 PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, const WeightedRow &wr,
@@ -692,9 +711,9 @@ PW_HD uint32_t lane_decide_weighted(uint32_t d, uint32_t n_in, uint32_t pp, doub
 // ... for a unit-weight row: w_out = fl32(1/q) (1.0f on the first step of a walk), w_prev = fl32(1/p), tot = the reference's
 // sequential float32 row total (w.sum(), sparse_rw.py:89)
 PW_HD uint32_t lane_decide_unit_bounded(uint32_t d, uint32_t n_in, uint32_t pp, double r, float tot, float w_out, float w_prev,
-                                        const ListView &cl, uint32_t &probes, uint32_t &k_safe) {
+                                        const ListView &cl, uint32_t &probes, uint32_t &k_safe, BoundedAmb *amb = nullptr) {
     const UnitPrefixRow row{(double)w_out, 1.0 - (double)w_out, pp != 0xffffffffu ? (double)w_prev - (double)w_out : 0.0};
-    return lane_decide_bounded(d, n_in, pp, r, tot, row, cl, probes, k_safe);
+    return lane_decide_bounded(d, n_in, pp, r, tot, row, cl, probes, k_safe, amb);
 }
 
 // ---- the float32 chain itself, evaluated by ONE thread (lane kernel, ambiguous steps) ---------------------------
@@ -981,6 +1000,8 @@ PW_HD float fast_rcp(float x) {
 // Arithmetic: everything is kept in ULPS OF THE TOP BINADE as float32 (errors of binade e_t - j scale by 2^-j), the
 // exact mass value v0 = E0 * x_unit as a 48-bit integer product split into its integer significand V and a fraction;
 // float32 roundings of the interval's terms are covered by a 2^-20 relative allowance on their magnitudes.
+PW_HD uint32_t lane_tight_tail(uint32_t pp, double r, float x_in, float x_out, float x_pv, uint32_t k1, uint32_t i1, uint32_t pv0,
+                               uint32_t kend, uint32_t p_f, int e_t, uint32_t V, float fr, float voff, float Z, float upu);
 PW_HD uint32_t lane_tight(uint32_t d, uint32_t pp, double r, float w_out, float w_prev, const LaneStep &ls) {
     using B = Binade<float>;
     const uint32_t sh_in = ls.shifts & 0xffu, sh_out = (ls.shifts >> 8) & 0xffu, sh_prev = (ls.shifts >> 16) & 0xffu;
@@ -1020,6 +1041,17 @@ PW_HD uint32_t lane_tight(uint32_t d, uint32_t pp, double r, float w_out, float 
         const float zr = ((jb + 6.0f) * (R + wmax) - 0.5f * jb * (jb - 1.0f)) * (1.001f / 16777216.0f) + 1e-6f;
         Z = (1.01f * zr + 1.01f * (float)E0 * (1.0f / 16777216.0f) + 0.01f) * upu * 1.002f + 1.0f;
     }
+    return lane_tight_tail(pp, r, x_in, x_out, x_pv, k1, i1, pv0, kend, p_f, e_t, V, fr, voff, Z, upu);
+}
+
+// The value-generic part of the interval decision, shared by the dyadic form above (exact integer masses) and the FLOATS form
+// below (arbitrary float32 values): given the binade e_t of the exact sum v0 of the values before k1, its integer significand
+// V and fraction fr (v0 / ulp_t = V + fr, voff = V - 2^23), the a-priori bound Z on |c_{k1-1} - v0| in ulps of that binade and
+// the smallest element value in the same ulps (xmin_u: bounds the number of additions below the evaluated binades).
+PW_HD uint32_t lane_tight_tail(uint32_t pp, double r, float x_in, float x_out, float x_pv, uint32_t k1, uint32_t i1, uint32_t pv0,
+                               uint32_t kend, uint32_t p_f, int e_t, uint32_t V, float fr, float voff, float Z, float upu) {
+    using B = Binade<float>;
+    const bool has_pv = pp != 0xffffffffu;
     if (!(voff - Z >= 0.0f) || !(voff + Z + 2.0f < 8388608.0f)) TIGHT_BAIL(4);
     float xmax = x_in > x_out ? x_in : x_out;
     if (has_pv && x_pv > xmax) xmax = x_pv;
@@ -1133,6 +1165,43 @@ PW_HD uint32_t lane_tight(uint32_t d, uint32_t pp, double r, float w_out, float 
         pos = nxt + 1u;
     }
     TIGHT_BAIL(15);
+}
+
+// ---- the interval decision for ARBITRARY float32 values (round 6: the FLOATS form -- unit weights, 1/p or 1/q not a power of
+// two -- in front of its float chains).  The chain adds x_in = fl32(1 / tot), x_out = fl32(w_out / tot),
+// x_pv = fl32(w_prev / tot) (sparse_rw.py:89, pecanpy.py:556-557): three float32 numbers in no exact ratio, so there is no
+// integer mass -- but the drift argument above never needed one: it needs the REAL sum v0 of the values before k1 (two products
+// of a float32 by a count below 2^24 and one value: each exact in float64, their sum to 2^-52 relative, far below an ulp of the
+// float32 chain), the a-priori bound on |c_{k1-1} - v0| (lane_decide_bounded: BoundedAmb::z_abs) and the class counts before k1.
+// Everything behind that -- quantised increments per binade, the elimination of the per-binade counts, the continuation
+// through the top binade for both ends of the interval -- is lane_tight_tail, the code the dyadic form runs.
+PW_HD uint32_t lane_tight_values(uint32_t d, uint32_t pp, double r, float x_in, float x_out, float x_pv, uint32_t k1, uint32_t i1,
+                                 uint32_t p_f, double z_abs) {
+    if (k1 == 0 || k1 >= d) TIGHT_BAIL(1);
+    const bool has_pv = pp != 0xffffffffu;
+    const uint32_t pv0 = (has_pv && pp < k1) ? 1u : 0u;
+    if (i1 + pv0 > k1) TIGHT_BAIL(2);
+    const uint32_t o0 = k1 - i1 - pv0;
+    if (o0 == 0) TIGHT_BAIL(2);                             // (the elimination runs over the "out" class)
+    if (!(x_in > 0.0f) || !(x_out > 0.0f) || (has_pv && !(x_pv > 0.0f))) TIGHT_BAIL(3);
+    const double v0 = (double)i1 * (double)x_in + (double)o0 * (double)x_out + (double)pv0 * (double)x_pv;
+    if (!(v0 > 0.0) || !(v0 < 2.0)) TIGHT_BAIL(3);
+    // binade of v0 as a float32 number: biased exponent e_t, v0 / ulp_t = V + fr with V in [2^23, 2^24)
+    const int e_t = (int)((FloatTraits<double>::bits(v0) >> 52) & 0x7ffu) - 1023 + 127;
+    if (e_t < 2 || e_t > 126) TIGHT_BAIL(3);
+    const double scaled = v0 * FloatTraits<double>::from_bits((uint64_t)(1023 + 150 - e_t) << 52);   // exact: v0 * 2^(150 - e_t)
+    if (!(scaled >= 8388608.0) || !(scaled < 16777216.0)) TIGHT_BAIL(3);
+    const uint32_t V = (uint32_t)scaled;
+    const float fr = (float)(scaled - (double)V);
+    const float voff = (float)(V - (1u << 23));
+    const double ulp_inv = FloatTraits<double>::from_bits((uint64_t)(1023 + 150 - e_t) << 52);
+    const double zu = z_abs * ulp_inv * 1.01 + 2e-9 * scaled + 1.0;    // (+ the float64 evaluation of v0 itself)
+    if (!(zu < 4194304.0)) TIGHT_BAIL(4);
+    float xmin = x_in < x_out ? x_in : x_out;
+    if (pv0 && x_pv < xmin) xmin = x_pv;
+    const float upu = (float)((double)xmin * ulp_inv) * 0.9999f;      // smallest value among the prefix's classes, ulps of the top binade
+    if (!(upu > 0.0f)) TIGHT_BAIL(3);
+    return lane_tight_tail(pp, r, x_in, x_out, x_pv, k1, i1, pv0, d, p_f, e_t, V, fr, voff, (float)zu * 1.0001f, upu);
 }
 
 #undef TIGHT_BAIL

@@ -221,7 +221,12 @@ __device__ unsigned long long g_lprof[16];
 #define PW_LANES_MIN_WAVES_C 3   // ... its occupancy (the chain code needs ~150 VGPRs)
 #endif
 #ifndef PW_LANES_FWAIT
-#define PW_LANES_FWAIT 40        // FLOATS form: steps the float64 bound leaves open gather before their float chains run together
+#define PW_LANES_FWAIT 16        // FLOATS form: steps left open by the bound AND by the interval decision gather before their float
+                                 // chains run together (round 5, without the interval decision: 40)
+#endif
+#ifndef PW_LANES_FTIGHT
+#define PW_LANES_FTIGHT 16       // FLOATS form (round 6): steps the float64 bound leaves open gather before the interval decision
+                                 // (lane_tight_values, ~900 instructions, no memory access) runs for all of them
 #endif
 #ifndef PW_LANES_CHUNK
 #define PW_LANES_CHUNK 1024   // most jobs a wavefront reserves per access to the shared job counter (host: a quarter of
@@ -380,8 +385,12 @@ walk_lanes_kernel(LanesArgs a) {
         uint32_t e, coff;                // ... its CSR entry and the offset of its list
         uint32_t flags;                  // bit 0: active, bit 2: waiting for the float chain, bit 3: resumed
     };
-    constexpr uint32_t F_ACTIVE = 1u, F_WAIT2 = 4u;   // waiting for the float chain (in-place form)
+    constexpr uint32_t F_ACTIVE = 1u, F_WAIT2 = 4u;   // waiting for the float chain (in-place form; FLOATS: for the interval decision)
     constexpr uint32_t F_PRE = 8u;                    // resumed walk: the pending step's choice is known (pre)
+    constexpr uint32_t F_WAIT3 = 16u;                 // FLOATS: the interval decision left the step open -- waiting for the float chain
+    // FLOATS: what the bounded decision knows about a step it left open (seqscan.h: BoundedAmb), kept while the lane waits
+    uint32_t tk1 = 0, ti1 = 0, tpn = 0;
+    float tz = 0.0f;
     uint32_t pre = 0;
     Walk A{0, 1, 0, 0, 0, 0, NOT_FOUND, 0, 0, 0};
     bool exhausted = false;
@@ -774,10 +783,16 @@ walk_lanes_kernel(LanesArgs a) {
                 if (!(t > 0.0f)) choice = LANE_NEEDS_WAVE;          // (NaN: the total's chain met a tie binade beyond the budget)
                 else {
                     uint32_t probes_ = 0, ks_ = 0;
-                    choice = lane_decide_unit_bounded(A.d, A.n_in, A.pp, r, t, wo, w_prev, lane_list(A.e, A.d, A.n_in, A.coff), probes_, ks_);
+                    BoundedAmb amb_;
+                    choice = lane_decide_unit_bounded(A.d, A.n_in, A.pp, r, t, wo, w_prev, lane_list(A.e, A.d, A.n_in, A.coff), probes_, ks_, &amb_);
                     n_probes += probes_;
                     if (choice == LANE_REDO) choice = LANE_NEEDS_WAVE;
-                    if (choice == LANE_AMBIGUOUS) { A.flags = F_ACTIVE | F_WAIT2; tot = t; }
+                    if (choice == LANE_AMBIGUOUS) {
+                        // (k_safe == 0: nothing is known below the draw -- straight to the chain)
+                        A.flags = F_ACTIVE | (ks_ ? F_WAIT2 : F_WAIT3);
+                        tot = t; tk1 = ks_; ti1 = amb_.f; tpn = amb_.p_next;
+                        tz = (float)amb_.z_abs * 1.000001f + 1e-37f;       // (rounded UP: a bound)
+                    }
                 }
             } else if (runnable) {
                 wo = A.j >= 2 ? w_out : 1.0f;   // first step of a walk: no bias (sparse_rw.py:66)
@@ -800,12 +815,43 @@ walk_lanes_kernel(LanesArgs a) {
                 // beyond the budget -- both: walk_kernel takes the walk over at this step
                 choice = res < A.d ? res : (res == LANE_CHAIN_END ? A.d : LANE_NEEDS_WAVE);
             }
-            if (a.tot_e) n_amb += (unsigned long long)__popcll(ballot(runnable && (A.flags & F_WAIT2) != 0));   // (left open just now)
-            {   // the steps the bound left open: their chains together, once enough lanes wait or nothing else can run
-                const uint64_t w2 = ballot((A.flags & F_WAIT2) != 0);
-                if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_FWAIT || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0)) {
-                    n_wave += (unsigned long long)__popcll(w2);
+            if (a.tot_e) n_amb += (unsigned long long)__popcll(ballot(runnable && (A.flags & (F_WAIT2 | F_WAIT3)) != 0));   // (left open just now)
+            {   // Round 6: the steps the bound left open go through the INTERVAL DECISION first (lane_tight_values: the float32 chain's
+                // systematic drift bounded from the class counts the bounded decision already has -- arithmetic only), once enough
+                // lanes wait or nothing else can run; nine in ten are settled there (RMAT-20 rows, uniform draws: 6.6 % open after
+                // the bound, 0.46 % after this), the rest wait on for the chain.
+                const uint64_t wt = ballot((A.flags & F_WAIT2) != 0);
+                if (wt != 0 && ((uint32_t)__popcll(wt) >= PW_LANES_FTIGHT || ballot(A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) == 0)) {
+                    bool rec = false;
                     if (A.flags & F_WAIT2) {
+                        const uint32_t res = lane_tight_values(A.d, A.pp, r, 1.0f / tot, wo / tot, w_prev / tot, tk1, ti1, tpn, (double)tz);
+                        if (res != LANE_AMBIGUOUS) { choice = res; A.flags = F_ACTIVE; rec = ((A.job + A.j * 7919u) & a.ver_mask) == 0u; }
+                        else A.flags = F_ACTIVE | F_WAIT3;
+                    }
+                    if (VERIFY) {   // keep what the float chain needs to decide this step again (lanes_verify_kernel, floats = 1)
+                        const uint64_t vm = ballot(rec);
+                        if (vm) {
+                            unsigned long long vb = 0;
+                            if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                            vb = readfirst_u64(vb);
+                            const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
+                            if (rec && slot < a.ver_cap) {
+                                uint4 *vp = (uint4 *)(a.ver + slot);
+                                vp[0] = make_uint4(A.d, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
+                                vp[1] = make_uint4(A.e, A.coff, A.d, A.job);
+                                vp[2] = make_uint4(__float_as_uint(tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
+                                                   (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
+                            }
+                        }
+                    }
+                }
+            }
+            {   // what is still open: the float chains together, once enough lanes wait or nothing else can run
+                const uint64_t w2 = ballot((A.flags & F_WAIT3) != 0);
+                if (w2 != 0 && ((uint32_t)__popcll(w2) >= PW_LANES_FWAIT ||
+                                ballot((A.flags == F_ACTIVE && choice != LANE_AMBIGUOUS) || (A.flags & F_WAIT2) != 0) == 0)) {
+                    n_wave += (unsigned long long)__popcll(w2);
+                    if (A.flags & F_WAIT3) {
                         uint32_t reads = 0;
                         const uint32_t res = lane_chain<true>(A.d, A.n_in, A.pp, r, 1.0f / tot, wo / tot, w_prev / tot,
                                                               lane_list(A.e, A.d, A.n_in, A.coff), reads);
@@ -1482,7 +1528,8 @@ wlist_kernel(CsrDev g, const uint32_t *__restrict__ edge_row, const float *__res
 // bad_jobs (optional, cap entries): the walks of the mismatching records -- the production sample hands them to walk_kernel
 __global__ void __launch_bounds__(256)
 lanes_verify_kernel(const VerRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
-                    unsigned long long *counts, VerRec *bad, uint32_t bad_cap, uint32_t *bad_jobs = nullptr, uint32_t bad_jobs_cap = 0) {
+                    unsigned long long *counts, VerRec *bad, uint32_t bad_cap, uint32_t *bad_jobs = nullptr, uint32_t bad_jobs_cap = 0,
+                    uint32_t floats = 0) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long chk = 0, mis = 0, tie = 0;
     if (i < n) {
@@ -1492,8 +1539,10 @@ lanes_verify_kernel(const VerRec *q, uint64_t n, const ELine *__restrict__ lines
         const double r = __longlong_as_double((long long)(((unsigned long long)q2.w << 32) | q2.z));
         const float x_in = 1.0f / tot;
         uint32_t reads = 0;
-        const uint32_t res = lane_chain(q0.x, q0.y, q0.z, r, x_in, x_in * wo, x_in * w_prev,
-                                        edge_list(lines, clist, q1.x, q1.z, q0.y, q1.y), reads);
+        uint32_t res;
+        // (floats: the FLOATS form's values are three separately rounded quotients and its chain runs over the whole row)
+        if (floats) res = lane_chain<true>(q0.x, q0.y, q0.z, r, x_in, wo / tot, w_prev / tot, edge_list(lines, clist, q1.x, q1.z, q0.y, q1.y), reads);
+        else res = lane_chain(q0.x, q0.y, q0.z, r, x_in, x_in * wo, x_in * w_prev, edge_list(lines, clist, q1.x, q1.z, q0.y, q1.y), reads);
         chk = 1;
         if (res == LANE_TIE) tie = 1;
         else if (res != q0.w) {

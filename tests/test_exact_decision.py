@@ -395,6 +395,46 @@ def test_bounded_decision_of_the_float_step(w_out, w_prev):
     assert open_on_sum / total_on_sum > 0.9, (open_on_sum, total_on_sum)      # a draw ON a partial sum cannot be settled by a bound
 
 
+@pytest.mark.parametrize("w_out,w_prev", FLOAT_BIASES + [(1.0, 1.0)])
+def test_interval_decision_of_the_float_step(w_out, w_prev):
+    """Round 6: in front of its float chains the FLOATS step runs the interval decision for ARBITRARY float32 values
+    (lane_tight_values: the chain's systematic drift bounded from the class counts the bounded decision has -- the routine
+    the dyadic form uses, fed with the real sum of the values instead of an integer mass).  Every position it gives
+    equals the sequential loops -- uniform draws, draws exactly on, one ulp and 1e-7 around every partial sum -- and it is
+    not vacuous: of the uniform draws the bound leaves open on long rows it settles most."""
+    lib = _lib.load()
+    w_out, w_prev = float(np.float32(w_out)), float(np.float32(w_prev))
+    rng = np.random.default_rng(int(w_out * 577 + w_prev * 37) + 3)
+    rows = []
+    for n in (2, 5, 33, 64, 65, 400, 3000, 20000, 70000):
+        for p_common in (0.0, 0.01, 0.03, 0.4, 1.0):
+            for with_prev in (False, True):
+                rows.append(random_row(rng, n, p_common, with_prev))
+    rows += lattice_rows(4096) + structured_rows(rng, 1500)
+    open_uni = settled_uni = 0
+    for cls in rows:
+        n = cls.size
+        tot, c32 = float_chain_reference(cls, w_out, w_prev)
+        cd = c32.astype(np.float64)
+        sub = slice(None, None, max(1, n // 300))
+        uni = rng.random(600)
+        on = cd[sub]
+        r = np.clip(np.concatenate([uni, on, np.nextafter(on, 0.0), np.nextafter(on, 2.0), on * (1 - 1e-7), on * (1 + 1e-7),
+                                    on * (1 - 3e-6), on * (1 + 3e-6), np.array([0.0, 1e-300, 1 - 2.0 ** -53])]), 0.0, np.nextafter(1.0, 0.0))
+        chain, lane, tight = (np.empty(r.size, dtype=np.uint32) for _ in range(3))
+        _lib.check(lib.pw_selftest_lane_unit_tight(np.ascontiguousarray(cls).ctypes.data_as(C.c_void_p), n, w_out, w_prev,
+                                                   r.ctypes.data_as(C.c_void_p), r.size, chain.ctypes.data_as(C.c_void_p),
+                                                   lane.ctypes.data_as(C.c_void_p), tight.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(chain, np.searchsorted(cd, r, side="left").astype(np.uint32))       # the hook's own reference
+        decided = tight != LANE_AMBIGUOUS
+        assert np.array_equal(tight[decided], chain[decided]), (n, w_out, w_prev, np.flatnonzero(tight[decided] != chain[decided])[:5])
+        assert np.array_equal(tight[lane != LANE_AMBIGUOUS], lane[lane != LANE_AMBIGUOUS])          # (a verdict of the bound stands)
+        if n >= 3000:
+            amb = lane[:600] == LANE_AMBIGUOUS
+            open_uni += int(amb.sum()); settled_uni += int((amb & decided[:600]).sum())
+    assert open_uni > 500 and settled_uni / open_uni > 0.3, (settled_uni, open_uni)   # (rows full of common neighbours are the hard ones)
+
+
 # ---- weighted rows: float64 prefix sums + a rigorous bound on the float32 chain (lane_decide_weighted) ------------------
 def _weighted_run(vals, base, cls, r):
     vals = np.ascontiguousarray(vals, np.float32)

@@ -505,7 +505,7 @@ def test_weighted_halves_on_twin_contexts_equal_one_context(monkeypatch):
     rng = np.random.default_rng(2)
     m = 1 << 16
     src, dst = rng.integers(0, m, 1 << 20), rng.integers(0, m, 1 << 20)
-    keep = (src != dst) & (src % 64 != 0)
+    keep = (src != dst) & (src % 4096 != 0)          # (16 sinks: a few hundred dead ends -- every repair round re-walks on the wave kernel)
     ip, ix, _ = csr_from_edges(src[keep], dst[keep], m)
     w = hash_edge_weights(ip, ix, 5)
     st2 = np.concatenate([np.arange(m, dtype=np.uint32)] * 17)

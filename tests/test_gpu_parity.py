@@ -292,11 +292,13 @@ def test_device_stream_at_deep_offsets():
     assert np.array_equal(eng.stream_sample(11, 3_000_000, 4000), rs.random_sample(4000))
 
 
-@pytest.mark.parametrize("parts", [2, 3, 5])
+@pytest.mark.parametrize("parts", [2, 3, 5, 8, 11])
 def test_host_call_walked_in_parts_equals_one_call(parts, monkeypatch):
     """pw_simulate walks large job arrays in parts (the copy-out of one part under the kernels of the next); part k + 1
     is addressed into the stream by the draws the earlier parts actually consumed -- undirected graph and a directed
     one with dead ends, against the oracle."""
+    # (from 8 parts on the device holds a RING of three part buffers instead of the matrix, and every part expands its own
+    #  stretch of the stream -- round 6)
     monkeypatch.setenv("PECANPY_AMD_PARTS", str(parts))
     indptr, indices, data = rmat_csr(11, seed=7)
     starts = orc.shuffled_starts(indptr.size - 1, 3, 1)

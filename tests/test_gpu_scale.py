@@ -120,6 +120,21 @@ def test_full_size_interval_decision_verified_by_the_float_chain(run, p, q, monk
           f"{st['verify_ties']} declined")
 
 
+@pytest.mark.parametrize("p,q", [(0.3, 1.7), (3.0, 0.37)])
+def test_full_size_float_form_interval_decision_verified(run, p, q, monkeypatch):
+    """... and for the FLOATS form (round 6: lane_tight_values in front of the float chains), at BASELINE size: every step
+    the interval decision settles -- a tenth of the 1.6e9 transitions -- decided again by the float32 chain over the whole row."""
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_TIGHT", "1")
+    run["eng"].simulate_device("SparseOTF", p, q, False, run["d_starts"], L, seed=SEED)
+    st = dict(run["eng"].last_stats)
+    assert st["lane_kernel"] == 2
+    assert st["verify_mismatch"] == 0 and st["verify_dropped"] == 0, st
+    assert st["verify_checked"] > 0.02 * st["total_steps"], st
+    print(f"[verify] FLOATS RMAT-{SCALE} p={p} q={q}: {st['total_steps']} transitions, {st['ambiguous_steps']} left open by the bound, "
+          f"{st['verify_checked']} settled by the interval decision and re-decided by the chain, {st['wave_chain_steps']} float chains, "
+          f"{st['verify_ties']} declined")
+
+
 @pytest.mark.parametrize("p,q", [(0.5, 2.0), (0.25, 4.0)])
 def test_full_size_oracle_prefix(run, p, q):
     """BASELINE size against the oracle itself: the first 20 000 jobs of the shuffled job array (stream offset 0,
@@ -427,3 +442,22 @@ def test_dense_fast_kernel_equals_the_complete_kernel(n, density, monkeypatch):
     assert eng.last_stats["redo_walks"] >= starts.size // 7
     assert eng.last_stats["total_steps"] == st["total_steps"]
     assert torch.equal(mixed, full)
+
+
+def test_host_call_through_the_ring_at_scale(monkeypatch):
+    """pw_simulate at a size where the ring of part buffers is the default (>= 800 MB of output: 8 parts, three buffers, a
+    stream expansion per part): RMAT-20, 10 x 80 -- equal to the device-resident call row for row, and to the whole-matrix form."""
+    import torch
+
+    indptr, indices, data = rmat_csr(20, seed=1)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 10)
+    np.random.RandomState(0).shuffle(starts)
+    eng = WalkEngine.from_csr(indptr, indices, None)
+    d = eng.simulate_device("SparseOTF", 0.5, 2.0, False, torch.from_numpy(starts.view(np.int32)).cuda(), 80, seed=3)
+    want = d.cpu().numpy().view(np.uint32)
+    del d
+    got = eng.simulate("SparseOTF", 0.5, 2.0, False, starts, 80, seed=3)
+    assert got.nbytes >= 800 << 20 and np.array_equal(got, want)
+    monkeypatch.setenv("PECANPY_AMD_NO_RING", "1")
+    assert np.array_equal(eng.simulate("SparseOTF", 0.5, 2.0, False, starts, 80, seed=3), want)

@@ -163,3 +163,38 @@ def test_sampled_verification_in_production(monkeypatch):
     monkeypatch.setenv("PECANPY_AMD_VERIFY_SAMPLE_POISON", "1")
     with pytest.warns(RuntimeWarning, match="sampled interval decisions"):
         g.simulate_walks_array(32, 80)
+
+
+@pytest.mark.parametrize("p,q", [(0.3, 1.7), (3.0, 0.37)])
+@pytest.mark.parametrize("family", ["holme_kim", "bipartite_hubs", "ring_lattice_512"])
+def test_float_form_interval_decision_verified_by_the_float_chain(family, p, q, monkeypatch):
+    """Round 6: the FLOATS form (1/p or 1/q not a power of two) runs the interval decision too (lane_tight_values, in front of its
+    float chains).  PECANPY_AMD_VERIFY_TIGHT=1 records every step it settles and the float32 chain over the whole row decides
+    each of them again on the device: none may differ.  Without the switch a 1/1024 sample is checked the same way."""
+    import torch
+
+    build, num_walks, L = FAMILIES[family]
+    indptr, indices, _ = build()
+    n = indptr.size - 1
+    num_walks = max(2, num_walks // 4)
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * num_walks)
+    np.random.RandomState(5).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    eng = WalkEngine.from_csr(indptr, indices, None)
+    monkeypatch.setenv("PECANPY_AMD_VERIFY_TIGHT", "1")
+    a = eng.simulate_device("SparseOTF", p, q, False, d_starts, L, seed=2)
+    st = dict(eng.last_stats)
+    monkeypatch.delenv("PECANPY_AMD_VERIFY_TIGHT")
+    b = eng.simulate_device("SparseOTF", p, q, False, d_starts, L, seed=2)
+    sb = dict(eng.last_stats)
+    assert torch.equal(a, b)
+    assert st["lane_kernel"] == 2 and st["verify_mismatch"] == 0 and st["verify_dropped"] == 0, st
+    assert st["verify_checked"] > 1000, st
+    assert sb["verify_mismatch"] == 0 and sb["verify_checked"] <= st["verify_checked"] // 256 + 64, sb
+    print(f"[verify] FLOATS {family} p={p} q={q}: {st['total_steps']} transitions, {st['ambiguous_steps']} left open by the bound, "
+          f"{st['verify_checked']} settled by the interval decision and re-decided by the chain, {st['wave_chain_steps']} float chains")
+    if family == "holme_kim" and p == 0.3:     # the check is live here too
+        monkeypatch.setenv("PECANPY_AMD_VERIFY_TIGHT", "poison")
+        c = eng.simulate_device("SparseOTF", p, q, False, d_starts, L, seed=2)
+        sp = eng.last_stats
+        assert torch.equal(a, c) and sp["verify_mismatch"] >= max(1, sp["verify_checked"] // 1024 - sp["verify_ties"])
