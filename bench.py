@@ -215,8 +215,9 @@ def main():
             indptr, indices, data = csr_from_edges(np.concatenate([rows, lp]), np.concatenate([indices.astype(np.int64), lp]), n_nodes)
             del rows
         t_graph = time.time() - t0
-        # the HIP runtime's start-up in this process (context, code objects: ~150 ms) is timed APART from the handle creation
-        # (rounds 4-5 timed them together); value_first_call charges both
+        # what is left of the HIP runtime's start-up at this point is timed APART from the handle creation (torch.cuda.set_device
+        # above has usually started the runtime: ~0; the ~150 ms "runtime / streams / events" stage INSIDE pw_csr_create is the first
+        # use of this library's code object and stays in graph_create_wall_ms); value_first_call charges both
         t_rt = time.perf_counter()
         torch.cuda.init()
         torch.empty(1, device=dev)
@@ -641,9 +642,9 @@ def main():
             "graph_index_build_ms": round(info["build_ms"], 1),
             "graph_create_wall_ms": round(create_wall_ms, 1),
             "hip_runtime_startup_ms": round(hip_startup_ms, 1),
-            "graph_create_note": "round 6: graph_create_wall_ms = pw_csr_create alone; the HIP runtime's start-up in a fresh process "
-                                 "(hip_runtime_startup_ms) was inside that figure in rounds 4-5 and is timed apart now; "
-                                 "value_first_call charges both, as before",
+            "graph_create_note": "graph_create_wall_ms = wall clock of pw_csr_create (incl. ~150 ms for the first use of the library's code "
+                                 "object: streams, events, module load); hip_runtime_startup_ms = what was left of the HIP runtime's own "
+                                 "start-up just before it (torch has usually paid it); value_first_call charges both",
             "value_first_call": round(total_steps / (sec_per_step + (create_wall_ms + hip_startup_ms) * 1e-3 + param_index_ms[0] * 1e-3) / 1e6, 3),
             # index that depends on (p, q, extend), built inside the first (warm-up) call and cached in the handle:
             # per-edge normalisers of weighted graphs

@@ -1737,7 +1737,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         if (parked && weighted) {   // the parked steps of the weighted form: one wavefront each, the wave-per-walk scan
             HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, sizeof(unsigned long long), g->stream));   // (record counter of the persistent grid)
             const uint64_t want_e = (parked + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
-            const unsigned egrid_e = (unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * 8);
+            static const int eager_wgs = getenv("PECANPY_AMD_EAGER_WGS") ? atoi(getenv("PECANPY_AMD_EAGER_WGS")) : 8;   // (workgroups per CU; experiments)
+            const unsigned egrid_e = (unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * (uint64_t)(eager_wgs > 0 ? eager_wgs : 8));
             if (extend) hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<true>, dim3(egrid_e), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa,
                                            g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
                                            (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));

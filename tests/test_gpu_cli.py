@@ -61,6 +61,22 @@ def test_cli_main_reproduces_the_reference_walks(mode, tmp_path, monkeypatch):
     assert got == want
 
 
+def test_cli_uses_the_named_devices_without_a_launcher(tmp_path, monkeypatch):
+    """Round 6: the console script spreads the walks over the GPUs of THIS process (PECANPY_AMD_DEVICES; no torchrun) -- here the
+    one device of the box named twice -- and writes the same walks as the one-device run (the reference's, SparseOTF p = q = 1)."""
+    monkeypatch.setenv("PECANPY_AMD_DUMP_WALKS", "1")
+    monkeypatch.setenv("PECANPY_AMD_DEVICES", "0,0")
+    edg, out = tmp_path / "karate.edg", tmp_path / "karate.walks"
+    ids = _write_edg(edg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cli.main(["--input", str(edg), "--output", str(out), "--mode", "SparseOTF", "--random_state", "0",
+                  "--num-walks", "10", "--walk-length", "80", "--workers", "1"])
+    gold = np.load(os.path.join(GOLDEN, "karate_SparseOTF_p1_q1.npz"))
+    want = [" ".join(ids[row[: row[-1]]].tolist()) for row in gold["walks"]]
+    assert out.read_text().splitlines() == want
+
+
 @pytest.mark.parametrize("mode", ("FirstOrderUnweighted", "PreCompFirstOrder"))
 @pytest.mark.parametrize("p,q", [(2, 1), (1, 0.1), (0.1, 0.1)])
 def test_cli_first_order_modes_reject_second_order_parameters(mode, p, q, tmp_path):

@@ -528,6 +528,29 @@ def test_sink_heavy_directed_graph_is_exact_by_default(monkeypatch):
     assert np.array_equal(eng.simulate("SparseOTF", 0.3, 1.7, False, starts, L, seed=seed), want2)
 
 
+def test_sink_heavy_repair_has_a_time_budget_and_ignores_value_zero_switches(monkeypatch):
+    """the block-wise repair is bounded -- PECANPY_AMD_REPAIR_SECONDS (default 600) -- and fails with a message that
+    names the ways out instead of running on silently; and the opt-in switches are read by VALUE: PECANPY_AMD_NOMINAL_STREAM=0
+    leaves the exact addressing on."""
+    from pecanpy_amd._lib import PwError
+
+    rng, n, indptr, indices, data = _sink_heavy_graph()
+    L, seed = 30, 2
+    starts = orc.shuffled_starts(n, 8, seed)
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts, L, seed)
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    monkeypatch.setenv("PECANPY_AMD_NOMINAL_STREAM", "0")
+    got = eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    assert eng.last_stats["stream_addressing"] == 0 and np.array_equal(got, want)
+    monkeypatch.delenv("PECANPY_AMD_NOMINAL_STREAM")
+    monkeypatch.setenv("PECANPY_AMD_REPAIR_SECONDS", "0.000001")
+    monkeypatch.setenv("PECANPY_AMD_REPAIR_BLOCK", "1")
+    with pytest.raises(PwError, match="PECANPY_AMD_REPAIR_SECONDS=0 lifts"):
+        eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed)
+    monkeypatch.setenv("PECANPY_AMD_REPAIR_SECONDS", "0")     # no limit
+    assert np.array_equal(eng.simulate("SparseOTF", 0.5, 2, False, starts, L, seed=seed), want)
+
+
 def test_sink_heavy_directed_graph_nominal_slots_are_an_opt_in(monkeypatch):
     """PECANPY_AMD_NOMINAL_STREAM=1: after 32 passes one fixed slot of walk_length draws per walk (reported in the stats) --
     deterministic, every walk equals the oracle run of that walk alone at its slot; decided once for the whole array
