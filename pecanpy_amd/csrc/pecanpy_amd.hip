@@ -114,6 +114,7 @@ struct pw_graph {
     // contexts side by side, so that one half's eager kernel runs beside the other half's lane round (simulate_twin)
     pw_graph *twin = nullptr;
     bool alias = false;                                 // this handle IS such a twin: the shared buffers are not its to free
+    bool twin_active = false;                           // the current call runs on both contexts: each takes a share of the GPU
     std::function<void()> on_tables_ready;              // simulate_twin: called once the call's per-(p, q) tables are in place
     bool has_loop = false;                              // the CSR has a self loop (unit graphs: lists fixed up, wave kernel's lazy step off)
     bool lanes_off = false;                             // PECANPY_AMD_NO_LANES was set when the handle was created: the index is
@@ -1567,6 +1568,10 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     else if (tails) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_in, (const void *)pw::walk_lanes_kernel<true, false>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_in < 1) occ_in = 1;
+    // twin contexts (weighted halves side by side): a persistent lane kernel sized for the whole GPU would keep the other half's
+    // eager kernel waiting for its workgroups to retire -- four of the six resident workgroups per CU here, six of eight for the
+    // eager kernel: C5 341 -> 311 ms per pass (sweep: 3..5 x 4..12, profiles/r06_c5_twin_sweep.txt)
+    if (weighted && g->twin_active) { if (occ > 4) occ = 4; if (occ_in > 4) occ_in = 4; }
     if (const char *oe = getenv("PECANPY_AMD_LANE_OCC")) {   // (experiments: fewer resident workgroups per CU than fit)
         const int cap = atoi(oe);
         if (cap >= 1 && cap < occ) occ = cap;
@@ -1737,8 +1742,9 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         if (parked && weighted) {   // the parked steps of the weighted form: one wavefront each, the wave-per-walk scan
             HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, sizeof(unsigned long long), g->stream));   // (record counter of the persistent grid)
             const uint64_t want_e = (parked + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
-            static const int eager_wgs = getenv("PECANPY_AMD_EAGER_WGS") ? atoi(getenv("PECANPY_AMD_EAGER_WGS")) : 8;   // (workgroups per CU; experiments)
-            const unsigned egrid_e = (unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * (uint64_t)(eager_wgs > 0 ? eager_wgs : 8));
+            static const int eager_env = getenv("PECANPY_AMD_EAGER_WGS") ? atoi(getenv("PECANPY_AMD_EAGER_WGS")) : 0;   // (workgroups per CU; experiments)
+            const int eager_wgs = eager_env > 0 ? eager_env : (g->twin_active ? 6 : 8);
+            const unsigned egrid_e = (unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * (uint64_t)eager_wgs);
             if (extend) hipLaunchKernelGGL(pw::lanes_eager_weighted_kernel<true>, dim3(egrid_e), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa,
                                            g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12, (const uint32_t *)g->d_wedge_row,
                                            (const unsigned long long *)g->d_wck_off, (const float *)(getenv("PECANPY_AMD_NO_WCKPT") ? nullptr : g->d_wck));
@@ -2546,6 +2552,8 @@ static int simulate_twin(pw_graph *g, int mode, double p, double q, int extend, 
     try {
         tb = std::thread([&]() { if (ready_f.get()) run_b(stream_skip + nominal_a); });
     } catch (const std::system_error &) { threaded = false; }
+    g->twin_active = t->twin_active = threaded;
+    struct ActiveGuard { pw_graph *a, *b; ~ActiveGuard() { a->twin_active = b->twin_active = false; } } active_guard{g, t};
     rc = simulate_device_impl(g, mode, p, q, extend, d_starts, half, walk_length, 1, seed, stream_skip, d_out, &sa);
     g->on_tables_ready = nullptr;
     if (!signalled) ready.set_value(false);     // (the first half failed before its tables were in place: the second is not walked)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r6_ab.sh <out dir under gpurun_out> -- headline A/B lines of round 6 (sampled verification on / off, self loops)
+# usage: tools/ab_lines.sh <out dir under gpurun_out> -- headline A/B lines of round 6 (sampled verification on / off, self loops)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$1; mkdir -p $OUT; cd $R
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-call"
 timeout 300 $B > $OUT/headline_sample_on.json 2> $OUT/err1.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r6_final.sh <out dir under gpurun_out> -- the round's final measurement set: bench lines of every config, a kernel
+# usage: tools/final_set.sh <out dir under gpurun_out> -- the round's final measurement set: bench lines of every config, a kernel
 # trace of the headline (rocprofv3 --kernel-trace --stats), PMC passes of the headline / FLOATS / C5 (tools/pmc_all.sh)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$1; mkdir -p $R/gpurun_out/$OUT; cd $R
 tools/bench_all.sh gpurun_out/$OUT/bench > /dev/null 2>&1
