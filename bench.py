@@ -67,9 +67,6 @@ def parse():
     ap.add_argument("--rank0-share", default="auto",
                     help="rank 0's shard as a fraction of a uniform one (it also assembles the matrix); 'auto' = the model of "
                          "DESIGN.md section 6 (0.5 at 8 GPUs), 1 = uniform")
-    ap.add_argument("--gather-mode", choices=("rccl", "peer"), default="rccl",
-                    help="rccl: send/recv into row slices + scatter on rank 0; peer: every rank writes its rows into rank 0's "
-                         "matrix itself (CUDA IPC mapping, stores over xGMI; no receive-side work)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: leave the walk shards on their GPUs (skip the gather on rank 0)")
     return ap.parse_args()
@@ -283,24 +280,11 @@ def main():
     gather = None
     job_has_nbr = has_nbr[starts]
     if do_gather:
-        from pecanpy_amd.sharding import PeerRowWriter, RowGather, isolated_row_filler
+        from pecanpy_amd.sharding import RowGather, isolated_row_filler
 
         fill = isolated_row_filler(starts, L, cdev)
-        gather_mode = args.gather_mode if cdev == dev else "rccl"
-        if gather_mode == "peer":
-            # every rank must end up in the same mode: agree on whether the IPC mapping worked everywhere
-            try:
-                gather = PeerRowWriter(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
-                ok = 1
-            except Exception as exc:   # noqa: BLE001 (any failure of the mapping: fall back, loudly)
-                print(f"bench.py rank {rank}: peer gather unavailable ({exc!r}); falling back to RCCL send/recv", file=sys.stderr)
-                gather, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                gather, gather_mode = None, "rccl"
-        if gather is None:
-            gather = RowGather(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
+        gather_mode = "rccl"    # (round 6: the peer-write assembly lives below the Python layer now -- pw_simulate_multi, one process)
+        gather = RowGather(n_jobs, L + 2, all_bounds, torch.int32, cdev, dst=0, known=~job_has_nbr, fill_known=fill)
         # (the matrix is allocated on rank 0 here: outside the timed region, like d_out)
     if do_gather and rank == 0 and cdev == dev:
         d_out = gather.own_rows()

@@ -11,7 +11,7 @@ import numpy as np
 
 from .engine import auto_rank0_share, shard_bounds
 
-__all__ = ["sharded_walk_matrix", "shard_bounds", "auto_rank0_share", "RowGather", "PeerRowWriter", "isolated_row_filler"]
+__all__ = ["sharded_walk_matrix", "shard_bounds", "auto_rank0_share", "RowGather", "isolated_row_filler"]
 
 
 def _dist():
@@ -136,92 +136,6 @@ class RowGather:
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._works, self._scatters, self._sent = [], [], []
         return self.full
-
-
-class PeerRowWriter:
-    """The same assembly WITHOUT receive-side work: rank ``dst`` shares its preallocated ``[n_rows, width]`` matrix with
-    the other ranks of the node (CUDA IPC: every process maps the allocation; xGMI peer access), and every sender
-    WRITES its rows into the matrix itself -- ``full[idx] = rows`` is one scatter kernel on the SENDER's GPU whose stores
-    travel over the sender's xGMI link to rank ``dst``.  Rank ``dst`` runs no receive kernels, allocates no staging
-    tensors and scatters nothing: it only walks its own shard and prefills the rows nobody sends.  Same interface as
-    ``RowGather`` (``post`` / ``expect`` / ``finish`` / ``prefill`` / ``own_rows``); ``expect`` is a no-op.
-    Selected by ``bench.py --gather-mode peer``; the RCCL send/recv form stays the default until an 8-GPU run has
-    compared them (single node, CUDA tensors and the nccl backend only).
-
-    HAZARD (unlike ``RowGather``, whose receives are posted by the reader): a sender's ``post`` of the NEXT pass writes straight
-    into rank ``dst``'s matrix.  The matrix returned by ``finish()`` must be consumed or copied before any rank starts its next
-    pass -- ``bench.py`` brackets every pass with a barrier on both sides."""
-
-    def __init__(self, n_rows, width, bounds, dtype, device, dst=0, group=None, known=None, fill_known=None):
-        import torch
-        from torch.multiprocessing.reductions import reduce_tensor
-
-        self.dist = _dist()
-        self.torch = torch
-        self.group, self.dst = group, dst
-        self.rank = self.dist.get_rank(group)
-        self.bounds = bounds
-        self.known = None if known is None else np.asarray(known, dtype=bool)
-        self.device = device
-        if torch.device(device).type != "cuda":
-            raise ValueError("PeerRowWriter needs CUDA tensors (peer writes over xGMI)")
-        self._owner = torch.empty((n_rows, width), dtype=dtype, device=device) if self.rank == dst else None
-        handle = [reduce_tensor(self._owner) if self.rank == dst else None]
-        self.dist.broadcast_object_list(handle, src=dst, group=group)
-        if self.rank == dst:
-            self.full = self._owner
-        else:
-            rebuild, args = handle[0]
-            args = list(args)
-            # torch's private rebuild_cuda_tensor tuple: (cls, size, stride, offset, storage_cls, dtype, storage_device, handle, ...);
-            # the layout is checked before element 6 is patched -- a different torch release fails here, loudly, and the caller
-            # (bench.py) falls back to the RCCL send / recv gather on every rank
-            if len(args) < 8 or not isinstance(args[6], int) or not isinstance(args[1], (tuple, torch.Size)):
-                raise RuntimeError("unexpected rebuild_cuda_tensor argument layout: peer gather unavailable with this torch")
-            args[6] = torch.cuda.current_device()     # (storage device index: the mapping lives in THIS process's context)
-            self.full = rebuild(*args)                # dst's matrix, mapped into this process: stores go over xGMI
-        self._sel_cache = {}
-        self._known_idx, self._fill_known = None, fill_known
-        if self.rank == dst and self.known is not None and fill_known is not None:
-            lo, hi = bounds[dst]
-            other = self.known.copy()
-            other[lo:hi] = False
-            self._known_idx = torch.from_numpy(np.flatnonzero(other)).to(device)
-        self.prefill()
-
-    def prefill(self):
-        if self._known_idx is not None and self._known_idx.numel():
-            self._fill_known(self.full, self._known_idx)
-
-    def own_rows(self):
-        lo, hi = self.bounds[self.dst]
-        return self.full[lo:hi]
-
-    def post(self, lo, hi, rows):
-        """Sender: writes its rows [lo, hi) (minus the known ones) into rank dst's matrix, on its own current stream."""
-        if hi <= lo or self.rank == self.dst:
-            return
-        sel = None
-        if self.known is not None:
-            key = (lo, hi)
-            if key not in self._sel_cache:
-                k = self.known[lo:hi]
-                self._sel_cache[key] = None if not k.any() else self.torch.from_numpy(np.flatnonzero(~k)).to(rows.device)
-            sel = self._sel_cache[key]
-        if sel is None:
-            self.full[lo:hi].copy_(rows, non_blocking=True)
-        elif sel.numel():
-            self.full.index_copy_(0, sel + lo, rows.index_select(0, sel))
-
-    def expect(self, pieces):
-        return None
-
-    def finish(self):
-        """Every rank: its own writes are over (device synchronize), then a barrier -- after it rank dst's matrix is
-        complete.  Returns the matrix on rank dst, None elsewhere."""
-        self.torch.cuda.synchronize()
-        self.dist.barrier(group=self.group)
-        return self.full if self.rank == self.dst else None
 
 
 def isolated_row_filler(starts, walk_length, device):

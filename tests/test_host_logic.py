@@ -237,3 +237,19 @@ def test_tapered_bounds_cover_the_shard_in_decreasing_chunks():
             if n >= 1000:
                 assert all(sizes[i] >= sizes[i + 1] for i in range(k - 1))
                 assert sizes[-1] <= n * 2 // (k * (k + 1)) + 1          # the tail is 2 / (k (k + 1)) of the shard
+
+
+def test_device_list_specs_parse_without_a_gpu():
+    """PECANPY_AMD_DEVICES forms (in-process multi-GPU, round 6): a list may name a device twice (every entry is a replica);
+    a bit mask goes through the C ABI (pw_device_mask_to_list), which rejects devices that are not visible."""
+    from pecanpy_amd import _lib
+    from pecanpy_amd.engine import visible_devices
+
+    assert visible_devices("0,0") == [0, 0]
+    assert visible_devices("2, 0 ,1") == [2, 0, 1]
+    assert visible_devices([1, 1, 0]) == [1, 1, 0]
+    n = _lib.load().pw_device_count()
+    assert visible_devices(None) == list(range(n)) and visible_devices("all") == list(range(n))
+    assert visible_devices("mask:0x0") == []
+    with pytest.raises(_lib.PwError, match="visible"):
+        visible_devices("mask:0x8000000000000000")
