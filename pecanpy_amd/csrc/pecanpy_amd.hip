@@ -29,6 +29,7 @@
 #include "mtjump.hpp"
 #include "seqscan.h"
 #include "walk_dense.hip.h"
+#include "walk_dense_w.hip.h"
 #include "walk_seq.hip.h"
 #include "walk_sparse.hip.h"
 #include "walk_lanes.hip.h"
@@ -98,6 +99,7 @@ struct pw_graph {
     uint64_t *d_adjbits = nullptr;   // dense graphs: bit-packed adjacency rows
     uint32_t *d_deg = nullptr;       // dense graphs: row degrees
     bool bits_only = false;          // dense graph created from packed bits: no compressed rows
+    bool dense_nonneg = false;       // weighted dense graph: every stored value is finite and > 0 (walk_dense_w.hip.h)
     uint32_t *d_foff = nullptr;      // CSR graphs: per-row membership filters (offsets, bits)
     uint64_t *d_fbits = nullptr;
     uint2 *d_kf = nullptr;           // CSR graphs: (neighbour id, filter word) per CSR entry
@@ -865,7 +867,7 @@ PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, 
     std::vector<uint32_t> cols;
     std::vector<double> vals;
     std::vector<uint64_t> bits((size_t)n * wpr, 0);
-    bool unit = true;
+    bool unit = true, nonneg = true;
     uint64_t nnz = 0;
     for (uint64_t i = 0; i < n; i++) {
         const double *row = data + i * n;
@@ -877,6 +879,7 @@ PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, 
                 vals.push_back(v);
                 bits[i * wpr + (x >> 6)] |= 1ull << (x & 63);
                 if (v != 1.0) unit = false;
+                if (!(v > 0.0) || !(v < 0x1p1000)) nonneg = false;
                 nnz++;
             }
         }
@@ -889,6 +892,7 @@ PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, 
     g->n_nodes = n_nodes;
     g->nnz = (uint32_t)nnz;
     g->unit = unit;
+    g->dense_nonneg = nonneg;
     g->words_per_row = wpr;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
@@ -970,7 +974,7 @@ PW_EXPORT int pw_graph_replicate(const pw_graph *src, int device, pw_graph **out
     int rc = graph_common_init(g, device);
     if (rc) { pw_graph_destroy(g); return rc; }
     g->kind = src->kind; g->n_nodes = src->n_nodes; g->nnz = src->nnz; g->unit = src->unit; g->max_degree = src->max_degree;
-    g->bits_only = src->bits_only; g->words_per_row = src->words_per_row; g->has_loop = src->has_loop; g->lanes_off = src->lanes_off;
+    g->bits_only = src->bits_only; g->dense_nonneg = src->dense_nonneg; g->words_per_row = src->words_per_row; g->has_loop = src->has_loop; g->lanes_off = src->lanes_off;
     g->vlines = src->vlines; g->clist_bytes = src->clist_bytes; g->line_bytes = src->line_bytes; g->fbits_words = src->fbits_words;
     g->slot_words = src->slot_words; g->n_clist = src->n_clist; g->list_max_len = src->list_max_len; g->index_bytes = src->index_bytes;
     g->thr_version = src->d_thr ? 1 : 0;
@@ -1493,10 +1497,87 @@ static int ensure_wlane_tables(pw_graph *g, const pw::WalkArgs &wa, bool extend,
     return 0;
 }
 
+// weighted dense graphs: the float64-bounded decision, one row stream per step (walk_dense_w.hip.h); the walks it hands
+// over (a partial sum inside the bound's interval: ~10^-11 of the steps) are walked again by the complete kernel
+static bool dense_weighted_eligible(const pw_graph *g, const pw::WalkArgs &wa, bool extend) {
+    if (g->kind != 1 || g->unit || g->bits_only || !g->dense_nonneg || !g->d_adjbits || !g->d_data) return false;
+    if (extend && !g->d_thr) return false;
+    if (wa.resume || getenv("PECANPY_AMD_DENSE_NO_WFAST")) return false;
+    // LDS of one wavefront: prev's packed row + its prefix popcounts + the block prefixes
+    const uint64_t lds = (uint64_t)g->words_per_row * 12u + ((uint64_t)g->n_nodes / pw::DWBLK + 2u) * 8u;
+    return lds <= 60u * 1024u;
+}
+
+static int launch_dense_weighted(pw_graph *g, const pw::WalkArgs &wa, bool extend, uint64_t *redo_total) {
+    uint64_t n_work = wa.job_list ? wa.n_list : wa.n_jobs;
+    if (!n_work) return 0;
+    pw::DenseWArgs da;
+    da.indptr = g->d_indptr;
+    da.indices = g->d_indices;
+    da.data = (const double *)g->d_data;
+    da.adjbits = g->d_adjbits;
+    da.thr = g->d_thr;
+    da.n = g->n_nodes;
+    da.wpr = g->words_per_row;
+    da.p = wa.p;
+    da.q = wa.q;
+    da.L = wa.L;
+    da.n_jobs = wa.n_jobs;
+    da.starts = wa.starts;
+    da.stream_off = wa.stream_off;
+    da.job_list = wa.job_list;
+    da.n_list = wa.n_list;
+    da.rng = wa.rng;
+    da.rng_base = wa.rng_base;
+    da.out = wa.out;
+    da.job_counter = wa.job_counter;
+    da.stats = wa.stats;
+    if (g->redo.ensure(n_work)) return PW_ERR_NOMEM;
+    da.redo_list = g->redo.p;
+    da.redo_count = g->counters.p + 6;
+    const char *rt = getenv("PECANPY_AMD_DENSE_REDO_TEST");   // tests: every k-th walk is handed over at its third step
+    da.redo_every = rt ? (uint32_t)strtoul(rt, nullptr, 10) : 0u;
+    da.lds_blocks = g->n_nodes / pw::DWBLK + 2u;
+    const size_t lds = (size_t)da.wpr * 8u + (size_t)da.lds_blocks * 8u + (size_t)da.wpr * 4u;
+    typedef void (*dw_fn)(pw::DenseWArgs);
+    dw_fn fn = extend ? pw::walk_dense_weighted_kernel<true> : pw::walk_dense_weighted_kernel<false>;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVE, lds));
+    if (occ < 1) occ = 1;
+    if (const char *oe = getenv("PECANPY_AMD_DENSE_W_OCC")) { const int cap = atoi(oe); if (cap >= 1 && cap < occ) occ = cap; }
+    uint64_t grid = (uint64_t)g->n_cu * (uint64_t)occ;
+    if (grid > n_work) grid = n_work;
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    HIP_TRY(hipMemsetAsync(g->counters.p + 6, 0, sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(pw::WAVE), lds, g->stream, da);
+    HIP_TRY(hipGetLastError());
+    unsigned long long nr = 0;
+    HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (!nr) return 0;
+    if (redo_total) *redo_total += nr;
+    pw::WalkArgs wr = wa;
+    wr.job_list = g->redo.p;
+    wr.n_list = nr;
+    wr.resume = 0;
+    int occ2 = 0;
+    walk_kernel_fn cf = pick_kernel(g, extend);
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, (const void *)cf, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
+    if (occ2 < 1) occ2 = 1;
+    uint64_t want = (nr + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
+    uint64_t grid2 = (uint64_t)g->n_cu * (uint64_t)occ2;
+    if (grid2 > want) grid2 = want;
+    HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(cf, dim3((unsigned)grid2), dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total = nullptr) {
     // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
     // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
     if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa, redo_total);
+    if (dense_weighted_eligible(g, wa, extend)) return launch_dense_weighted(g, wa, extend, redo_total);
     int occ = 0;
     walk_kernel_fn fn = pick_kernel(g, extend);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
