@@ -1304,9 +1304,12 @@ static int launch_dense_bits(pw_graph *g, const pw::WalkArgs &wa, uint64_t *redo
     typedef void (*fast_fn)(pw::DenseArgs, uint32_t *, unsigned long long *, uint32_t);
     fast_fn ff = nullptr;
     if (fn != pw::walk_dense_bits_kernel<0> && is_pow2_double(1.0 / wa.p) && is_pow2_double(1.0 / wa.q) && !getenv("PECANPY_AMD_DENSE_NO_FAST")) {
-        if (da.wpr <= 64 * 8) ff = pw::walk_dense_fast_kernel<8, 0>;
-        else if (da.wpr <= 64 * 16) ff = pw::walk_dense_fast_kernel<16, 8>;
-        else if (da.wpr <= 64 * 25) ff = pw::walk_dense_fast_kernel<25, 16>;
+        // (round 6: prev's row in LDS instead of registers -- three wavefronts per SIMD instead of two; PECANPY_AMD_DENSE_KEEP_REGS=1:
+        //  the register form, rounds 3-5)
+        const bool ldsk = getenv("PECANPY_AMD_DENSE_KEEP_REGS") == nullptr;
+        if (da.wpr <= 64 * 8) ff = ldsk ? pw::walk_dense_fast_kernel<8, 0, true> : pw::walk_dense_fast_kernel<8, 0>;
+        else if (da.wpr <= 64 * 16) ff = ldsk ? pw::walk_dense_fast_kernel<16, 8, true> : pw::walk_dense_fast_kernel<16, 8>;
+        else if (da.wpr <= 64 * 25) ff = ldsk ? pw::walk_dense_fast_kernel<25, 16, true> : pw::walk_dense_fast_kernel<25, 16>;
         else ff = pw::walk_dense_fast_kernel<32, 25>;
     }
     auto grid_for = [&](const void *f, uint64_t work, unsigned *out) -> int {

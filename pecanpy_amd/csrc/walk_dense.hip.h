@@ -529,12 +529,18 @@ walk_dense_bits_kernel(DenseArgs a) {
 // (128) spills in the step loop: 199 / 57 M steps/s against 396 at ER-100k.  At 396 M steps/s x 12.5 KB per row the kernel
 // moves 5 TB/s, four fifths of the achievable HBM rate.)
 // FULL: the first FULL word groups lie inside every row this instantiation is launched for (wpr > 64 * FULL): no bounds test.
-template <int WPL, int FULL>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE)
+// LDSK (round 6): the row of the vertex the walk came from waits in LDS (WPL x 512 bytes per wavefront; every lane reads and
+// writes its own slots only: no barrier) and is REPLACED word by word by the row of cur inside the count pass, so no row is
+// live in registers across the decision; the four words per lane of the target segment are then read back -- cur's from LDS,
+// prev's from memory again (2 KB, read one step ago: cache hits).  Three wavefronts per SIMD instead of two.
+template <int WPL, int FULL, bool LDSK = false>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, LDSK ? 3 : 1)
 walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *redo_count, uint32_t redo_every) {
     constexpr int NSEG = (WPL + 3) / 4;   // a segment = DQW 64-bit words = 4 words per lane
     static_assert(DQW / WAVE == 4, "segment = four words per lane");
     const int lane = lane_id();
+    __shared__ uint64_t s_keep[LDSK ? WAVES_PER_BLOCK * WPL * WAVE : 1];
+    uint64_t *const lk = s_keep + (LDSK ? (threadIdx.x / WAVE) * (WPL * WAVE) + lane : 0);   // slot i of this lane: lk[i * WAVE]
     const uint32_t L = a.L, n = a.n, wpr = a.wpr;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
@@ -553,10 +559,12 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
         uint32_t cur = start, prev = 0;
         uint32_t len_out = L + 1;
         double rbuf = 0.0;
-        uint64_t keep[WPL];   // row of the vertex the walk was at one step ago (word i * 64 + lane)
+        uint64_t keep[LDSK ? 1 : WPL];   // row of the vertex the walk was at one step ago (word i * 64 + lane)
         uint64_t cws[WPL];    // row of cur
+        if (!LDSK) {
 #pragma unroll
-        for (int i = 0; i < WPL; i++) keep[i] = 0ull;
+            for (int i = 0; i < WPL; i++) keep[LDSK ? 0 : i] = 0ull;
+        }
         bool redo = false, dead = false;
         uint32_t j = 1;
         for (; j <= L; j++) {
@@ -570,10 +578,13 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
             const double r = readlane_f64(rbuf, (int)jr);
             const bool has_prev = j >= 2;
             const uint64_t *__restrict__ crow = a.adjbits + (uint64_t)cur * wpr;
+            // (scalar base + this lane's 32-bit byte offset + a constant: ONE address register for the whole row instead of a
+            //  64-bit address per load)
+            const char *const crow_lane = (const char *)crow + (uint64_t)((uint32_t)lane * 8u);
 #pragma unroll
             for (int i = 0; i < WPL; i++) {   // every load of the row in flight at once
                 const uint32_t w = (uint32_t)i * WAVE + lane;
-                cws[i] = (i < FULL || w < wpr) ? crow[w] : 0ull;
+                cws[i] = (i < FULL || w < wpr) ? *(const uint64_t *)(crow_lane + (size_t)i * (WAVE * 8)) : 0ull;
             }
             uint32_t n_pv = 0;
             if (has_prev) n_pv = (uint32_t)((uni(crow[prev >> 6]) >> (prev & 63)) & 1ull);
@@ -586,8 +597,10 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                 const uint32_t w = (uint32_t)i * WAVE + lane;
                 uint64_t cw = cws[i];
                 if (has_prev && (prev >> 6) == w) cw &= ~(1ull << (prev & 63));   // prev forms its own class
-                const uint32_t ci = (uint32_t)__popcll(cw & keep[i]);
+                const uint64_t kw = LDSK ? (has_prev ? lk[i * WAVE] : 0ull) : keep[LDSK ? 0 : i];
+                const uint32_t ci = (uint32_t)__popcll(cw & kw);
                 pks[i / 4] += ci | (((uint32_t)__popcll(cw) - ci) << 16);           // (<= 256 per lane and class)
+                if (LDSK) lk[i * WAVE] = cws[i];
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
@@ -633,7 +646,20 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
             // the eight words of the target segment; then the row of cur BECOMES the prev row of the next step: from here
             // on one copy of a row is live (the search works on the words just taken out)
             uint64_t c4[4] = {0, 0, 0, 0}, p4[4] = {0, 0, 0, 0};
-            {
+            if (LDSK) {
+                if (sx != NOT_FOUND) {
+                    const uint64_t *__restrict__ prow = a.adjbits + (uint64_t)prev * wpr;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const uint32_t wi = 4u * sx + (uint32_t)jj;
+                        const uint32_t w = wi * WAVE + (uint32_t)lane;
+                        if (wi < (uint32_t)WPL) {
+                            c4[jj] = lk[wi * WAVE];
+                            if (has_prev && w < wpr) p4[jj] = prow[w];
+                        }
+                    }
+                }
+            } else {
 #define PW_DSEG(SG)                                                                  \
     case SG:                                                                         \
         _Pragma("unroll") for (int jj = 0; jj < 4; jj++) {                           \
@@ -643,8 +669,10 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                     switch (sx) { PW_DSEG(0) PW_DSEG(1) PW_DSEG(2) PW_DSEG(3) PW_DSEG(4) PW_DSEG(5) PW_DSEG(6) PW_DSEG(7) default: break; }
 #undef PW_DSEG
             }
+            if (!LDSK) {
 #pragma unroll
-            for (int i = 0; i < WPL; i++) keep[i] = cws[i];
+                for (int i = 0; i < WPL; i++) keep[LDSK ? 0 : i] = cws[i];
+            }
             if (sx != NOT_FOUND) {
                 {
                     uint64_t in4[4], out4[4];
@@ -712,7 +740,7 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
             if (redo_every && j == 3 && job % redo_every == 0) { redo = true; break; }   // (test switch: exercises the hand-over)
             if (lane == 0) row[j] = nxt;
             prev = cur;
-            cur = nxt;
+            cur = uni(nxt);   // (a scalar: the row loads take their base from scalar registers)
         }
         if (redo) {   // walk_dense_bits_kernel walks this job again (and writes the whole row)
             if (lane == 0) redo_list[atomicAdd(redo_count, 1ull)] = (uint32_t)job;

@@ -12,16 +12,19 @@
 //     (per lane, per 256-element block, block prefixes P[b] kept in LDS).  Membership of a column in prev's row is one bit of
 //     prev's packed row (N/8 bytes, staged in LDS once per step); node2vec+ finds data[prev, x] at the RANK of bit x in that
 //     row (prefix popcounts per word in LDS): prev's float64 weights are gathered in ascending order, its columns never read.
-//   * Every value is non-negative, so ANY summation order of n terms errs by at most (1+u)^(n-1) - 1 relative, u = 2^-53.
-//     With S(k) the real prefix sums and TOT = S(n-1):  tot_ref = TOT (1+b), |b| <= (1+u)^(n-1) - 1;  the reference's chain
-//     c_k = S(k) / tot_ref * (1+a_k), |a_k| <= (1+u)^(k+2) - 1 (one rounding per quotient, one per addition applied to a
-//     partial sum that only grows);  this kernel's S~(k) = S(k)(1+s_k), TOT~ = TOT (1+t), T = fl(r * TOT~).  Hence
-//         c_k >= r  <=>  S~(k) >= T * F,   F in [1 - E, 1 + E],   E = 4 (n + 32) u (1 + 2^-20)
-//     (at most 2 n + 2 n / 256 + 45 factors (1 +- u) in F).  The chain is monotone, so with k1 the first element of the block
+//   * Every value is non-negative, so a sum in ANY order in which no term passes through more than m additions errs by at
+//     most (1+u)^m - 1 relative, u = 2^-53.  With S(k) the real prefix sums and TOT = S(n-1):  the reference's
+//     tot_ref = TOT (1+b), 1+b a product of at most n-1 factors (1 +- u);  its chain c_k = S(k) / tot_ref * (1+a_k), at most
+//     k+1 factors (one rounding per quotient, one per addition applied to a partial sum that only grows);  this kernel's
+//     S~(k) = S(k)(1+s_k) and TOT~ = TOT (1+t), at most nblk+14 and nblk+10 factors (4 additions per lane and block, 6 levels
+//     of the wave sum, nblk block prefixes; in the block scan 3 + 6 + 1 more);  T = fl(r * TOT~), one.  Hence
+//         c_k >= r  <=>  S~(k) >= T * F,   |F - 1| <= E = (2 n + 2 nblk + 32) u (1 + 2^-20)
+//     The chain is monotone, so with k1 the first element of the block
 //     scan whose S~ reaches T (1 - E):  S~(k1 - 1) < T (1 - E)  and  S~(k1) >= T (1 + E)  prove  c_{k1-1} < r <= c_{k1}, i.e.
-//     k1 is what np.searchsorted returns.  A partial sum inside [T (1 - E), T (1 + E)) -- probability ~ 4 n u per step, 10^-11
-//     at n = 20 000 -- a negative / non-finite value, or a draw no partial sum reaches (the reference then reads past the
-//     row) hands the WALK to the complete kernel through the redo list, as walk_dense_fast_kernel does.
+//     k1 is what np.searchsorted returns.  A partial sum inside [T (1 - E), T (1 + E)) -- probability ~ 2 n^2 u per step: 10^-8
+//     at n = 5 000 non-zeros, one walk in 10^6 -- a negative / non-finite value, or a draw no partial sum reaches (the
+//     reference then reads past the row) hands the WALK to the complete kernel through the redo list, as
+//     walk_dense_fast_kernel does.
 //   * the block that holds k1 (256 elements, 3 KB) is read a second time and scanned; nothing else is read twice.
 //
 // Declared bytes per step: 12 d(cur) + N / 8 (+ 8 d(prev) for node2vec+) + 8 (draw) + 4 (output).
@@ -231,7 +234,8 @@ walk_dense_weighted_kernel(DenseWArgs a) {
             wave_lds_fence();
             const double TOT = run;
             // ---- thresholds of the bounded decision (header) ----
-            const double E = (4.0 * ((double)d + 32.0) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
+            // (2 d + 2 nblk + 32 factors (1 +- u) at most: header; + 8 u for the two thresholds' own roundings)
+            const double E = ((2.0 * (double)d + 2.0 * (double)nblk + 32.0) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
             const double T = r * TOT;
             const double Tl = T - T * E, Th = T + T * E;
             bool ok = ballot(bad) == 0ull && TOT > 0.0 && TOT < 0x1p1000;
