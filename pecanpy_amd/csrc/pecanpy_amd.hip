@@ -905,7 +905,10 @@ PW_EXPORT int pw_dense_create(const double *data, uint32_t n_nodes, int device, 
     if (!rc) rc = up((void **)&g->d_adjbits, bits.data(), sizeof(uint64_t) * bits.size());
     if (!rc) {
         std::vector<uint32_t> deg(n);
-        for (uint64_t i = 0; i < n; i++) deg[i] = indptr[i + 1] - indptr[i];
+        for (uint64_t i = 0; i < n; i++) {
+            deg[i] = indptr[i + 1] - indptr[i];
+            if (deg[i] > g->max_degree) g->max_degree = deg[i];
+        }
         rc = up((void **)&g->d_deg, deg.data(), sizeof(uint32_t) * deg.size());
     }
     if (rc) { pw_graph_destroy(g); return rc; }
@@ -1507,7 +1510,7 @@ static bool dense_weighted_eligible(const pw_graph *g, const pw::WalkArgs &wa, b
     if (extend && !g->d_thr) return false;
     if (wa.resume || getenv("PECANPY_AMD_DENSE_NO_WFAST")) return false;
     // LDS of one wavefront: prev's packed row + its prefix popcounts + the block prefixes
-    const uint64_t lds = (uint64_t)g->words_per_row * 12u + ((uint64_t)g->n_nodes / pw::DWBLK + 2u) * 8u;
+    const uint64_t lds = (uint64_t)g->words_per_row * 12u + ((uint64_t)g->max_degree / pw::DWBLK_MIN + 2u) * 8u;
     return lds <= 60u * 1024u;
 }
 
@@ -1540,7 +1543,7 @@ static int launch_dense_weighted(pw_graph *g, const pw::WalkArgs &wa, bool exten
     da.redo_count = g->counters.p + 6;
     const char *rt = getenv("PECANPY_AMD_DENSE_REDO_TEST");   // tests: every k-th walk is handed over at its third step
     da.redo_every = rt ? (uint32_t)strtoul(rt, nullptr, 10) : 0u;
-    da.lds_blocks = g->n_nodes / pw::DWBLK + 2u;
+    da.lds_blocks = g->max_degree / pw::DWBLK_MIN + 2u;
     const size_t lds = (size_t)da.wpr * 8u + (size_t)da.lds_blocks * 8u + (size_t)da.wpr * 4u;
     typedef void (*dw_fn)(pw::DenseWArgs);
     dw_fn fn = extend ? pw::walk_dense_weighted_kernel<true> : pw::walk_dense_weighted_kernel<false>;

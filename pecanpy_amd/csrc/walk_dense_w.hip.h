@@ -9,16 +9,17 @@
 //
 //   * ONE pass over the compressed row of cur (uint32 column + float64 weight per non-zero, coalesced) computes every biased
 //     value e_j EXACTLY as the reference does (same divisions / products, -ffp-contract=off) and sums them in ANY order
-//     (per lane, per 256-element block, block prefixes P[b] kept in LDS).  Membership of a column in prev's row is one bit of
+//     (per lane, per block of 256 elements -- 128 for node2vec+ --, block prefixes P[b] kept in LDS).  Membership of a column in prev's row is one bit of
 //     prev's packed row (N/8 bytes, staged in LDS once per step); node2vec+ finds data[prev, x] at the RANK of bit x in that
 //     row (prefix popcounts per word in LDS): prev's float64 weights are gathered in ascending order, its columns never read.
 //   * Every value is non-negative, so a sum in ANY order in which no term passes through more than m additions errs by at
 //     most (1+u)^m - 1 relative, u = 2^-53.  With S(k) the real prefix sums and TOT = S(n-1):  the reference's
 //     tot_ref = TOT (1+b), 1+b a product of at most n-1 factors (1 +- u);  its chain c_k = S(k) / tot_ref * (1+a_k), at most
 //     k+1 factors (one rounding per quotient, one per addition applied to a partial sum that only grows);  this kernel's
-//     S~(k) = S(k)(1+s_k) and TOT~ = TOT (1+t), at most nblk+14 and nblk+10 factors (4 additions per lane and block, 6 levels
-//     of the wave sum, nblk block prefixes; in the block scan 3 + 6 + 1 more);  T = fl(r * TOT~), one.  Hence
-//         c_k >= r  <=>  S~(k) >= T * F,   |F - 1| <= E = (2 n + 2 nblk + 32) u (1 + 2^-20)
+//     S~(k) = S(k)(1+s_k) and TOT~ = TOT (1+t), at most nblk + 2 B + 12 and nblk + B + 6 factors (B additions per lane and
+//     block of B x 64 elements, 6 levels of the wave sum, nblk block prefixes; in the block scan B - 1 + 6 + 1 more);
+//     T = fl(r * TOT~), one.  Hence
+//         c_k >= r  <=>  S~(k) >= T * F,   |F - 1| <= E = (2 n + 2 nblk + 3 B + 20) u (1 + 2^-20)
 //     The chain is monotone, so with k1 the first element of the block
 //     scan whose S~ reaches T (1 - E):  S~(k1 - 1) < T (1 - E)  and  S~(k1) >= T (1 + E)  prove  c_{k1-1} < r <= c_{k1}, i.e.
 //     k1 is what np.searchsorted returns.  A partial sum inside [T (1 - E), T (1 + E)) -- probability ~ 2 n^2 u per step: 10^-8
@@ -33,8 +34,13 @@
 
 namespace pw {
 
-constexpr int DWB = 4;                        // 64-element iterations per block
-constexpr uint32_t DWBLK = DWB * WAVE;        // elements per block
+#ifndef PW_DWB
+#define PW_DWB 4       // 64-element iterations per block, node2vec (HBM bound at 2 .. 8: ER-20k 149.0 / 149.5 / 151.3 ms per pass)
+#endif
+#ifndef PW_DWB_EXT
+#define PW_DWB_EXT 2   // ... node2vec+ (the gathers behind the column load make it latency bound: 70 VGPRs and seven wavefronts per
+#endif                 // SIMD at 2, 84 / five at 4, 112 / four at 8: ER-20k 274 / 286 / 321 ms per pass)
+constexpr uint32_t DWBLK_MIN = WAVE;          // smallest block any instantiation uses (host: capacity of the block-prefix array)
 
 struct DenseWArgs {
     const uint32_t *__restrict__ indptr;
@@ -58,7 +64,7 @@ struct DenseWArgs {
     uint32_t *redo_list;
     unsigned long long *redo_count;
     uint32_t redo_every;                      // tests: every k-th walk is handed over at its third step
-    uint32_t lds_blocks;                      // capacity of the block-prefix array (>= max degree / 256 + 2)
+    uint32_t lds_blocks;                      // capacity of the block-prefix array (>= max degree / DWBLK_MIN + 2)
 };
 
 __device__ __forceinline__ double dw_wave_sum(double v) {
@@ -109,6 +115,8 @@ template <bool EXTEND> struct DenseWStep {
 template <bool EXTEND>
 __global__ void __launch_bounds__(WAVE)
 walk_dense_weighted_kernel(DenseWArgs a) {
+    constexpr int DWB = EXTEND ? PW_DWB_EXT : PW_DWB;
+    constexpr uint32_t DWBLK = DWB * WAVE;        // elements per block
     extern __shared__ uint64_t dw_lds[];
     uint64_t *pb = dw_lds;                               // [wpr]
     double *P = (double *)(pb + a.wpr);                  // [lds_blocks]
@@ -234,8 +242,8 @@ walk_dense_weighted_kernel(DenseWArgs a) {
             wave_lds_fence();
             const double TOT = run;
             // ---- thresholds of the bounded decision (header) ----
-            // (2 d + 2 nblk + 32 factors (1 +- u) at most: header; + 8 u for the two thresholds' own roundings)
-            const double E = ((2.0 * (double)d + 2.0 * (double)nblk + 32.0) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
+            // (2 d + 2 nblk + 3 DWB + 20 factors (1 +- u) at most: header; + 8 u for the two thresholds' own roundings)
+            const double E = ((2.0 * (double)d + 2.0 * (double)nblk + (double)(3 * DWB + 20)) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
             const double T = r * TOT;
             const double Tl = T - T * E, Th = T + T * E;
             bool ok = ballot(bad) == 0ull && TOT > 0.0 && TOT < 0x1p1000;
