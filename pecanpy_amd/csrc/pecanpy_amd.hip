@@ -1543,6 +1543,8 @@ static int launch_dense_weighted(pw_graph *g, const pw::WalkArgs &wa, bool exten
     da.redo_count = g->counters.p + 6;
     const char *rt = getenv("PECANPY_AMD_DENSE_REDO_TEST");   // tests: every k-th walk is handed over at its third step
     da.redo_every = rt ? (uint32_t)strtoul(rt, nullptr, 10) : 0u;
+    const char *xt = getenv("PECANPY_AMD_DENSE_EXACT_TEST");  // tests: steps with (job + step) % k == 0 are decided by the in-kernel chain
+    da.exact_every = xt ? (uint32_t)strtoul(xt, nullptr, 10) : 0u;
     da.lds_blocks = g->max_degree / pw::DWBLK_MIN + 2u;
     const size_t lds = (size_t)da.wpr * 8u + (size_t)da.lds_blocks * 8u + (size_t)da.wpr * 4u;
     typedef void (*dw_fn)(pw::DenseWArgs);

@@ -25,7 +25,10 @@
 //     k1 is what np.searchsorted returns.  A partial sum inside [T (1 - E), T (1 + E)) -- probability ~ 2 n^2 u per step: 10^-8
 //     at n = 5 000 non-zeros, one walk in 10^6 -- a negative / non-finite value, or a draw no partial sum reaches (the
 //     reference then reads past the row) hands the WALK to the complete kernel through the redo list, as
-//     walk_dense_fast_kernel does.
+//     walk_dense_fast_kernel does.  Round 6, second half: a step whose partial sum falls inside the interval is decided IN PLACE
+//     by the reference's two loops themselves (values 64 at a time, the float64 additions one after the other in row order:
+//     ~40 us of one wavefront) -- one redone walk cost ~10 ms of the complete kernel behind a 140 ms pass; only negative /
+//     non-finite values and the read past the row still go to the redo list.
 //   * the block that holds k1 (256 elements, 3 KB) is read a second time and scanned; nothing else is read twice.
 //
 // Declared bytes per step: 12 d(cur) + N / 8 (+ 8 d(prev) for node2vec+) + 8 (draw) + 4 (output).
@@ -64,6 +67,7 @@ struct DenseWArgs {
     uint32_t *redo_list;
     unsigned long long *redo_count;
     uint32_t redo_every;                      // tests: every k-th walk is handed over at its third step
+    uint32_t exact_every;                     // tests: steps with (job + step) % k == 0 skip the bounded decision (the in-kernel chain decides)
     uint32_t lds_blocks;                      // capacity of the block-prefix array (>= max degree / DWBLK_MIN + 2)
 };
 
@@ -125,7 +129,7 @@ walk_dense_weighted_kernel(DenseWArgs a) {
     const uint32_t L = a.L, n = a.n, wpr = a.wpr;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.job_list ? a.n_list : a.n_jobs;
-    unsigned long long st_steps = 0, st_dead = 0;
+    unsigned long long st_steps = 0, st_dead = 0, st_exact = 0;
 
     DenseWStep<EXTEND> sv;
     sv.pb = pb;
@@ -246,9 +250,10 @@ walk_dense_weighted_kernel(DenseWArgs a) {
             const double E = ((2.0 * (double)d + 2.0 * (double)nblk + (double)(3 * DWB + 20)) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
             const double T = r * TOT;
             const double Tl = T - T * E, Th = T + T * E;
-            bool ok = ballot(bad) == 0ull && TOT > 0.0 && TOT < 0x1p1000;
+            const bool ok = ballot(bad) == 0ull && TOT > 0.0 && TOT < 0x1p1000;
             uint32_t nxt = NOT_FOUND;
-            if (ok) {
+            const bool force_exact = a.exact_every && (job + j) % a.exact_every == 0;   // (test switch)
+            if (ok && !force_exact) {
                 uint32_t tb = NOT_FOUND;
                 for (uint32_t b0 = 0; b0 < nblk && tb == NOT_FOUND; b0 += WAVE) {
                     const uint32_t b = b0 + (uint32_t)lane;
@@ -282,7 +287,31 @@ walk_dense_weighted_kernel(DenseWArgs a) {
                     }
                 }
             }
-            if (nxt == NOT_FOUND || nxt >= n) { redo = true; break; }
+            if (nxt == NOT_FOUND && ok) {
+                // ---- a partial sum inside the bound's interval: the reference's two loops themselves, in their order ----
+                // (values 64 at a time in parallel, the additions one after the other: ~40 us of one wavefront, once per ~10^8
+                //  steps; the complete kernel would walk the whole walk again: ~10 ms)
+                double tot = 0.0;
+                for (uint32_t k0 = 0; k0 < d; k0 += WAVE) {                       // tot = w.sum()  (dense_rw.py:69 / 116)
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const double e = sv.value(k < d ? cols[k] : 0u, k < d ? wts[k] : 0.0);
+                    const uint32_t m = d - k0 < (uint32_t)WAVE ? d - k0 : (uint32_t)WAVE;
+                    for (uint32_t l = 0; l < m; l++) tot = tot + readlane_f64(e, (int)l);
+                }
+                double c = 0.0;
+                for (uint32_t k0 = 0; k0 < d && nxt == NOT_FOUND; k0 += WAVE) {   // cdf = np.cumsum(w / tot); searchsorted (pecanpy.py:609-610)
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const uint32_t col = k < d ? cols[k] : 0u;
+                    const double v = sv.value(col, k < d ? wts[k] : 0.0) / tot;
+                    const uint32_t m = d - k0 < (uint32_t)WAVE ? d - k0 : (uint32_t)WAVE;
+                    for (uint32_t l = 0; l < m; l++) {
+                        c = c + readlane_f64(v, (int)l);
+                        if (c >= r) { nxt = readlane_u32(col, (int)l); break; }
+                    }
+                }
+                st_exact++;
+            }
+            if (nxt == NOT_FOUND || nxt >= n) { redo = true; break; }   // (no partial sum reaches r: the reference reads past the row)
             if (a.redo_every && j == 3 && job % a.redo_every == 0) { redo = true; break; }
             if (lane == 0) row[j] = nxt;
             prev = cur;
@@ -300,6 +329,7 @@ walk_dense_weighted_kernel(DenseWArgs a) {
     if (lane == 0) {
         if (st_steps) atomicAdd(&a.stats[0], st_steps);
         if (st_dead) atomicAdd(&a.stats[3], st_dead);
+        if (st_exact) atomicAdd(&a.stats[7], st_exact);   // (pw_stats.ambiguous_steps: steps decided by the float64 chain itself)
     }
 }
 

@@ -68,6 +68,11 @@ def test_bounded_kernel_equals_the_complete_kernel_and_the_oracle(extend, gamma,
     m = 300
     want, ost = orc.walks_dense_otf(mat, p, q, starts[:m], L, 5, thr=thr, return_stats=True)
     assert np.array_equal(fast[:m], want)
+    # the in-kernel float64 chain (what decides a step whose partial sum falls inside the bound's interval: one in ~10^8) on
+    # every fifth step -- same matrix, and the counter says so
+    ex, sx = _run(eng, p, q, extend, starts, L, 5, {"PECANPY_AMD_DENSE_EXACT_TEST": "5"})
+    assert np.array_equal(ex, fast) and sx["redo_walks"] == 0
+    assert sx["ambiguous_steps"] >= sf["total_steps"] // 6 and sf["ambiguous_steps"] <= 2
     # the hand-over: every 7th walk is given to the complete kernel at its third step -- same matrix
     redo, sr = _run(eng, p, q, extend, starts, L, 5, {"PECANPY_AMD_DENSE_REDO_TEST": "7"})
     assert np.array_equal(redo, fast) and sr["redo_walks"] >= starts.size // 7 - 1 and sr["total_steps"] == sf["total_steps"]
