@@ -742,7 +742,10 @@ static thread_local uint64_t g_lane_seq_elems = 0, g_lane_binades = 0;
 __device__ unsigned long long g_wd[32];   // debug builds: state of a wavefront / thread whose loop ran away
 #endif
 constexpr uint32_t LANE_HEAD = 32;        // leading elements added one by one
-constexpr uint32_t LANE_TIE_BUDGET = 4096;  // runs walked one by one inside binades with a rounding tie
+#ifndef PW_LANE_TIE_BUDGET
+#define PW_LANE_TIE_BUDGET 4096
+#endif
+constexpr uint32_t LANE_TIE_BUDGET = PW_LANE_TIE_BUDGET;  // runs walked one by one inside binades with a rounding tie
 
 struct ChainEval {   // partial sum (in ulps of the current binade) after common neighbour i at position P
     uint64_t C, ii, io;
@@ -760,8 +763,10 @@ struct ChainEval {   // partial sum (in ulps of the current binade) after common
 // kernel, where every step is two chains and their dependent probes are what a step waits for (+5 %); the chain
 // kernels of the dyadic path run ~60 probes per chain at full occupancy and lose 3 % of a pass to the extra traffic.
 template <bool WIDE = false>
+// tie_budget_init: runs a binade with a rounding tie may be walked by (0: return LANE_TIE at the first such binade --
+// lanes_chain_kernel's first pass, which leaves those chains to a second, densely packed launch).
 PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
-                          const ListView &cl, uint32_t &reads, float *c_end = nullptr) {
+                          const ListView &cl, uint32_t &reads, float *c_end = nullptr, uint32_t tie_budget_init = LANE_TIE_BUDGET) {
     using B = Binade<float>;
     float c = 0.0f;
     uint32_t k = 0;    // next element to add
@@ -803,7 +808,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
     // the sum changes binade every few elements at first (and the values tie there half of the time)
     PW_LANE_SEQ(LANE_HEAD, 0);
     if (hit) return k;
-    uint32_t tie_budget = LANE_TIE_BUDGET;
+    uint32_t tie_budget = tie_budget_init;
 #if defined(PW_LANES_WATCHDOG) && defined(__HIP_DEVICE_COMPILE__)
     uint32_t wd_chain = 0;
 #endif
@@ -847,9 +852,15 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
                 if (m) {
                     const uint64_t first = (Cc & 1ull) ? qo.a1 : qo.a0;
                     const uint64_t each = qo.a0;   // no tie: a0 == a1; after a tying addition the sum is even
-                    // smallest t in [1, m] with Cc + first + (t - 1) * each >= Tt
-                    uint64_t t = 1;
-                    if (Cc + first < Tt) t = each ? 2ull + div_floor_small(Tt - (Cc + first) - 1ull, each) : 0xffffffffull;
+                    // smallest t in [1, m] with Cc + first + (t - 1) * each >= Tt -- the division only for the ONE run that gets
+                    // there (the sums grow: a run whose last element stays below Tt has no such t); round 6: this loop runs once
+                    // per common neighbour of a tying binade -- thousands of times on a hub row -- and was 7.7 of the chain
+                    // kernels' 17.6 ms per RMAT-22 pass
+                    uint64_t t = 0xffffffffull;
+                    if (Cc + first + (uint64_t)(m - 1u) * each >= Tt) {
+                        t = 1;
+                        if (Cc + first < Tt) t = each ? 2ull + div_floor_small(Tt - (Cc + first) - 1ull, each) : 0xffffffffull;
+                    }
                     if (t <= m) {
                         kf = k + (uint32_t)t - 1u;
                         const uint64_t Cf = Cc + first + (t - 1ull) * each;
