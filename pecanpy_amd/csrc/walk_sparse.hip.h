@@ -311,7 +311,10 @@ constexpr int WAVES_PER_BLOCK = 4;
 #endif
 constexpr int MASK_WORDS = PW_MASK_WORDS;        // per wave: 32*MASK_WORDS neighbours per segment
 constexpr uint32_t SEG = MASK_WORDS * 32;
-constexpr uint32_t CHAIN_CKPT = 1024;   // weighted lane form: spacing of the recorded chain values (divides SEG, multiple of the scan's 256-element trips)
+#ifndef PW_CHAIN_CKPT
+#define PW_CHAIN_CKPT 256   // (round 6: 1024 -> 256: a parked step scans at most 256 elements + its window instead of 1024; C5 311 -> 282 ms
+#endif                      //  per pass, 1 404 -> 1 553 M steps/s; 512: 292 ms; the records take 360 instead of 90 MB at weighted RMAT-20)
+constexpr uint32_t CHAIN_CKPT = PW_CHAIN_CKPT;   // weighted lane form: spacing of the recorded chain values (divides SEG, multiple of the scan's 256-element trips)
 constexpr int EPL = 4;                           // elements per lane per generic scan pass
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return readfirst_u32(v); }
 __device__ __forceinline__ double uni(double v) {
