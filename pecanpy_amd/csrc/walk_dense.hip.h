@@ -602,15 +602,10 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                 pks[i / 4] += ci | (((uint32_t)__popcll(cw) - ci) << 16);           // (<= 256 per lane and class)
                 if (LDSK) lk[i * WAVE] = cws[i];
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                for (int sg = 0; sg < NSEG; sg++) pks[sg] += (uint32_t)__shfl_xor((int)pks[sg], off, WAVE);
-            }
             uint32_t n_in = 0, n_out = 0;
 #pragma unroll
-            for (int sg = 0; sg < NSEG; sg++) {
-                pks[sg] = uni(pks[sg]);
+            for (int sg = 0; sg < NSEG; sg++) {   // (DPP sums: wave.h; round 6 -- 78 ds_bpermute trips per step before)
+                pks[sg] = wave_sum_u32(pks[sg]);
                 n_in += pks[sg] & 0xffffu;
                 n_out += pks[sg] >> 16;
             }
@@ -686,12 +681,9 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                         out4[jj] = cw & ~p4[jj];
                         pk[jj] = (uint32_t)__popcll(in4[jj]) | ((uint32_t)__popcll(out4[jj]) << 16);
                     }
-                    uint32_t sm4[4] = {pk[0], pk[1], pk[2], pk[3]};   // four independent wave sums, interleaved
+                    uint32_t sm4[4];   // four independent wave sums
 #pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) sm4[jj] += (uint32_t)__shfl_xor((int)sm4[jj], off, WAVE);
-                    }
+                    for (int jj = 0; jj < 4; jj++) sm4[jj] = wave_sum_u32(pk[jj]);
                     uint64_t in_s = 0, out_s = 0, eg = e0;
                     uint32_t pk_s = 0, g_sel = NOT_FOUND;
 #pragma unroll
@@ -706,12 +698,7 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                         }
                     }
                     if (g_sel != NOT_FOUND) {
-                        uint32_t incl = pk_s;   // inclusive scan over the lanes (the halves cannot carry: sums <= 4096)
-#pragma unroll
-                        for (int off = 1; off < WAVE; off <<= 1) {
-                            const uint32_t y = (uint32_t)__shfl_up((int)incl, (unsigned)off, WAVE);
-                            if (lane >= off) incl += y;
-                        }
+                        const uint32_t incl = wave_incl_scan_u32(pk_s);   // inclusive scan over the lanes (the halves cannot carry: sums <= 4096)
                         const bool pv_here = pw_word != NOT_FOUND && (pw_word >> 6) == g_sel;
                         const uint32_t pv_lane = pw_word & 63u;
                         const uint64_t G = eg + (uint64_t)(incl & 0xffffu) * Wi + (uint64_t)(incl >> 16) * Wo +

@@ -53,6 +53,27 @@ template <> __device__ __forceinline__ uint64_t shfl_up_uint<uint64_t>(uint64_t 
 
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 
+// ---- data-parallel-primitive (DPP) sums: a lane adds the value of another lane as an operand modifier of the add itself --
+// no LDS crossbar trip (ds_bpermute), no address register, no lgkmcnt wait.  Inclusive scan over the 64 lanes: row_shr 1, 2,
+// 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3
+// (row_bcast:31); lanes without a source add 0.  The total is what lane 63 holds.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xF>(v);
+    v = dpp_add_u32<0x112, 0xF>(v);
+    v = dpp_add_u32<0x114, 0xF>(v);
+    v = dpp_add_u32<0x118, 0xF>(v);
+    v = dpp_add_u32<0x142, 0xA>(v);
+    v = dpp_add_u32<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // wave-uniform result (a scalar register)
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), WAVE - 1);
+}
+
 // orders this wave's LDS traffic (cross-lane hand-off through LDS inside one wavefront)
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
