@@ -72,9 +72,7 @@ struct DenseWArgs {
 };
 
 __device__ __forceinline__ double dw_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return readlane_f64(v, 0);   // ONE value for the whole wavefront (the lanes' association orders differ)
+    return readlane_f64(wave_incl_scan_f64(v), WAVE - 1);   // ONE value for the whole wavefront: the scan's last lane (6 additions deep)
 }
 
 // The biased value of one non-zero of cur's row, statement by statement the reference's arithmetic.
@@ -196,13 +194,8 @@ walk_dense_weighted_kernel(DenseWArgs a) {
                     const uint64_t v = w < wpr ? prow[w] : 0ull;
                     if (w < wpr) pb[w] = v;
                     if (EXTEND) {
-                        uint32_t incl = (uint32_t)__popcll(v);
-                        const uint32_t own = incl;
-#pragma unroll
-                        for (int off = 1; off < WAVE; off <<= 1) {
-                            const uint32_t y = (uint32_t)__shfl_up((int)incl, (unsigned)off, WAVE);
-                            if (lane >= off) incl += y;
-                        }
+                        const uint32_t own = (uint32_t)__popcll(v);
+                        const uint32_t incl = wave_incl_scan_u32(own);
                         if (w < wpr) pr[w] = carry + incl - own;
                         carry += readlane_u32(incl, WAVE - 1);
                     }
@@ -267,12 +260,7 @@ walk_dense_weighted_kernel(DenseWArgs a) {
                         const uint32_t k = tb * DWBLK + (uint32_t)i * WAVE + (uint32_t)lane;
                         const uint32_t col = k < d ? cols[k] : 0u;
                         const double w = k < d ? wts[k] : 0.0;
-                        double sc = sv.value(col, w);
-#pragma unroll
-                        for (int off = 1; off < WAVE; off <<= 1) {
-                            const double y = __shfl_up(sc, (unsigned)off, WAVE);
-                            if (lane >= off) sc += y;
-                        }
+                        const double sc = wave_incl_scan_f64(sv.value(col, w));
                         const double S = base + sc;
                         const uint64_t m = ballot(k < d && S >= Tl);
                         if (m) {

@@ -588,7 +588,13 @@ template <typename T, bool UNIT> struct RowVals {
 };
 
 // ---- steps 2/3: bit-exact sequential running sum, evaluated wave-parallel -----------------------------
+// (round 6: the lanes' values travel as DPP operands -- row_shr 1, 2, 4, 8, row_bcast 15 / 31: wave.h -- instead of through the
+//  LDS crossbar; a lane without a source receives (0, 0), the identity of the composition)
+#ifndef PW_SCAN_DPP
+#define PW_SCAN_DPP 1
+#endif
 template <typename T> __device__ __forceinline__ Inc<T> wave_scan_inc(Inc<T> f) {
+#if !PW_SCAN_DPP
     using U = typename FloatTraits<T>::UInt;
     const int lane = lane_id();
 #pragma unroll
@@ -599,6 +605,11 @@ template <typename T> __device__ __forceinline__ Inc<T> wave_scan_inc(Inc<T> f) 
         Inc<T> h = Binade<T>::compose(g, f);
         if (lane >= off) f = h;
     }
+    return f;
+#endif
+#define PW_STEP_(CTRL, RM) { Inc<T> g; g.a0 = dpp_get<CTRL, RM>(f.a0); g.a1 = dpp_get<CTRL, RM>(f.a1); f = Binade<T>::compose(g, f); }
+    PW_DPP_SCAN_LEVELS(PW_STEP_)
+#undef PW_STEP_
     return f;
 }
 
@@ -638,6 +649,11 @@ __device__ __forceinline__ int seq_scan_binade(T &c, uint32_t &k, uint32_t kend,
             U sum = f[0].a0;
 #pragma unroll
             for (int e = 1; e < EPL; e++) { sum += f[e].a0; sum = sum > B::SAT ? B::SAT : sum; }
+#if PW_SCAN_DPP
+#define PW_STEP_(CTRL, RM) { const U t = dpp_get<CTRL, RM>(sum); const U nsum = sum + t; sum = nsum > B::SAT ? B::SAT : nsum; }
+            PW_DPP_SCAN_LEVELS(PW_STEP_)
+#undef PW_STEP_
+#else
 #pragma unroll
             for (int off = 1; off < WAVE; off <<= 1) {
                 U t = shfl_up_uint<U>(sum, off);
@@ -645,6 +661,7 @@ __device__ __forceinline__ int seq_scan_binade(T &c, uint32_t &k, uint32_t kend,
                 nsum = nsum > B::SAT ? B::SAT : nsum;
                 if (lane >= off) sum = nsum;
             }
+#endif
             Cincl = C + sum;
         } else {
             Inc<T> agg = f[0];

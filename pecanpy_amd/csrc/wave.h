@@ -70,6 +70,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     v = dpp_add_u32<0x143, 0xC>(v);
     return v;
 }
+// the same scan over float64 values (two DPP moves + one add per level; lanes without a source add +0.0: exact)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+    v = dpp_add_f64<0x111, 0xF>(v);
+    v = dpp_add_f64<0x112, 0xF>(v);
+    v = dpp_add_f64<0x114, 0xF>(v);
+    v = dpp_add_f64<0x118, 0xF>(v);
+    v = dpp_add_f64<0x142, 0xA>(v);
+    v = dpp_add_f64<0x143, 0xC>(v);
+    return v;
+}
+// the value of the lane a DPP control names (0 for lanes without a source): building block of scans whose operator is not a
+// plain add (saturating sums, parity-function composition: walk_sparse.hip.h)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_get(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp_get(uint64_t v) {
+    const uint32_t lo = dpp_get<CTRL, ROW_MASK>((uint32_t)v), hi = dpp_get<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// the six levels of the 64-lane inclusive scan: STEP(control, row mask)
+#define PW_DPP_SCAN_LEVELS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // wave-uniform result (a scalar register)
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), WAVE - 1);
 }
