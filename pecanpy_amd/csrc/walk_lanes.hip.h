@@ -487,19 +487,26 @@ walk_lanes_kernel(LanesArgs a) {
     // QUAD: one 64-byte slot per lane -- the edge line the walk entered, later the list sector its search looks into
     __shared__ uint4 s_quad[QUAD ? WAVES_PER_BLOCK : 1][4][WAVE];
     uint4 (*const qbuf)[WAVE] = s_quad[QUAD ? readfirst_u32(threadIdx.x / WAVE) : 0];
-    const uint32_t qslot = QUAD ? (uint32_t)(uintptr_t)(lds_ptr_t)&qbuf[0][0] + (uint32_t)lane * 64u : 0u;   // LDS address of this lane's slot
+    // (round 6, second half: instruction k of a fetch serves lane k of every QUAD -- the sector a quad's lanes load is one of
+    //  their own four, handed round by a DPP quad broadcast instead of a ds_bpermute trip through the LDS crossbar -- so lane
+    //  4 j + k owns the 64 bytes the quad j writes in instruction k: slot 16 k + j)
+    const uint32_t qslot = QUAD ? (uint32_t)(uintptr_t)(lds_ptr_t)&qbuf[0][0] + (((uint32_t)lane & 3u) * 16u + ((uint32_t)lane >> 2)) * 64u : 0u;   // LDS address of this lane's slot
     // sector `sec` (64-byte units from `base`) of every lane with `want` set -> that lane's slot.  Converged code only.
     // (0xffffffff names no sector: the lines array has fewer than 2^32 - 1 entries, the overflow array fewer sectors still)
-    const int q_src4 = (lane >> 2) << 2;                                   // byte index of this lane's source lane, instruction 0
     const uint32_t q_piece = (uint32_t)(lane & 3) * 16u;
     auto quad_issue = [&](bool want, const uint8_t *base, uint32_t sec) {
         const uint32_t ws = want ? sec : 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t osec = (uint32_t)__builtin_amdgcn_ds_bpermute(q_src4 + k * 64, (int)ws);
-            if (osec != 0xffffffffu)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (uint64_t)osec * 64u + q_piece), (lds_ptr_t)&qbuf[k][0], 16, 0, 0);
+#define PW_QUAD_K(k, ctrl)                                                                                             \
+        {                                                                                                              \
+            const uint32_t osec = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ws, ctrl, 0xF, 0xF, false);          \
+            if (osec != 0xffffffffu)                                                                                   \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (uint64_t)osec * 64u + q_piece), (lds_ptr_t)&qbuf[k][0], 16, 0, 0); \
         }
+        PW_QUAD_K(0, 0x00)   // quad_perm:[0,0,0,0]
+        PW_QUAD_K(1, 0x55)   // quad_perm:[1,1,1,1]
+        PW_QUAD_K(2, 0xAA)   // quad_perm:[2,2,2,2]
+        PW_QUAD_K(3, 0xFF)   // quad_perm:[3,3,3,3]
+#undef PW_QUAD_K
     };
     // (the compiler does not order an LDS read behind the LDS-DMA that fills it: the wait is explicit)
     auto quad_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
