@@ -730,6 +730,15 @@ PW_HD uint32_t lane_decide_unit_bounded(uint32_t d, uint32_t n_in, uint32_t pp, 
 // the wavefront chain, which implements it).
 constexpr uint32_t LANE_CHAIN_END = 0xfffffffbu;
 constexpr uint32_t LANE_TIE = 0xfffffffau;
+constexpr uint32_t LANE_TIE_PENDING = 0xfffffff8u;   // (lane_chain with a ChainResume: stopped in front of a rounding-tie binade)
+// State of a chain that stopped in front of a binade with a rounding tie (lanes_chain_kernel, round 6: the wavefront walks that
+// binade TOGETHER -- 64 list entries per trip, a parity-function scan -- and the chain goes on behind it): the float32 sum,
+// the next element and the number of common neighbours before it.
+struct ChainResume {
+    float c;
+    uint32_t k, i0;
+    uint32_t started;   // 0: a fresh chain (the head runs); 1: resume at (c, k, i0)
+};
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // host-side instrumentation of lane_chain (self test): elements added one by one after the head, binade iterations
@@ -766,11 +775,14 @@ template <bool WIDE = false>
 // tie_budget_init: runs a binade with a rounding tie may be walked by (0: return LANE_TIE at the first such binade --
 // lanes_chain_kernel's first pass, which leaves those chains to a second, densely packed launch).
 PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in, float x_out, float x_prev,
-                          const ListView &cl, uint32_t &reads, float *c_end = nullptr, uint32_t tie_budget_init = LANE_TIE_BUDGET) {
+                          const ListView &cl, uint32_t &reads, float *c_end = nullptr, uint32_t tie_budget_init = LANE_TIE_BUDGET,
+                          ChainResume *rs = nullptr) {
     using B = Binade<float>;
     float c = 0.0f;
     uint32_t k = 0;    // next element to add
     uint32_t i0 = 0;   // number of common neighbours before k
+    const bool resumed = rs != nullptr && rs->started != 0u;
+    if (resumed) { c = rs->c; k = rs->k; i0 = rs->i0; }
     // cursor over the list: position of common neighbour i0, served from a cached 4-entry window so that walking
     // the list costs one (dependent) load per four entries instead of one per entry
     ListWin cw = {{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
@@ -806,8 +818,10 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
     } while (0)
     bool hit = false;
     // the sum changes binade every few elements at first (and the values tie there half of the time)
-    PW_LANE_SEQ(LANE_HEAD, 0);
-    if (hit) return k;
+    if (!resumed) {
+        PW_LANE_SEQ(LANE_HEAD, 0);
+        if (hit) return k;
+    }
     uint32_t tie_budget = tie_budget_init;
 #if defined(PW_LANES_WATCHDOG) && defined(__HIP_DEVICE_COMPILE__)
     uint32_t wd_chain = 0;
@@ -834,6 +848,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         const uint64_t Tt = B::threshold(r, eb);   // <= TOP
         const Inc<float> qi = B::quantize(x_in, eb), qo = B::quantize(x_out, eb);
         if ((qi.a0 != qi.a1 && next_in < lim) || qo.a0 != qo.a1) {
+            if (rs) { rs->c = c; rs->k = k; rs->i0 = i0; rs->started = 1u; return LANE_TIE_PENDING; }   // (the wavefront walks this binade)
             // A value sits exactly half way between two sums of this binade: its increment depends on the parity of
             // the running sum (round half to even), so the counts alone no longer determine the sum.  Walk the
             // binade RUN BY RUN instead: a run of m "out" neighbours adds (C odd ? a1 : a0) once and -- the sum being
