@@ -738,7 +738,10 @@ struct ChainResume {
     float c;
     uint32_t k, i0;
     uint32_t started;   // 0: a fresh chain (the head runs); 1: resume at (c, k, i0)
+    uint32_t yield;     // 1: return LANE_YIELD behind every iteration of the binade loop (the wavefront's chains advance in step,
+                        //    so that a chain that went on behind its tying binade does not run the rest of its binades alone)
 };
+constexpr uint32_t LANE_YIELD = 0xfffffff7u;
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // host-side instrumentation of lane_chain (self test): elements added one by one after the head, binade iterations
@@ -837,9 +840,11 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
             return LANE_TIE;
         }
 #endif
+#define PW_LANE_YIELD() do { if (rs != nullptr && rs->yield) { rs->c = c; rs->k = k; rs->i0 = i0; rs->started = 1u; return LANE_YIELD; } } while (0)
         if (k == pp) {   // prev is a single element: always a real addition (no closed form, no tie question)
             PW_LANE_SEQ(1u, 0);
             if (hit) return k;
+            PW_LANE_YIELD();
             continue;
         }
         const uint32_t lim = (pp != 0xffffffffu && pp > k && pp < kend) ? pp : kend;   // closed form over [k, lim)
@@ -942,6 +947,7 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
                 if (lim == kend) { if (c_end) *c_end = c; return LANE_CHAIN_END; }
                 k = lim;
                 i0 = lo;
+                PW_LANE_YIELD();
                 PW_LANE_CURSOR();
                 continue;
             }
@@ -957,10 +963,12 @@ PW_HD uint32_t lane_chain(uint32_t kend, uint32_t n_in, uint32_t pp, double r, f
         if ((double)c >= r) return kf;
         k = kf + 1u;
         i0 = lo + (kf == p_f ? 1u : 0u);
+        if (k < kend) PW_LANE_YIELD();
         PW_LANE_CURSOR();
     }
     if (c_end) *c_end = c;
     return LANE_CHAIN_END;
+#undef PW_LANE_YIELD
 #undef PW_LANE_SEQ
 #undef PW_LANE_CURSOR
 }

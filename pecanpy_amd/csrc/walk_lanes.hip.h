@@ -1298,6 +1298,9 @@ __device__ __forceinline__ TieOut coop_tie_binade(const void *lp, uint32_t wide,
 #ifndef PW_CHAIN_COOP
 #define PW_CHAIN_COOP 1
 #endif
+#ifndef PW_CHAIN_STEP
+#define PW_CHAIN_STEP 1   // the wavefront's chains advance one binade at a time, in step (tying binades are walked between the steps)
+#endif
 __global__ void __launch_bounds__(256, PW_CHAIN_WAVES)
 lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
                    unsigned long long *stats) {
@@ -1336,7 +1339,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     ListView cl = edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w);
     const void *const list_p = cl.p;                       // (global memory: what the cooperative walk of a tying binade reads)
     ChainResume rs;
-    rs.c = 0.0f; rs.k = 0u; rs.i0 = 0u; rs.started = 0u;
+    rs.c = 0.0f; rs.k = 0u; rs.i0 = 0u; rs.started = 0u; rs.yield = PW_CHAIN_STEP ? 1u : 0u;
     uint32_t res = 0u;
     if (active) {
         uint32_t reads = 0;
@@ -1357,7 +1360,7 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     // goes on with its chain (a chain meets such binades in two consecutive ones at most)
     for (;;) {
         uint64_t pend = ballot(active && res == LANE_TIE_PENDING);
-        if (!pend) break;
+        if (!pend && !ballot(active && res == LANE_YIELD)) break;
         while (pend) {
             const int l = __builtin_ctzll(pend);
             pend &= pend - 1ull;
@@ -1379,16 +1382,17 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
                 if (!o.leave) {                    // [k, lim) stays inside the binade and below the target
                     const float cn = B::make(o.Cc, eb);
                     if (lim_l == kend_l) res = LANE_CHAIN_END;
-                    else { rs.c = cn; rs.k = lim_l; rs.i0 = o.i0; }          // (k == lim == pp: prev is added next)
+                    else { rs.c = cn; rs.k = lim_l; rs.i0 = o.i0; res = LANE_YIELD; }   // (k == lim == pp: prev is added next)
                 } else if (o.Cc < (uint32_t)B::TOP) res = o.kf;             // target reached inside the binade
                 else {
                     const float cn = B::make(o.Cprev, eb) + (o.at_in ? xi_l : xo_l);
                     if ((double)cn >= r_l) res = o.kf;
-                    else { rs.c = cn; rs.k = o.kf + 1u; rs.i0 = o.i0; }
+                    else if (o.kf + 1u >= kend_l) res = LANE_CHAIN_END;     // (no element left: the chain ends below the target)
+                    else { rs.c = cn; rs.k = o.kf + 1u; rs.i0 = o.i0; res = LANE_YIELD; }
                 }
             }
         }
-        if (active && res == LANE_TIE_PENDING) {   // (still pending: the chain goes on behind its binade)
+        if (active && res == LANE_YIELD) {   // (the chain goes on: behind its tying binade, or -- PW_CHAIN_STEP -- one iteration at a time)
             uint32_t reads = 0;
             res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_out, x_prev, cl, reads, nullptr, LANE_TIE_BUDGET, &rs);
             reads_l += reads;
