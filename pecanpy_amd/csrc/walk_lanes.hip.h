@@ -301,6 +301,167 @@ __device__ unsigned long long g_lprof[16];
             else if (!(draw_prefetched_)) r = a.rng[A.soff + (A.j - 1)];   /* the next step's draw, asked for now */ \
     } while (0)
 
+// ---- a binade with a ROUNDING TIE, walked by the whole wavefront (round 6) ------------------------------------------------------
+// In such a binade a value sits exactly half way between two sums (round half to even depends on the parity of the running sum),
+// so the class counts no longer determine the sum and lane_chain walks the binade RUN BY RUN: one iteration per common neighbour,
+// ~10^4 on the largest hub rows, ONE lane busy -- 7.7 of the chain kernels' 17.6 ms per RMAT-22 pass, and the tail of every chain
+// launch.  Here the 64 lanes take 64 consecutive list entries per trip.  Entry j at position P_j stands for the run of m_j "out"
+// elements before it and the common neighbour itself; what that adds to an even / an odd sum is a PARITY FUNCTION (a0, a1) in
+// closed form (a run adds qo.a[parity] once and qo.a0 for each further element -- after a tying addition the sum is even, without
+// a tie a0 == a1 --, the common neighbour qi.a[parity behind the run]); parity functions compose associatively (seqscan.h:
+// Binade::compose), so one wave scan (wave_scan_inc: DPP) yields the sum behind every entry of the trip, a ballot the first entry
+// at which it reaches the target or the binade's top, and the element inside that entry's run is the division lane_chain does.
+// Same integers as the sequential loop, entry by entry (A/B: the walk matrices of the RMAT-22 passes, tests/).
+// All arguments are wave uniform; lp / wide: the list in global memory (uint16 / uint32 positions).
+struct TieOut {
+    uint32_t leave;     // the sum reached Tt (target or top of the binade) at element kf
+    uint32_t at_in;     // ... kf is a common neighbour (else an "out" element)
+    uint32_t kf;
+    uint32_t k, i0;     // next element and number of common neighbours before it (leave: i0 behind kf's entry when at_in)
+    uint32_t Cc, Cprev; // sum in ulps of the binade behind k - 1 (leave: behind kf, and before kf)
+};
+__device__ __forceinline__ TieOut coop_tie_binade(const void *lp, uint32_t wide, uint32_t n_in, uint32_t k, uint32_t lim, uint32_t i0,
+                                                  uint32_t C, uint32_t Tt, Inc<float> qi, Inc<float> qo) {
+    using B = Binade<float>;
+    const int lane = lane_id();
+    TieOut o;
+    o.leave = 0u; o.at_in = 0u; o.kf = 0u; o.k = k; o.i0 = i0; o.Cc = C; o.Cprev = C;
+    // the run of m "out" elements from sum Cx: does it reach Tt, and where
+    auto out_run = [&](uint32_t Cx, uint32_t k0, uint32_t m) -> bool {
+        const uint64_t first = (Cx & 1u) ? qo.a1 : qo.a0, each = qo.a0;
+        const uint64_t Cend = (uint64_t)Cx + first + (uint64_t)(m - 1u) * each;
+        if (Cend < (uint64_t)Tt) { o.Cc = (uint32_t)Cend; return false; }
+        uint64_t t = 1;
+        if ((uint64_t)Cx + first < (uint64_t)Tt) t = 2ull + div_floor_small((uint64_t)Tt - ((uint64_t)Cx + first) - 1ull, each);
+        const uint64_t Cf = (uint64_t)Cx + first + (t - 1ull) * each;
+        o.kf = k0 + (uint32_t)t - 1u;
+        o.Cprev = t == 1 ? Cx : (uint32_t)(Cf - each);
+        o.Cc = (uint32_t)(Cf > 0xffffffffull ? 0xffffffffull : Cf);
+        o.leave = 1u; o.at_in = 0u;
+        return true;
+    };
+    for (;;) {
+        const uint32_t j = o.i0 + (uint32_t)lane;
+        uint32_t P = 0xffffffffu;
+        if (j < n_in) P = wide ? ((const uint32_t *)lp)[j] : (uint32_t)((const uint16_t *)lp)[j];
+        const bool in_range = P < lim;                                   // (ascending: the in-range entries are a prefix of the lanes)
+        uint32_t prevP = (uint32_t)__shfl_up((int)P, 1u, WAVE);
+        if (lane == 0) prevP = o.k - 1u;                                 // (k >= 1: the head was added one by one)
+        const uint32_t m = in_range ? P - prevP - 1u : 0u;
+        Inc<float> F;
+        F.a0 = 0u; F.a1 = 0u;
+        if (in_range) {
+            uint64_t v0 = 0, v1 = 0;
+            if (m) {
+                const uint64_t rest = (uint64_t)(m - 1u) * (uint64_t)qo.a0;
+                v0 = (uint64_t)qo.a0 + rest;
+                v1 = (uint64_t)qo.a1 + rest;
+            }
+            const uint64_t t0 = v0 + (uint64_t)((v0 & 1ull) ? qi.a1 : qi.a0);
+            const uint64_t t1 = v1 + (uint64_t)(((v1 + 1ull) & 1ull) ? qi.a1 : qi.a0);
+            F.a0 = t0 > (uint64_t)B::SAT ? B::SAT : (uint32_t)t0;
+            F.a1 = t1 > (uint64_t)B::SAT ? B::SAT : (uint32_t)t1;
+        }
+        const Inc<float> G = wave_scan_inc<float>(F);
+        uint64_t ci = (uint64_t)o.Cc + (uint64_t)((o.Cc & 1u) ? G.a1 : G.a0);
+        const uint32_t Cincl = ci > (uint64_t)B::SAT ? B::SAT : (uint32_t)ci;   // sum behind this entry's common neighbour
+        const uint64_t rng = ballot(in_range);
+        const uint32_t n_valid = (uint32_t)__popcll(rng);
+        const uint64_t hit = ballot(in_range && Cincl >= Tt);
+        if (hit) {
+            const int l = __builtin_ctzll(hit);
+            const uint32_t Cx = l ? readlane_u32(Cincl, l - 1) : o.Cc;
+            const uint32_t Pl = readlane_u32(P, l), ml = readlane_u32(m, l);
+            o.i0 += (uint32_t)l;
+            if (ml && out_run(Cx, Pl - ml, ml)) { o.k = o.kf + 1u; return o; }
+            const uint32_t Cb = ml ? o.Cc : Cx;                          // (out_run left the sum behind the run in o.Cc)
+            const uint32_t inc = (Cb & 1u) ? qi.a1 : qi.a0;
+            o.kf = Pl; o.Cprev = Cb; o.Cc = Cb + inc; o.leave = 1u; o.at_in = 1u;
+            o.i0 += 1u; o.k = Pl + 1u;
+            return o;
+        }
+        if (n_valid) {
+            o.Cc = readlane_u32(Cincl, (int)n_valid - 1);
+            o.k = readlane_u32(P, (int)n_valid - 1) + 1u;
+            o.i0 += n_valid;
+        }
+        if (n_valid < (uint32_t)WAVE) break;                             // the list is exhausted, or its next entry lies beyond lim
+    }
+    if (o.k < lim) {                                                     // the "out" elements up to lim
+        if (out_run(o.Cc, o.k, lim - o.k)) { o.k = o.kf + 1u; return o; }
+        o.k = lim;
+    }
+    return o;
+}
+
+#ifndef PW_CHAIN_COOP
+#define PW_CHAIN_COOP 1
+#endif
+#ifndef PW_CHAIN_STEP
+#define PW_CHAIN_STEP 1   // the wavefront's chains advance one binade at a time, in step (tying binades are walked between the steps)
+#endif
+// The float32 chains of the lanes with `active` set, by the wavefront: every chain advances one iteration of lane_chain's binade
+// loop at a time (PW_CHAIN_STEP), a lane that stops in front of a binade with a rounding tie has it walked by all 64 lanes
+// (coop_tie_binade) and goes on.  CONVERGED code: every lane of the wavefront calls it.  list_p: the list in global memory
+// (cl.p before any staging).  Returns what lane_chain returns (position, LANE_CHAIN_END, LANE_TIE).
+__device__ __forceinline__ uint32_t lane_chain_wave(bool active, uint32_t kend, uint32_t n_in, uint32_t pp, double r, float x_in,
+                                                    float x_out, float x_prev, const ListView &cl, const void *list_p, uint32_t &reads_total) {
+    using B = Binade<float>;
+    ChainResume rs;
+    rs.c = 0.0f; rs.k = 0u; rs.i0 = 0u; rs.started = 0u; rs.yield = PW_CHAIN_STEP ? 1u : 0u;
+    uint32_t res = 0u;
+    reads_total = 0;
+    if (active) {
+        uint32_t reads = 0;
+        res = lane_chain(kend, n_in, pp, r, x_in, x_out, x_prev, cl, reads, nullptr, LANE_TIE_BUDGET, PW_CHAIN_COOP ? &rs : nullptr);
+        reads_total += reads;
+    }
+#if PW_CHAIN_COOP
+    for (;;) {
+        uint64_t pend = ballot(active && res == LANE_TIE_PENDING);
+        if (!pend && !ballot(active && res == LANE_YIELD)) break;
+        while (pend) {
+            const int l = __builtin_ctzll(pend);
+            pend &= pend - 1ull;
+            // the owner's chain, wave uniform
+            const float c_l = readlane_f32(rs.c, l), xi_l = readlane_f32(x_in, l), xo_l = readlane_f32(x_out, l);
+            const uint32_t k_l = readlane_u32(rs.k, l), i0_l = readlane_u32(rs.i0, l);
+            const uint32_t kend_l = readlane_u32(kend, l), nin_l = readlane_u32(n_in, l), pp_l = readlane_u32(pp, l);
+            const double r_l = readlane_f64(r, l);
+            const void *lp_l = (const void *)readlane_u64((uint64_t)(uintptr_t)list_p, l);
+            const uint32_t wide_l = readlane_u32(cl.wide, l);
+            const uint32_t lim_l = (pp_l != 0xffffffffu && pp_l > k_l && pp_l < kend_l) ? pp_l : kend_l;
+            const int eb = B::eb_of(c_l);
+            const uint32_t C = B::sig_of(c_l);
+            const uint32_t Tt = (uint32_t)B::threshold(r_l, eb);
+            const Inc<float> qi = B::quantize(xi_l, eb), qo = B::quantize(xo_l, eb);
+            const TieOut o = coop_tie_binade(lp_l, wide_l, nin_l, k_l, lim_l, i0_l, C, Tt, qi, qo);
+            if (lane_id() == l) {                  // what lane_chain does behind the binade's loop
+                reads_total += o.i0 - i0_l;
+                if (!o.leave) {                    // [k, lim) stays inside the binade and below the target
+                    const float cn = B::make(o.Cc, eb);
+                    if (lim_l == kend_l) res = LANE_CHAIN_END;
+                    else { rs.c = cn; rs.k = lim_l; rs.i0 = o.i0; res = LANE_YIELD; }   // (k == lim == pp: prev is added next)
+                } else if (o.Cc < (uint32_t)B::TOP) res = o.kf;             // target reached inside the binade
+                else {
+                    const float cn = B::make(o.Cprev, eb) + (o.at_in ? xi_l : xo_l);
+                    if ((double)cn >= r_l) res = o.kf;
+                    else if (o.kf + 1u >= kend_l) res = LANE_CHAIN_END;     // (no element left: the chain ends below the target)
+                    else { rs.c = cn; rs.k = o.kf + 1u; rs.i0 = o.i0; res = LANE_YIELD; }
+                }
+            }
+        }
+        if (active && res == LANE_YIELD) {   // (the chain goes on: behind its tying binade, or -- PW_CHAIN_STEP -- one iteration at a time)
+            uint32_t reads = 0;
+            res = lane_chain(kend, n_in, pp, r, x_in, x_out, x_prev, cl, reads, nullptr, LANE_TIE_BUDGET, &rs);
+            reads_total += reads;
+        }
+    }
+#endif
+    return res;
+}
+
+
 struct __attribute__((packed, aligned(4))) OutCells {   // four staged output cells: one 16-byte store, 4-byte aligned
     uint32_t v[4];
 };
@@ -600,21 +761,29 @@ walk_lanes_kernel(LanesArgs a) {
                                     (uint32_t)__popcll(m_def | m_set | m_chn) >= (uint32_t)(POOL_N - POOL_N / 8))) {
                 force_chain = false;
                 n_wave += (unsigned long long)__popcll(m_chn);
-                if ((m_chn >> lane) & 1ull) {
-                    const uint4 p0 = pool[0][lane], p1 = pool[1][lane];
-                    const uint32_t kmax_s = *(const uint32_t *)&pool[2][lane];
-                    const uint2 p4 = *(const uint2 *)&pool[4][lane];
+                {   // (round 6: the chains advance in step, tying binades are walked by the whole wavefront: lane_chain_wave)
+                    const bool mine = (m_chn >> lane) & 1ull;
+                    uint4 p0 = make_uint4(0u, 0u, 0u, 1u), p1 = make_uint4(0u, 0xffffffffu, 0u, 0u);
+                    uint32_t kmax_s = 0u;
+                    uint2 p4 = make_uint2(0u, 0u);
+                    if (mine) {
+                        p0 = pool[0][lane]; p1 = pool[1][lane];
+                        kmax_s = *(const uint32_t *)&pool[2][lane];
+                        p4 = *(const uint2 *)&pool[4][lane];
+                    }
                     const float wo_s = p0.y >= 2u ? w_out : 1.0f;
                     const double r_s = __longlong_as_double((long long)(((unsigned long long)p4.y << 32) | p4.x));
                     const float x_in = 1.0f / (float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev);
                     uint32_t reads = 0;
-                    const uint32_t res = lane_chain(kmax_s, p1.x, p1.y, r_s, x_in, x_in * wo_s, x_in * w_prev,
-                                                    edge_list(a.lines, a.clist, p1.z, p0.w, p1.x, p1.w), reads);
-                    n_probes += reads;
-                    uint32_t ch = res;
-                    if (res == LANE_CHAIN_END) ch = p0.w;              // never reached: the mirrored overflow read (choice == degree)
-                    if (res == LANE_TIE) ch = LANE_NEEDS_WAVE;         // tie budget: the wave kernel takes the walk over at this step
-                    *(uint32_t *)&pool[2][lane] = ch;
+                    const ListView cl_s = edge_list(a.lines, a.clist, p1.z, p0.w, p1.x, p1.w);
+                    const uint32_t res = lane_chain_wave(mine, kmax_s, p1.x, p1.y, r_s, x_in, x_in * wo_s, x_in * w_prev, cl_s, cl_s.p, reads);
+                    if (mine) {
+                        n_probes += reads;
+                        uint32_t ch = res;
+                        if (res == LANE_CHAIN_END) ch = p0.w;              // never reached: the mirrored overflow read (choice == degree)
+                        if (res == LANE_TIE) ch = LANE_NEEDS_WAVE;         // tie budget: the wave kernel takes the walk over at this step
+                        *(uint32_t *)&pool[2][lane] = ch;
+                    }
                 }
                 m_set |= m_chn;
                 m_chn = 0;
@@ -1202,105 +1371,6 @@ walk_lanes_kernel(LanesArgs a) {
 #define PW_CHAIN_SORT 1    // the 256 records of a workgroup are dealt to its lanes in the order of their prefix bound kmax (the chain's
                            // length): a wavefront lasts as long as its longest chain, so chains of similar length share one
 #endif
-// ---- a binade with a ROUNDING TIE, walked by the whole wavefront (round 6) ------------------------------------------------------
-// In such a binade a value sits exactly half way between two sums (round half to even depends on the parity of the running sum),
-// so the class counts no longer determine the sum and lane_chain walks the binade RUN BY RUN: one iteration per common neighbour,
-// ~10^4 on the largest hub rows, ONE lane busy -- 7.7 of the chain kernels' 17.6 ms per RMAT-22 pass, and the tail of every chain
-// launch.  Here the 64 lanes take 64 consecutive list entries per trip.  Entry j at position P_j stands for the run of m_j "out"
-// elements before it and the common neighbour itself; what that adds to an even / an odd sum is a PARITY FUNCTION (a0, a1) in
-// closed form (a run adds qo.a[parity] once and qo.a0 for each further element -- after a tying addition the sum is even, without
-// a tie a0 == a1 --, the common neighbour qi.a[parity behind the run]); parity functions compose associatively (seqscan.h:
-// Binade::compose), so one wave scan (wave_scan_inc: DPP) yields the sum behind every entry of the trip, a ballot the first entry
-// at which it reaches the target or the binade's top, and the element inside that entry's run is the division lane_chain does.
-// Same integers as the sequential loop, entry by entry (A/B: the walk matrices of the RMAT-22 passes, tests/).
-// All arguments are wave uniform; lp / wide: the list in global memory (uint16 / uint32 positions).
-struct TieOut {
-    uint32_t leave;     // the sum reached Tt (target or top of the binade) at element kf
-    uint32_t at_in;     // ... kf is a common neighbour (else an "out" element)
-    uint32_t kf;
-    uint32_t k, i0;     // next element and number of common neighbours before it (leave: i0 behind kf's entry when at_in)
-    uint32_t Cc, Cprev; // sum in ulps of the binade behind k - 1 (leave: behind kf, and before kf)
-};
-__device__ __forceinline__ TieOut coop_tie_binade(const void *lp, uint32_t wide, uint32_t n_in, uint32_t k, uint32_t lim, uint32_t i0,
-                                                  uint32_t C, uint32_t Tt, Inc<float> qi, Inc<float> qo) {
-    using B = Binade<float>;
-    const int lane = lane_id();
-    TieOut o;
-    o.leave = 0u; o.at_in = 0u; o.kf = 0u; o.k = k; o.i0 = i0; o.Cc = C; o.Cprev = C;
-    // the run of m "out" elements from sum Cx: does it reach Tt, and where
-    auto out_run = [&](uint32_t Cx, uint32_t k0, uint32_t m) -> bool {
-        const uint64_t first = (Cx & 1u) ? qo.a1 : qo.a0, each = qo.a0;
-        const uint64_t Cend = (uint64_t)Cx + first + (uint64_t)(m - 1u) * each;
-        if (Cend < (uint64_t)Tt) { o.Cc = (uint32_t)Cend; return false; }
-        uint64_t t = 1;
-        if ((uint64_t)Cx + first < (uint64_t)Tt) t = 2ull + div_floor_small((uint64_t)Tt - ((uint64_t)Cx + first) - 1ull, each);
-        const uint64_t Cf = (uint64_t)Cx + first + (t - 1ull) * each;
-        o.kf = k0 + (uint32_t)t - 1u;
-        o.Cprev = t == 1 ? Cx : (uint32_t)(Cf - each);
-        o.Cc = (uint32_t)(Cf > 0xffffffffull ? 0xffffffffull : Cf);
-        o.leave = 1u; o.at_in = 0u;
-        return true;
-    };
-    for (;;) {
-        const uint32_t j = o.i0 + (uint32_t)lane;
-        uint32_t P = 0xffffffffu;
-        if (j < n_in) P = wide ? ((const uint32_t *)lp)[j] : (uint32_t)((const uint16_t *)lp)[j];
-        const bool in_range = P < lim;                                   // (ascending: the in-range entries are a prefix of the lanes)
-        uint32_t prevP = (uint32_t)__shfl_up((int)P, 1u, WAVE);
-        if (lane == 0) prevP = o.k - 1u;                                 // (k >= 1: the head was added one by one)
-        const uint32_t m = in_range ? P - prevP - 1u : 0u;
-        Inc<float> F;
-        F.a0 = 0u; F.a1 = 0u;
-        if (in_range) {
-            uint64_t v0 = 0, v1 = 0;
-            if (m) {
-                const uint64_t rest = (uint64_t)(m - 1u) * (uint64_t)qo.a0;
-                v0 = (uint64_t)qo.a0 + rest;
-                v1 = (uint64_t)qo.a1 + rest;
-            }
-            const uint64_t t0 = v0 + (uint64_t)((v0 & 1ull) ? qi.a1 : qi.a0);
-            const uint64_t t1 = v1 + (uint64_t)(((v1 + 1ull) & 1ull) ? qi.a1 : qi.a0);
-            F.a0 = t0 > (uint64_t)B::SAT ? B::SAT : (uint32_t)t0;
-            F.a1 = t1 > (uint64_t)B::SAT ? B::SAT : (uint32_t)t1;
-        }
-        const Inc<float> G = wave_scan_inc<float>(F);
-        uint64_t ci = (uint64_t)o.Cc + (uint64_t)((o.Cc & 1u) ? G.a1 : G.a0);
-        const uint32_t Cincl = ci > (uint64_t)B::SAT ? B::SAT : (uint32_t)ci;   // sum behind this entry's common neighbour
-        const uint64_t rng = ballot(in_range);
-        const uint32_t n_valid = (uint32_t)__popcll(rng);
-        const uint64_t hit = ballot(in_range && Cincl >= Tt);
-        if (hit) {
-            const int l = __builtin_ctzll(hit);
-            const uint32_t Cx = l ? readlane_u32(Cincl, l - 1) : o.Cc;
-            const uint32_t Pl = readlane_u32(P, l), ml = readlane_u32(m, l);
-            o.i0 += (uint32_t)l;
-            if (ml && out_run(Cx, Pl - ml, ml)) { o.k = o.kf + 1u; return o; }
-            const uint32_t Cb = ml ? o.Cc : Cx;                          // (out_run left the sum behind the run in o.Cc)
-            const uint32_t inc = (Cb & 1u) ? qi.a1 : qi.a0;
-            o.kf = Pl; o.Cprev = Cb; o.Cc = Cb + inc; o.leave = 1u; o.at_in = 1u;
-            o.i0 += 1u; o.k = Pl + 1u;
-            return o;
-        }
-        if (n_valid) {
-            o.Cc = readlane_u32(Cincl, (int)n_valid - 1);
-            o.k = readlane_u32(P, (int)n_valid - 1) + 1u;
-            o.i0 += n_valid;
-        }
-        if (n_valid < (uint32_t)WAVE) break;                             // the list is exhausted, or its next entry lies beyond lim
-    }
-    if (o.k < lim) {                                                     // the "out" elements up to lim
-        if (out_run(o.Cc, o.k, lim - o.k)) { o.k = o.kf + 1u; return o; }
-        o.k = lim;
-    }
-    return o;
-}
-
-#ifndef PW_CHAIN_COOP
-#define PW_CHAIN_COOP 1
-#endif
-#ifndef PW_CHAIN_STEP
-#define PW_CHAIN_STEP 1   // the wavefront's chains advance one binade at a time, in step (tying binades are walked between the steps)
-#endif
 __global__ void __launch_bounds__(256, PW_CHAIN_WAVES)
 lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, const uint8_t *__restrict__ clist, float w_prev,
                    unsigned long long *stats) {
@@ -1338,67 +1408,18 @@ lanes_chain_kernel(SuspRec *q, uint64_t n, const ELine *__restrict__ lines, cons
     const float x_in = 1.0f / tot, x_out = x_in * wo, x_prev = x_in * w_prev;
     ListView cl = edge_list(lines, clist, q1.z, q0.w, q1.x, q1.w);
     const void *const list_p = cl.p;                       // (global memory: what the cooperative walk of a tying binade reads)
-    ChainResume rs;
-    rs.c = 0.0f; rs.k = 0u; rs.i0 = 0u; rs.started = 0u; rs.yield = PW_CHAIN_STEP ? 1u : 0u;
-    uint32_t res = 0u;
-    if (active) {
-        uint32_t reads = 0;
-        if (PW_CHAIN_TAILS && q1.x != 0u) {   // bytes 16..63 of the entry's line -> LDS (the inline list or the pivots)
-            const uint4 *rp = (const uint4 *)(lines + q1.z);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 1), (lds_ptr_t)&dtail[0][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 2), (lds_ptr_t)&dtail[1][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 3), (lds_ptr_t)&dtail[2][0], 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            cl.tail = (uint32_t)(uintptr_t)(lds_ptr_t)&dtail[0][threadIdx.x & (WAVE - 1)];
-            cl.inl = (q0.w <= 65536u && q1.x <= EL_INLINE) ? 1u : 0u;
-        }
-        res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_out, x_prev, cl, reads, nullptr, LANE_TIE_BUDGET, PW_CHAIN_COOP ? &rs : nullptr);
-        reads_l += reads;
+    if (active && PW_CHAIN_TAILS && q1.x != 0u) {   // bytes 16..63 of the entry's line -> LDS (the inline list or the pivots)
+        const uint4 *rp = (const uint4 *)(lines + q1.z);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 1), (lds_ptr_t)&dtail[0][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 2), (lds_ptr_t)&dtail[1][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(rp + 3), (lds_ptr_t)&dtail[2][0], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cl.tail = (uint32_t)(uintptr_t)(lds_ptr_t)&dtail[0][threadIdx.x & (WAVE - 1)];
+        cl.inl = (q0.w <= 65536u && q1.x <= EL_INLINE) ? 1u : 0u;
     }
-#if PW_CHAIN_COOP
-    // the binades with a rounding tie: every lane that stopped in front of one has its binade walked by the whole wavefront, then
-    // goes on with its chain (a chain meets such binades in two consecutive ones at most)
-    for (;;) {
-        uint64_t pend = ballot(active && res == LANE_TIE_PENDING);
-        if (!pend && !ballot(active && res == LANE_YIELD)) break;
-        while (pend) {
-            const int l = __builtin_ctzll(pend);
-            pend &= pend - 1ull;
-            // the owner's chain, wave uniform
-            const float c_l = readlane_f32(rs.c, l), xi_l = readlane_f32(x_in, l), xo_l = readlane_f32(x_out, l);
-            const uint32_t k_l = readlane_u32(rs.k, l), i0_l = readlane_u32(rs.i0, l);
-            const uint32_t kend_l = readlane_u32(q2.x, l), nin_l = readlane_u32(q1.x, l), pp_l = readlane_u32(q1.y, l);
-            const double r_l = readlane_f64(r, l);
-            const void *lp_l = (const void *)readlane_u64((uint64_t)(uintptr_t)list_p, l);
-            const uint32_t wide_l = readlane_u32(cl.wide, l);
-            const uint32_t lim_l = (pp_l != 0xffffffffu && pp_l > k_l && pp_l < kend_l) ? pp_l : kend_l;
-            const int eb = B::eb_of(c_l);
-            const uint32_t C = B::sig_of(c_l);
-            const uint32_t Tt = (uint32_t)B::threshold(r_l, eb);
-            const Inc<float> qi = B::quantize(xi_l, eb), qo = B::quantize(xo_l, eb);
-            const TieOut o = coop_tie_binade(lp_l, wide_l, nin_l, k_l, lim_l, i0_l, C, Tt, qi, qo);
-            reads_l += (lane_id() == l) ? (unsigned long long)(o.i0 - i0_l) : 0ull;
-            if (lane_id() == l) {                  // what lane_chain does behind the binade's loop
-                if (!o.leave) {                    // [k, lim) stays inside the binade and below the target
-                    const float cn = B::make(o.Cc, eb);
-                    if (lim_l == kend_l) res = LANE_CHAIN_END;
-                    else { rs.c = cn; rs.k = lim_l; rs.i0 = o.i0; res = LANE_YIELD; }   // (k == lim == pp: prev is added next)
-                } else if (o.Cc < (uint32_t)B::TOP) res = o.kf;             // target reached inside the binade
-                else {
-                    const float cn = B::make(o.Cprev, eb) + (o.at_in ? xi_l : xo_l);
-                    if ((double)cn >= r_l) res = o.kf;
-                    else if (o.kf + 1u >= kend_l) res = LANE_CHAIN_END;     // (no element left: the chain ends below the target)
-                    else { rs.c = cn; rs.k = o.kf + 1u; rs.i0 = o.i0; res = LANE_YIELD; }
-                }
-            }
-        }
-        if (active && res == LANE_YIELD) {   // (the chain goes on: behind its tying binade, or -- PW_CHAIN_STEP -- one iteration at a time)
-            uint32_t reads = 0;
-            res = lane_chain(q2.x, q1.x, q1.y, r, x_in, x_out, x_prev, cl, reads, nullptr, LANE_TIE_BUDGET, &rs);
-            reads_l += reads;
-        }
-    }
-#endif
+    uint32_t reads_c = 0;
+    const uint32_t res = lane_chain_wave(active, q2.x, q1.x, q1.y, r, x_in, x_out, x_prev, cl, list_p, reads_c);
+    reads_l += reads_c;
     if (active) {
         uint32_t choice = res;
         if (res == LANE_CHAIN_END) choice = q0.w;          // never reached: the mirrored overflow read (choice == degree)
