@@ -17,6 +17,7 @@
 // walks the jobs the fast kernel hands over).  HBM per step: N/8 bytes (fast) .. 3 N/8 (complete, wide rows) instead of
 // ~10 N bytes.
 #pragma once
+#include <type_traits>
 #include "walk_sparse.hip.h"
 
 namespace pw {
@@ -533,9 +534,16 @@ walk_dense_bits_kernel(DenseArgs a) {
 // writes its own slots only: no barrier) and is REPLACED word by word by the row of cur inside the count pass, so no row is
 // live in registers across the decision; the four words per lane of the target segment are then read back -- cur's from LDS,
 // prev's from memory again (2 KB, read one step ago: cache hits).  Three wavefronts per SIMD instead of two.
-template <int WPL, int FULL, bool LDSK = false>
+// BOUNDED (round 6): 1/p or 1/q NOT a power of two.  The class counts are the same; the masses are float64 values
+// count_in + count_out * fl(1/q) + [prev] * fl(1/p) (a handful of roundings each, accumulated level by level of the search) and the
+// decision is the float64-BOUNDED one of walk_dense_w.hip.h: with T = fl(r * TOT~) and E = (2 d + 64) u, the first column whose
+// mass reaches T (1 - E) is np.searchsorted's answer when its mass also reaches T (1 + E) (the reference's tot carries at most
+// d - 1 factors (1 +- u), its chain k + 1, the masses here fewer than 24); otherwise -- ~2 d^2 u of the steps -- the walk goes to
+// walk_dense_bits_kernel through the redo list like any undecided step.
+template <int WPL, int FULL, bool LDSK = false, bool BOUNDED = false>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, LDSK ? 3 : 1)
 walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *redo_count, uint32_t redo_every) {
+    using M = typename std::conditional<BOUNDED, double, uint64_t>::type;   // a mass: float64 value / integer units of the smallest weight
     constexpr int NSEG = (WPL + 3) / 4;   // a segment = DQW 64-bit words = 4 words per lane
     static_assert(DQW / WAVE == 4, "segment = four words per lane");
     const int lane = lane_id();
@@ -618,22 +626,30 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
             const double td = (double)n_in + (double)n_out * w_out + (double)n_pv * w_prevp;
             const double S = td / u, wi = 1.0 / u, wo = w_out / u, wp = w_prevp / u;   // exact: powers of two
             const double wmax = fmax(wi, fmax(wo, wp)) + 2.0;
-            bool ok = (n_out == 0 || is_pow2_fp<double>(w_out)) && (n_pv == 0 || is_pow2_fp<double>(w_prevp)) &&
-                      n_in + n_out + n_pv == d && S <= 1099511627776.0 && wmax <= 1048576.0 && r > 0.0;
+            bool ok = BOUNDED ? (n_in + n_out + n_pv == d && r > 0.0 && td > 0.0 && td < 0x1p1000)
+                              : ((n_out == 0 || is_pow2_fp<double>(w_out)) && (n_pv == 0 || is_pow2_fp<double>(w_prevp)) &&
+                                 n_in + n_out + n_pv == d && S <= 1099511627776.0 && wmax <= 1048576.0 && r > 0.0);
             uint32_t nxt = NOT_FOUND;
-            uint64_t lo_th = 0, hi_th = 0, Wi = 0, Wo = 0, Wp = 0, e0 = 0;
+            M lo_th = (M)0, hi_th = (M)0, Wi = (M)0, Wo = (M)0, Wp = (M)0, e0 = (M)0;
             uint32_t sx = NOT_FOUND;
             const uint32_t pw_word = prev_col != NOT_FOUND ? (prev >> 6) : NOT_FOUND;   // word of prev's own class
             if (ok) {
-                const ExactThresholds64 th = exact_thresholds_f64(r * S, (double)d, wmax - 2.0);
-                lo_th = th.lo; hi_th = th.hi;
-                Wi = (uint64_t)wi; Wo = (uint64_t)wo; Wp = (uint64_t)wp;
+                if (BOUNDED) {
+                    const double E = ((2.0 * (double)d + 64.0) * 0x1p-53) * (1.0 + 0x1p-20) + 8.0 * 0x1p-53;
+                    const double T = r * td;
+                    lo_th = (M)(T - T * E); hi_th = (M)(T + T * E);
+                    Wi = (M)1.0; Wo = (M)w_out; Wp = (M)w_prevp;
+                } else {
+                    const ExactThresholds64 th = exact_thresholds_f64(r * S, (double)d, wmax - 2.0);
+                    lo_th = (M)th.lo; hi_th = (M)th.hi;
+                    Wi = (M)(uint64_t)wi; Wo = (M)(uint64_t)wo; Wp = (M)(uint64_t)wp;
+                }
                 const uint32_t pseg = pw_word != NOT_FOUND ? pw_word / DQW : NOT_FOUND;
 #pragma unroll
                 for (int sg = 0; sg < NSEG; sg++) {
                     if (sx == NOT_FOUND) {
-                        const uint64_t e1 = e0 + (uint64_t)(pks[sg] & 0xffffu) * Wi + (uint64_t)(pks[sg] >> 16) * Wo +
-                                            (pseg == (uint32_t)sg ? Wp : 0ull);
+                        const M e1 = e0 + (M)(pks[sg] & 0xffffu) * Wi + (M)(pks[sg] >> 16) * Wo +
+                                     (pseg == (uint32_t)sg ? Wp : (M)0);
                         if (e1 >= lo_th) sx = (uint32_t)sg; else e0 = e1;
                     }
                 }
@@ -684,15 +700,16 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                     uint32_t sm4[4];   // four independent wave sums
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) sm4[jj] = wave_sum_u32(pk[jj]);
-                    uint64_t in_s = 0, out_s = 0, eg = e0;
+                    uint64_t in_s = 0, out_s = 0;
+                    M eg = e0;
                     uint32_t pk_s = 0, g_sel = NOT_FOUND;
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
                         if (g_sel == NOT_FOUND) {   // (wave uniform)
                             const uint32_t sm = uni(sm4[jj]);
                             const uint32_t grp = 4u * sx + (uint32_t)jj;
-                            const uint64_t e_next = eg + (uint64_t)(sm & 0xffffu) * Wi + (uint64_t)(sm >> 16) * Wo +
-                                                    ((pw_word != NOT_FOUND && (pw_word >> 6) == grp) ? Wp : 0ull);
+                            const M e_next = eg + (M)(sm & 0xffffu) * Wi + (M)(sm >> 16) * Wo +
+                                             ((pw_word != NOT_FOUND && (pw_word >> 6) == grp) ? Wp : (M)0);
                             if (e_next >= lo_th) { g_sel = grp; in_s = in4[jj]; out_s = out4[jj]; pk_s = pk[jj]; }
                             else eg = e_next;
                         }
@@ -701,23 +718,25 @@ walk_dense_fast_kernel(DenseArgs a, uint32_t *redo_list, unsigned long long *red
                         const uint32_t incl = wave_incl_scan_u32(pk_s);   // inclusive scan over the lanes (the halves cannot carry: sums <= 4096)
                         const bool pv_here = pw_word != NOT_FOUND && (pw_word >> 6) == g_sel;
                         const uint32_t pv_lane = pw_word & 63u;
-                        const uint64_t G = eg + (uint64_t)(incl & 0xffffu) * Wi + (uint64_t)(incl >> 16) * Wo +
-                                           ((pv_here && pv_lane <= (uint32_t)lane) ? Wp : 0ull);
+                        const M G = eg + (M)(incl & 0xffffu) * Wi + (M)(incl >> 16) * Wo +
+                                    ((pv_here && pv_lane <= (uint32_t)lane) ? Wp : (M)0);
                         const uint64_t hm = ballot(G >= lo_th);
                         if (hm) {
                             const int l = __builtin_ctzll(hm);
-                            const uint32_t pk_l = readlane_u32(pk_s, l);
+                            // the mass before lane l's word from the EXCLUSIVE counts (no subtraction: a float64 difference of two
+                            // masses would carry the rounding of the larger one into the small ones at the start of a row)
+                            const uint32_t ex_l = readlane_u32(incl, l) - readlane_u32(pk_s, l);
                             const bool pv_word = pv_here && pv_lane == (uint32_t)l;
-                            const uint64_t e2 = readlane_u64(G, l) -
-                                                ((uint64_t)(pk_l & 0xffffu) * Wi + (uint64_t)(pk_l >> 16) * Wo + (pv_word ? Wp : 0ull));
+                            const M e2 = eg + (M)(ex_l & 0xffffu) * Wi + (M)(ex_l >> 16) * Wo + ((pv_here && pv_lane < (uint32_t)l) ? Wp : (M)0);
                             const uint64_t inw = readlane_u64(in_s, l), outw = readlane_u64(out_s, l);
                             const uint64_t mb = lane == WAVE - 1 ? ~0ull : ((2ull << lane) - 1ull);   // bits 0 .. lane
-                            const uint64_t Gb = e2 + (uint64_t)__popcll(inw & mb) * Wi + (uint64_t)__popcll(outw & mb) * Wo +
-                                                ((pv_word && (prev & 63u) <= (uint32_t)lane) ? Wp : 0ull);
+                            const M Gb = e2 + (M)(uint32_t)__popcll(inw & mb) * Wi + (M)(uint32_t)__popcll(outw & mb) * Wo +
+                                         ((pv_word && (prev & 63u) <= (uint32_t)lane) ? Wp : (M)0);
                             const uint64_t hb = ballot(Gb >= lo_th);
                             if (hb) {
                                 const int b = __builtin_ctzll(hb);
-                                if (readlane_u64(Gb, b) >= hi_th) nxt = (g_sel * WAVE + (uint32_t)l) * 64u + (uint32_t)b;   // decisive
+                                const M Gsel = BOUNDED ? (M)readlane_f64((double)Gb, b) : (M)readlane_u64((uint64_t)Gb, b);
+                                if (Gsel >= hi_th) nxt = (g_sel * WAVE + (uint32_t)l) * 64u + (uint32_t)b;   // decisive
                             }
                         }
                     }

@@ -428,7 +428,9 @@ def test_dense_fast_kernel_equals_the_complete_kernel(n, density, monkeypatch):
     starts = np.arange(n, dtype=np.uint32)[: 30000]
     np.random.RandomState(2).shuffle(starts)
     d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
-    for p, q in ((0.5, 2.0), (4.0, 0.25), (1.0, 1.0)):
+    # (round 6: 1/p or 1/q not a power of two -- the last three pairs -- run the same kernel with float64 masses and the
+    #  float64-bounded decision, BOUNDED; a partial sum inside the bound's interval, ~2 d^2 u of the steps, hands the walk over)
+    for p, q in ((0.3, 1.7), (3.0, 0.37), (1.0, 0.9), (0.5, 2.0), (4.0, 0.25), (1.0, 1.0)):
         fast = eng.simulate_device("DenseOTF", p, q, False, d_starts, 40, seed=3)
         st = dict(eng.last_stats)
         monkeypatch.setenv("PECANPY_AMD_DENSE_NO_FAST", "1")
