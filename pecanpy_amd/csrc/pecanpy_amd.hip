@@ -1590,9 +1590,11 @@ static int launch_dense_weighted(pw_graph *g, const pw::WalkArgs &wa, bool exten
 }
 
 static int launch_wave_walks(pw_graph *g, pw::WalkArgs &wa, bool extend, uint64_t *redo_total = nullptr) {
-    // unweighted dense graphs: the column-space kernel wins once rows span several thousand columns
-    // (ER-100k: 66 Msteps/s); small matrices are faster through their compressed rows (ER-8k: 199 vs 116)
-    if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000)) return launch_dense_bits(g, wa, redo_total);
+    // unweighted dense graphs: the column-space kernels at every size (round 6: with prev's row in LDS and DPP sums the packed rows
+    // beat the compressed ones from N = 1 000 on -- ER-1k 364 -> 682, ER-8k 207 -> 1 135, ER-12k 158 -> 1 145 M steps/s; rounds 2-5
+    // sent matrices of up to 12 000 rows through their compressed rows; PECANPY_AMD_DENSE_SMALL_ROWS=1: that rule)
+    const bool small_rows = env_on("PECANPY_AMD_DENSE_SMALL_ROWS");
+    if (g->kind == 1 && g->unit && g->d_deg && (g->bits_only || g->n_nodes > 12000 || !small_rows)) return launch_dense_bits(g, wa, redo_total);
     if (dense_weighted_eligible(g, wa, extend)) return launch_dense_weighted(g, wa, extend, redo_total);
     int occ = 0;
     walk_kernel_fn fn = pick_kernel(g, extend);

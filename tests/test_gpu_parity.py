@@ -422,17 +422,22 @@ def test_dense_bits_kernel_vs_oracle(n, density, p, q):
 
 
 @pytest.mark.parametrize("p,q", [(0.5, 2), (2, 0.25), (1, 1)])
-def test_dense_bits_exact_search_equals_float64_chain_kernel(p, q):
+def test_dense_bits_exact_search_equals_float64_chain_kernel(p, q, monkeypatch):
     """The column-space kernel decides the CDF search in exact arithmetic; the compressed-row DenseOTF
-    kernel runs the float64 chain.  Same graph, 1.2e6 transitions: identical walks."""
+    kernel runs the float64 chain.  Same graph, 1.2e6 transitions: identical walks.  (Round 6: a matrix handle takes the
+    column-space kernels at every size; PECANPY_AMD_DENSE_SMALL_ROWS=1 is rounds 2-5's rule -- compressed rows up to 12 000 rows.)"""
     from pecanpy_amd.synth import er_dense_mask
 
     n = 5000
     adj = er_dense_mask(n, 0.2, seed=9)
     starts = orc.shuffled_starts(n, 3, 1)
-    chain = WalkEngine.from_dense(adj.astype(np.float64))          # n <= 12000: compressed-row kernel
+    chain = WalkEngine.from_dense(adj.astype(np.float64))
     bits = WalkEngine.from_dense_bits(_pack_bits(adj), n)           # packed rows: column-space kernel
+    monkeypatch.setenv("PECANPY_AMD_DENSE_SMALL_ROWS", "1")         # n <= 12000: compressed-row kernel
     a = chain.simulate("DenseOTF", p, q, False, starts, 80, seed=2)
+    monkeypatch.delenv("PECANPY_AMD_DENSE_SMALL_ROWS")
+    c = chain.simulate("DenseOTF", p, q, False, starts, 80, seed=2)   # the same handle through the column-space kernels
+    assert np.array_equal(a, c)
     b = bits.simulate("DenseOTF", p, q, False, starts, 80, seed=2)
     assert np.array_equal(a, b), _diff_report(b, a)
     assert chain.last_stats["total_steps"] == bits.last_stats["total_steps"] > 10**6
