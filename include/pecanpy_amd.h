@@ -99,6 +99,12 @@ typedef struct {
 const char *pw_version(void);
 const char *pw_last_error(void);
 int pw_device_count(void);
+/* One-time start-up of this library on `device` (the first stream a process creates through the library costs ~140 ms on an
+ * MI355X box -- code objects, queues -- whatever torch or another library has initialised before): a caller with host work in front
+ * of its first handle (reading an edge list: cli.py:328-337, graph.py:270-341) runs this on a helper thread beside that work and
+ * pw_csr_create / pw_dense_create find the runtime warm.  *ms (optional) receives the wall clock of the call.  No reference
+ * counterpart (Numba's JIT compilation at the first call is the reference's start-up cost, pecanpy.py:164). */
+int pw_warmup(int device, double *ms);
 
 /* ---- graph handles --------------------------------------------------------------------- */
 /* CSR in the reference's SparseGraph layout (graph.py:409-413): indptr uint32[n_nodes+1],

@@ -62,6 +62,7 @@ SYMBOLS = {
     "pw_version": (C.c_char_p, []),
     "pw_last_error": (C.c_char_p, []),
     "pw_device_count": (C.c_int, []),
+    "pw_warmup": (C.c_int, [C.c_int, _f64p]),
     "pw_csr_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "pw_graph_index_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -153,6 +154,42 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+_warm = {"thread": None, "ms": None}
+
+
+def warmup_async(device=0):
+    """Start the library's one-time start-up on `device` (pw_warmup: ~140 ms for the first stream a process creates through the
+    library) on a helper thread and return at once: callers with host work in front of their first graph handle -- reading an edge
+    list, generating a graph -- call this first and find the runtime warm.  Harmless without a GPU or without the library (nothing
+    happens); `warmup_ms()` tells what it took once it is done."""
+    import threading
+
+    if _warm["thread"] is not None or not os.path.exists(LIB_PATH):
+        return
+
+    def run():
+        try:
+            ms = C.c_double(0.0)
+            if load().pw_warmup(C.c_int(device), C.byref(ms)) == 0:
+                _warm["ms"] = ms.value
+        except Exception:  # noqa: BLE001 (a warm-up that cannot run changes nothing: the first handle pays the start-up)
+            pass
+
+    _warm["thread"] = threading.Thread(target=run, name="pecanpy_amd-warmup", daemon=True)
+    _warm["thread"].start()
+    import atexit
+
+    atexit.register(lambda: _warm["thread"].join(timeout=5.0))   # (the interpreter does not leave while the runtime is starting)
+
+
+def warmup_ms():
+    """Wall clock of the finished warm-up in ms, or None (not started / still running / no GPU)."""
+    t = _warm["thread"]
+    if t is not None and not t.is_alive():
+        return _warm["ms"]
+    return None
 
 
 def check(rc):

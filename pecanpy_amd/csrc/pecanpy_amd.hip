@@ -261,6 +261,19 @@ PW_EXPORT int pw_device_count(void) {
     return n;
 }
 
+PW_EXPORT int pw_warmup(int device, double *ms) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = pw_device_count();
+    if (n <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(PW_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIP_TRY(hipStreamDestroy(s));
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PW_OK;
+}
+
 PW_EXPORT void pw_graph_destroy(pw_graph *g) {
     if (!g) return;
     if (g->twin) { pw_graph_destroy(g->twin); g->twin = nullptr; }
@@ -330,6 +343,10 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
 }
 
 static int graph_common_init(pw_graph *g, int device) {
+    const bool dbg = getenv("PECANPY_AMD_CREATE_DEBUG") != nullptr;
+    auto nowms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = nowms();
+    auto lap = [&](const char *what) { if (dbg) { const double t = nowms(); fprintf(stderr, "[create]   init: %-28s %8.2f ms\n", what, t - t0); t0 = t; } };
     int n = pw_device_count();
     if (n <= 0) return fail(PW_ERR_NO_DEVICE, "no HIP device visible (libpecanpy_amd needs a GPU; there is no CPU fallback)");
     if (device < 0 || device >= n) return fail(PW_ERR_INVALID, "device index out of range");
@@ -338,12 +355,17 @@ static int graph_common_init(pw_graph *g, int device) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     g->n_cu = prop.multiProcessorCount;
+    lap("device count / properties");
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    lap("stream");
     HIP_TRY(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+    lap("stream2");
     HIP_TRY(hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming));
     for (auto &e : g->ev) HIP_TRY(hipEventCreate(&e));
+    lap("events");
     HIP_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
     for (auto &e : g->ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    lap("copy stream + events");
     return 0;
 }
 
@@ -365,28 +387,59 @@ struct LaneWorkItems {
 static void make_lane_work_items(const uint32_t *indptr, const uint32_t *indices, uint32_t n_nodes, LaneWorkItems &w) {
     const uint32_t JCHUNK = 16384;
     w.vm0.assign((size_t)n_nodes + 1, 0u);
-    for (uint32_t h = 0; h < n_nodes; h++) {
-        const uint32_t d = indptr[h + 1] - indptr[h];
-        if (d < 2) {
-            // one neighbour k: N(h) & N(k) = {k} & N(k) is empty -- unless k has a SELF LOOP (then k's position in its own
-            // row is the one common neighbour of h and k; the pair is h's to take only when k -> h is no edge, but an item
-            // too many costs nothing).  (The indices are validated later, on the device: nothing is assumed of them here.)
-            if (d == 1 && indices) {
-                const uint32_t k = indices[indptr[h]];
-                if (k != h && k < n_nodes) {
-                    const uint32_t *row = indices + indptr[k], *end = indices + indptr[k + 1];
-                    if (std::binary_search(row, end, k)) w.small.push_back({h, 0u, 1u, 0u, 0u, d});
+    // The vertex pass on up to four threads, a contiguous range each (round 6: since the library's start-up no longer hides it --
+    // pw_warmup -- this pass, 185 ms on one thread at RMAT-22 with its scattered look-ups behind the one-neighbour rows, was what
+    // pw_csr_create waited for): the rows of up to LB_SMALL entries become items at once, the longer ones are listed and turned
+    // into items below, in vertex order (their per-segment count bases are a running sum).
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt >= 8 ? 4u : (nt >= 4 ? 2u : 1u);
+    if (n_nodes < (1u << 16)) nt = 1u;
+    std::vector<std::vector<pw::LaneBuildItem>> smalls(nt);
+    std::vector<std::vector<uint32_t>> bigs(nt);
+    auto scan = [&](unsigned t) {
+        const uint32_t h0 = (uint32_t)((uint64_t)n_nodes * t / nt), h1 = (uint32_t)((uint64_t)n_nodes * (t + 1) / nt);
+        std::vector<pw::LaneBuildItem> &sm = smalls[t];
+        sm.reserve((size_t)(h1 - h0) / 2 + 16);
+        for (uint32_t h = h0; h < h1; h++) {
+            const uint32_t d = indptr[h + 1] - indptr[h];
+            if (d < 2) {
+                // one neighbour k: N(h) & N(k) = {k} & N(k) is empty -- unless k has a SELF LOOP (then k's position in its own
+                // row is the one common neighbour of h and k; the pair is h's to take only when k -> h is no edge, but an item
+                // too many costs nothing).  (The indices are validated later, on the device: nothing is assumed of them here.)
+                if (d == 1 && indices) {
+                    const uint32_t k = indices[indptr[h]];
+                    if (k != h && k < n_nodes) {
+                        const uint32_t *row = indices + indptr[k], *end = indices + indptr[k + 1];
+                        if (std::binary_search(row, end, k)) sm.push_back({h, 0u, 1u, 0u, 0u, d});
+                    }
                 }
+                continue;
             }
-            continue;
+            if (d <= (uint32_t)pw::LB_SMALL) sm.push_back({h, 0u, 1u, 0u, 0u, d});
+            else bigs[t].push_back(h);
         }
-        if (d <= (uint32_t)pw::LB_SMALL) { w.small.push_back({h, 0u, 1u, 0u, 0u, d}); continue; }
-        const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
-        uint32_t m0 = 0;
-        if (nseg > 1) { m0 = (uint32_t)w.segcnt_total; w.segcnt_total += (uint64_t)d * nseg; w.vm0[h] = m0; }
-        for (uint32_t sg = 0; sg < nseg; sg++)
-            for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) w.large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) {
+            try { th.emplace_back(scan, t); } catch (const std::system_error &) { scan(t); }
+        }
+        scan(0);
+        for (auto &x : th) x.join();
     }
+    size_t n_small = 0;
+    for (auto &v : smalls) n_small += v.size();
+    w.small.reserve(n_small);
+    for (auto &v : smalls) { w.small.insert(w.small.end(), v.begin(), v.end()); std::vector<pw::LaneBuildItem>().swap(v); }
+    for (unsigned t = 0; t < nt; t++)
+        for (uint32_t h : bigs[t]) {
+            const uint32_t d = indptr[h + 1] - indptr[h];
+            const uint32_t nseg = (d + pw::LB_SEG - 1) / pw::LB_SEG;
+            uint32_t m0 = 0;
+            if (nseg > 1) { m0 = (uint32_t)w.segcnt_total; w.segcnt_total += (uint64_t)d * nseg; w.vm0[h] = m0; }
+            for (uint32_t sg = 0; sg < nseg; sg++)
+                for (uint32_t j0 = 0; j0 < d; j0 += JCHUNK) w.large.push_back({h, sg, nseg, m0, j0, j0 + JCHUNK < d ? j0 + JCHUNK : d});
+        }
     // the longest rows first (their workgroups run longest)
     std::stable_sort(w.large.begin(), w.large.end(), [&](const pw::LaneBuildItem &x, const pw::LaneBuildItem &y) {
         return indptr[x.h + 1] - indptr[x.h] > indptr[y.h + 1] - indptr[y.h];

@@ -77,6 +77,14 @@ class Base(BaseGraph):
         self._run_seed = None
         self.device = None  # GPU index; None -> LOCAL_RANK / 0
         self.last_stats = None
+        # the library's one-time start-up (~140 ms for the first stream it creates) runs on a helper thread beside what comes
+        # next in the reference's flow -- reading the graph (cli.py:328-337) -- instead of in front of the first walk
+        import os
+
+        if os.environ.get("PECANPY_AMD_NO_WARMUP") is None:
+            from . import _lib
+
+            _lib.warmup_async(int(os.environ.get("LOCAL_RANK", "0")))
 
     # ---- engine plumbing -------------------------------------------------------------------
     def _device_index(self):
