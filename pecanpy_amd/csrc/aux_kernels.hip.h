@@ -85,8 +85,90 @@ constexpr int MT_POLY_WORDS = 312;
 // jump tree have one, two, four ... jumps and would otherwise leave the GPU idle for ~0.4 ms each); every part folds
 // its slice of the polynomial into tmp[jump][624] with atomicXor (tmp zeroed), mt_jump_store_kernel moves the result
 // into place.  parts == 1: the result is written directly.
+// Round 6: the taps of g are first unpacked into a LIST of sequence offsets in LDS (uint16, ascending, padded to a multiple of
+// 16 with the offset of a zeroed block behind the sequence), then every output word folds 16 taps per trip: sixteen independent
+// LDS reads in flight instead of one bit-scan + one dependent read per tap (mt_jump_v1_kernel below: ~87 cycles per tap at 2.5
+// wavefronts per SIMD -- the LDS round trip -- i.e. ~0.36 ms per jump, 3.3 ms for the eleven tree levels of an RMAT-22 pass).
+// `parts` > 1 slices the tap LIST (16-tap granules), not the polynomial's words.
+constexpr int MT_TAP_CAP = 19968 + 16;               // >= 19937 taps rounded up to 16, + one granule read ahead
+constexpr int MT_ZERO_OFF = MT_SEQ_BLOCKS * 624;     // seq[MT_ZERO_OFF + t] = 0 for t < 624: what a padding tap reads
 __global__ void __launch_bounds__(640)
 mt_jump_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly, uint32_t src_stride,
+               uint32_t dst_offset, uint32_t parts, uint32_t *tmp) {
+    __shared__ uint32_t seq[(MT_SEQ_BLOCKS + 1) * 624];
+    __shared__ __attribute__((aligned(16))) uint16_t taps[MT_TAP_CAP];
+    __shared__ uint32_t wcnt[MT_POLY_WORDS];
+    const int t = threadIdx.x;
+    const uint32_t jump = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint64_t src = (uint64_t)jump * src_stride;
+    uint64_t word = 0;
+    if (t < 624) { seq[t] = states[src * 624 + t]; seq[MT_ZERO_OFF + t] = 0u; }
+    if (t < MT_POLY_WORDS) {
+        word = poly[t];
+        if (t == MT_POLY_WORDS - 1) word &= (1ull << (19937 - 64 * (MT_POLY_WORDS - 1))) - 1ull;   // (degree < 19937)
+        wcnt[t] = (uint32_t)__popcll(word);
+    }
+    __syncthreads();
+    uint32_t total = 0, pos = 0;
+    for (int k = 0; k < MT_POLY_WORDS; k++) {   // (uniform reads: 312 broadcasts)
+        const uint32_t c = wcnt[k];
+        if (k < t) pos += c;
+        total += c;
+    }
+    if (t < MT_POLY_WORDS)
+        while (word) {
+            const int b = __builtin_ctzll(word);
+            word &= word - 1;
+            taps[pos++] = (uint16_t)(t * 64 + b);
+        }
+    const uint32_t padded = (total + 15u) & ~15u;
+    if ((uint32_t)t < padded - total) taps[total + (uint32_t)t] = (uint16_t)MT_ZERO_OFF;
+    __syncthreads();
+    // this part's slice of the list, in granules of 16 taps
+    const uint32_t gran = padded / 16u;
+    const uint32_t g0 = (uint32_t)((uint64_t)gran * part / parts), g1 = (uint32_t)((uint64_t)gran * (part + 1u) / parts);
+    const uint32_t k0 = g0 * 16u, k1 = g1 * 16u;
+    // it reads sequence words up to (its last real tap) + 623
+    int need = 1;
+    if (k1 > k0) {
+        const uint32_t last = k1 <= total ? taps[k1 - 1u] : (total > k0 ? taps[total - 1u] : 0u);
+        need = (int)((last + 623u) / 624u) + 1;
+    }
+    if (need > MT_SEQ_BLOCKS) need = MT_SEQ_BLOCKS;
+    for (int blk = 1; blk < need; blk++) {
+        uint32_t *nw = seq + blk * 624;
+        const uint32_t *od = nw - 624;
+        if (t < 227) nw[t] = mt_mix_dev(od[t], od[t + 1], od[t + 397]);
+        __syncthreads();
+        if (t >= 227 && t < 454) nw[t] = mt_mix_dev(od[t], od[t + 1], nw[t - 227]);
+        __syncthreads();
+        if (t >= 454 && t < 624) nw[t] = mt_mix_dev(od[t], (t < 623) ? od[t + 1] : nw[0], nw[t - 227]);
+        __syncthreads();
+    }
+    if (t < 624) {
+        const uint32_t *sb = seq + t;
+        uint32_t acc0 = 0, acc1 = 0;
+        uint4 qa = *(const uint4 *)(taps + k0), qb = *(const uint4 *)(taps + k0 + 8u);
+        for (uint32_t k = k0; k < k1; k += 16u) {
+            // (the next trip's offsets are requested before this trip's words: k + 16 <= MT_TAP_CAP - 16 lies inside the array)
+            const uint4 na = *(const uint4 *)(taps + k + 16u), nb = *(const uint4 *)(taps + k + 24u);
+            const uint32_t x0 = sb[qa.x & 0xffffu], x1 = sb[qa.x >> 16], x2 = sb[qa.y & 0xffffu], x3 = sb[qa.y >> 16];
+            const uint32_t x4 = sb[qa.z & 0xffffu], x5 = sb[qa.z >> 16], x6 = sb[qa.w & 0xffffu], x7 = sb[qa.w >> 16];
+            const uint32_t y0 = sb[qb.x & 0xffffu], y1 = sb[qb.x >> 16], y2 = sb[qb.y & 0xffffu], y3 = sb[qb.y >> 16];
+            const uint32_t y4 = sb[qb.z & 0xffffu], y5 = sb[qb.z >> 16], y6 = sb[qb.w & 0xffffu], y7 = sb[qb.w >> 16];
+            acc0 ^= (x0 ^ x1) ^ (x2 ^ x3) ^ (x4 ^ x5) ^ (x6 ^ x7);
+            acc1 ^= (y0 ^ y1) ^ (y2 ^ y3) ^ (y4 ^ y5) ^ (y6 ^ y7);
+            qa = na; qb = nb;
+        }
+        const uint32_t acc = acc0 ^ acc1;
+        if (parts == 1) states[(src + dst_offset) * 624 + t] = acc;
+        else if (acc) atomicXor(&tmp[(uint64_t)jump * 624 + t], acc);
+    }
+}
+
+// (the first form: one bit scan and one dependent LDS read per tap; PECANPY_AMD_MT_JUMP_V1=1, kept for same-box comparisons)
+__global__ void __launch_bounds__(640)
+mt_jump_v1_kernel(uint32_t *__restrict__ states, const uint64_t *__restrict__ poly, uint32_t src_stride,
                uint32_t dst_offset, uint32_t parts, uint32_t *tmp) {
     __shared__ uint32_t seq[MT_SEQ_BLOCKS * 624];
     __shared__ uint64_t spoly[MT_POLY_WORDS];

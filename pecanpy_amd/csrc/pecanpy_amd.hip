@@ -2264,8 +2264,11 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
             uint32_t parts = jumps >= 128 ? 1u : (uint32_t)(g->n_cu > 0 ? g->n_cu : 256) / jumps;
             if (parts > 39) parts = 39;
             if (parts < 1) parts = 1;
-            hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
-                               dst_offset, parts, g->jump_tmp.p);
+            static const bool v1 = env_on("PECANPY_AMD_MT_JUMP_V1");   // (the tap loop of rounds 1-5, for same-box comparisons)
+            if (v1) hipLaunchKernelGGL(pw::mt_jump_v1_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
+                                       dst_offset, parts, g->jump_tmp.p);
+            else hipLaunchKernelGGL(pw::mt_jump_kernel, dim3(jumps * parts), dim3(640), 0, g->stream, mt_states, poly, src_stride,
+                                    dst_offset, parts, g->jump_tmp.p);
             if (parts > 1)
                 hipLaunchKernelGGL(pw::mt_jump_store_kernel, dim3(jumps), dim3(640), 0, g->stream, mt_states, g->jump_tmp.p,
                                    src_stride, dst_offset);
@@ -2285,6 +2288,9 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
         mc->valid = true;
         mc->seed = seed; mc->first_block = first_block; mc->per_gen_log = per_gen_log; mc->n_gen = n_gen;
     }
+    // (measured and not kept, round 6: the block in two LDS copies -- three barriers per block instead of six -- with 64 / 128 /
+    //  256 lanes per generator: 8.4 / 6.9 / 6.06 ms of jump + expansion per RMAT-22 pass against 6.08-6.16: the expansion is bound
+    //  by its 12.9 GB of stores at ~3 TB/s, not by the barriers)
     hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, mt_states,
                        (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
     HIP_TRY(hipGetLastError());
