@@ -1823,8 +1823,18 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     }
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
+    const uint64_t late_chains = getenv("PECANPY_AMD_LATE_CHAINS") ? (uint64_t)strtoull(getenv("PECANPY_AMD_LATE_CHAINS"), nullptr, 10) : 16ull;
     for (int round = 0;; round++) {
-        const bool chains_now = chains_form && round == 0;
+        // LATE rounds in the CHAINS form (round 6): once a round resumes few enough walks -- the third round of an RMAT-22 pass on --
+        // the rest of the pass is a sequence of short launches that each last as long as their slowest walks (lane round, chain
+        // launch, lane round, ...); the CHAINS form runs the chains of such a round inside it, so the sequence ends one or two
+        // launches earlier.  PECANPY_AMD_LATE_CHAINS = resumed walks per resident lane up to which a round takes it (0: never;
+        // default 16).  RMAT-22 pass, same box, same walks: the rounds behind the second, 1.43 M + 0.32 M walks, 2.96 + 2.09 ms ->
+        // one round of 3.7 ms; the pass 103.4 -> 102.3 ms.  32 (the second round too: 5.2 M walks): 12.9 ms against 7.7 + 3.0 + 2.1;
+        // 64 (every round behind the first): 44.6 against 36.1 (profiles/r06_late_chains.txt).
+        const bool chains_late = late_chains > 0 && round >= 1 && !weighted && !tails && use_queue && !verify_full && !tail_env &&
+                                 g->list_max_len == 0xffffffffu && todo >= lanes_resident_c && todo <= late_chains * lanes_resident_c;
+        const bool chains_now = (chains_form && round == 0) || chains_late;
         bool queue_out = chains_now || (use_queue && todo > tail && round < (weighted ? 512 : 64));
         if (queue_out && round >= 1 && g->susp[round & 1].ensure((size_t)todo + 2 * (size_t)lanes_resident)) {
             (void)hipGetLastError();

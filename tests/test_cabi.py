@@ -80,6 +80,20 @@ def test_no_cpu_fallback_without_gpu():
         WalkEngine.from_csr(indptr, indices, None)
 
 
+@pytest.mark.skipif(_lib.load().pw_device_count() > 0, reason="needs a box WITHOUT a GPU")
+def test_warmup_without_a_gpu_is_an_error_in_c_and_harmless_in_the_host_layer():
+    """pw_warmup (the library's start-up, meant for a helper thread beside the graph read) reports the missing device like every
+    other entry point; the host layer's warmup_async swallows that -- the first graph handle then fails loudly as before."""
+    ms = C.c_double(-1.0)
+    assert _lib.load().pw_warmup(C.c_int(0), C.byref(ms)) != 0
+    assert b"no HIP device" in _lib.load().pw_last_error()
+    _lib.warmup_async(0)
+    t = _lib._warm["thread"]
+    assert t is not None
+    t.join(timeout=30.0)
+    assert not t.is_alive() and _lib.warmup_ms() is None
+
+
 def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

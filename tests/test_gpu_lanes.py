@@ -320,6 +320,37 @@ def test_chains_form_equals_the_rounds_and_the_oracle(p, q, monkeypatch):
     assert np.array_equal(got, hwant)
 
 
+def test_late_rounds_in_the_chains_form_equal_the_plain_rounds_and_the_oracle(monkeypatch):
+    """Round 6: a round that resumes few walks per resident lane runs in the CHAINS form (its float chains inside the launch), so
+    the tail of a pass is one launch instead of lane round / chain launch / lane round ...  Same walks as the plain rounds
+    (PECANPY_AMD_LATE_CHAINS=0) and as the oracle on a prefix, in fewer rounds -- on a job array large enough for the rounds."""
+    import torch
+
+    indptr, indices, data = rmat_csr(19, seed=3)
+    n = indptr.size - 1
+    starts = np.concatenate([np.arange(n, dtype=np.uint32)] * 20)          # 10.5 M jobs: beyond the CHAINS form's own range
+    np.random.RandomState(2).shuffle(starts)
+    d_starts = torch.from_numpy(starts.view(np.int32)).cuda()
+    eng = WalkEngine.from_csr(indptr, indices, data)
+    runs = {}
+    for name, late in (("plain", "0"), ("late", "64"), ("default", None)):
+        if late is not None:
+            monkeypatch.setenv("PECANPY_AMD_LATE_CHAINS", late)
+        out = eng.simulate_device("SparseOTF", 0.5, 2, False, d_starts, 80, seed=11)
+        if late is not None:
+            monkeypatch.delenv("PECANPY_AMD_LATE_CHAINS")
+        runs[name] = (out, dict(eng.last_stats))
+    for name, (out, st) in runs.items():
+        assert st["lane_kernel"] == 1 and st["redo_walks"] == 0, (name, st)
+        assert torch.equal(out, runs["plain"][0]), name
+        assert st["total_steps"] == runs["plain"][1]["total_steps"]
+    assert runs["plain"][1]["lane_rounds"] >= 3
+    assert 1 < runs["late"][1]["lane_rounds"] < runs["plain"][1]["lane_rounds"]
+    assert runs["default"][1]["lane_rounds"] <= runs["plain"][1]["lane_rounds"]
+    want = orc.walks_sparse_otf(indptr, indices, data, 0.5, 2, starts[:6000], 80, 11)
+    assert np.array_equal(runs["late"][0][:6000].cpu().numpy().view(np.uint32), want)
+
+
 def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
     """Directed graph with sinks: the repair passes run the lane kernel on job lists; with every chain step parked the
     rounds resume walks of a job list."""
@@ -341,6 +372,26 @@ def test_parked_walks_in_repair_passes_on_job_lists(monkeypatch):
     assert st0["stream_addressing"] == 0
     want = orc.walks_sparse_otf(indptr, indices, data, 0.25, 4, starts, 12, 3)
     assert np.array_equal(got, want)
+
+
+def test_library_warmup_entry_point():
+    """pw_warmup: the library's one-time start-up as a call of its own (round 6; Base.__init__ runs it on a helper thread beside
+    the graph read).  It succeeds on a visible device, reports its wall clock, rejects a device that is not there, and the host
+    layer's helper thread ends with the time recorded."""
+    import ctypes as C
+
+    from pecanpy_amd import _lib
+
+    lib = _lib.load()
+    ms = C.c_double(-1.0)
+    assert lib.pw_warmup(C.c_int(0), C.byref(ms)) == 0 and ms.value >= 0.0
+    assert lib.pw_warmup(C.c_int(0), None) == 0
+    assert lib.pw_warmup(C.c_int(lib.pw_device_count()), C.byref(ms)) != 0
+    _lib.warmup_async(0)
+    t = _lib._warm["thread"]
+    assert t is not None
+    t.join(timeout=60.0)
+    assert not t.is_alive() and _lib.warmup_ms() is not None
 
 
 def test_graph_handle_releases_its_device_memory(monkeypatch):

@@ -21,6 +21,12 @@ int main(int argc, char **argv) {
     };
     if (!strcmp(mode, "two")) { void *a = alloc(4.5, true); void *b = alloc(5.2, true); void *c = alloc(13.8, true); void *d = alloc(5.2, false); hipFree(a); hipFree(b); hipFree(c); hipFree(d); alloc(5.2, false); }
     else if (!strcmp(mode, "one")) { alloc(9.7, true); alloc(0.5, true); alloc(13.8, true); }
+    else if (!strcmp(mode, "pre")) {   // does ONE big allocation, freed at once, make the later ones cheap? (pw_warmup's pretouch)
+        const double gb = argc > 2 ? atof(argv[2]) : 40.0;
+        void *a = alloc(gb, false); double t0 = now(); hipFree(a); printf("[pre] hipFree %.2f ms\n", (now() - t0) * 1e3);
+        void *b = alloc(4.5, true); void *c = alloc(5.2, true); void *d = alloc(13.8, true); void *e2 = alloc(12.9, true);
+        hipFree(b); hipFree(c); hipFree(d); hipFree(e2);
+    }
     else if (!strcmp(mode, "small")) { for (int i = 0; i < 6; i++) alloc(1.0, false); alloc(5.2, false); }
     return 0;
 }
