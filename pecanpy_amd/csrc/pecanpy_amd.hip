@@ -1758,13 +1758,16 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     // walks.  Its chain code costs a wavefront per SIMD and its chain passes run at 20 of 64 lanes, so it pays up to ~32 jobs per
     // resident lane (RMAT-22 graph, 1.3 / 2.6 / 5.2 M jobs: 13.3 -> 7.3, 16.8 -> 11.7, 23.9 -> 21.4 ms per call; 10.5 M: 37.9 vs
     // 39.6; 41.9 M: 118 vs 146); lists of less than a job per lane keep the plain in-place launch.
+    // Round 6: with the LATE rounds in the CHAINS form (below) the rounds win from ~16 jobs per resident lane on -- 2.6 / 5.2 /
+    // 10.5 M jobs: CHAINS from the first round 10.6 / 19.6 / 36.5 ms per call, rounds + late chains 10.8 / 18.3 / 32.4 (1.3 M: 6.5
+    // against 9.4, one in-place launch) -- so the form takes job arrays of up to 16 jobs per resident lane (rounds 5-6: 32).
     // PECANPY_AMD_LANE_CHAINS=0/1 overrides.
     int occ_c = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, (const void *)pw::walk_lanes_kernel<false, false, false, false, false, true>, pw::WAVES_PER_BLOCK * pw::WAVE, 0));
     if (occ_c < 1) occ_c = 1;
     const uint64_t lanes_resident_c = (uint64_t)g->n_cu * (uint64_t)occ_c * pw::WAVES_PER_BLOCK * pw::WAVE;
     bool chains_form = !weighted && !getenv("PECANPY_AMD_VERIFY_TIGHT") && !tail_env && !getenv("PECANPY_AMD_NO_CHAIN_QUEUE") &&
-                       g->list_max_len == 0xffffffffu && n_work >= lanes_resident_c && n_work <= 32 * lanes_resident_c;
+                       g->list_max_len == 0xffffffffu && n_work >= lanes_resident_c && n_work <= 16 * lanes_resident_c;
     if (const char *ce = getenv("PECANPY_AMD_LANE_CHAINS")) chains_form = atoi(ce) != 0 && !weighted && !getenv("PECANPY_AMD_VERIFY_TIGHT");
     if (chains_form) use_queue = true;      // (a step that finds the pool full is still parked: the round loop below takes care of it)
     // Queue capacities (round 6: from what CAN be parked, not from the job array -- device memory a fresh box has not handed out
