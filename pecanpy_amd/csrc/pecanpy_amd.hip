@@ -157,6 +157,7 @@ struct pw_graph {
     hipStream_t stream2 = nullptr;   // side stream: the zero-fill of the walk matrix runs under the stream expansion
     hipEvent_t ev_side = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> round_ev;          // lane rounds: a pair of events per round, read once behind the last round (no sync per round)
     // pw_simulate() walks a large job array in parts: the stream of the WHOLE array is expanded once, and while this is
     // set expand_stream() serves the parts' sub-ranges from g->rng as it stands (never kept across API calls)
     struct { bool valid = false, user = false; uint32_t seed = 0; uint64_t first_block = 0, n_blocks = 0; } rng_hold;   // (user: pw_stream_hold)
@@ -332,6 +333,8 @@ PW_EXPORT void pw_graph_destroy(pw_graph *g) {
         if (b) (void)hipHostFree(b);
     if (g->seed_state) (void)hipHostFree(g->seed_state);
     for (auto &e : g->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : g->round_ev)
         if (e) (void)hipEventDestroy(e);
     if (g->ev_side) (void)hipEventDestroy(g->ev_side);
     for (auto &e : g->ev_copy)
@@ -1826,6 +1829,7 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     }
     unsigned long long nr = 0, parked = 0;
     uint64_t todo = n_work;
+    int n_rounds = 0;
     const uint64_t late_chains = getenv("PECANPY_AMD_LATE_CHAINS") ? (uint64_t)strtoull(getenv("PECANPY_AMD_LATE_CHAINS"), nullptr, 10) : 16ull;
     for (int round = 0;; round++) {
         // LATE rounds in the CHAINS form (round 6): once a round resumes few enough walks -- the third round of an RMAT-22 pass on --
@@ -1861,7 +1865,12 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
         }
         HIP_TRY(hipMemsetAsync(g->counters.p, 0, sizeof(unsigned long long), g->stream));
         HIP_TRY(hipMemsetAsync(g->counters.p + 32, 0, sizeof(unsigned long long), g->stream));
-        HIP_TRY(hipEventRecord(g->ev[4], g->stream));
+        while (g->round_ev.size() < 2 * (size_t)round + 2) {   // (this round's pair: read behind the last round)
+            hipEvent_t ne = nullptr;
+            HIP_TRY(hipEventCreate(&ne));
+            g->round_ev.push_back(ne);
+        }
+        HIP_TRY(hipEventRecord(g->round_ev[2 * (size_t)round], g->stream));
         if (verify_full || (verify_sample && round == 0)) HIP_TRY(hipMemsetAsync(g->counters.p + 40, 0, 4 * sizeof(unsigned long long), g->stream));
         const dim3 lgrid((unsigned)grid), lblock(pw::WAVES_PER_BLOCK * pw::WAVE);
         if (chains_now && verify) hipLaunchKernelGGL((pw::walk_lanes_kernel<false, true, false, false, false, true>), lgrid, lblock, 0, g->stream, la);
@@ -1929,13 +1938,17 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
                 HIP_TRY(hipGetLastError());
             }
         }
-        HIP_TRY(hipEventRecord(g->ev[5], g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));
-        float rms = 0;
-        HIP_TRY(hipEventElapsedTime(&rms, g->ev[4], g->ev[5]));
-        g->lane_ms += rms;
+        HIP_TRY(hipEventRecord(g->round_ev[2 * (size_t)round + 1], g->stream));
         g->lane_rounds++;
-        if (getenv("PW_DEBUG_ROUNDS")) fprintf(stderr, "[lanes] round %d: %llu walks, %llu parked, %.2f ms\n", round, (unsigned long long)todo, parked, rms);
+        n_rounds = round + 1;
+        if (getenv("PW_DEBUG_ROUNDS")) {
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            float rms = 0;
+            HIP_TRY(hipEventElapsedTime(&rms, g->round_ev[2 * (size_t)round], g->round_ev[2 * (size_t)round + 1]));
+            fprintf(stderr, "[lanes] round %d: %llu walks, %llu parked, %.2f ms\n", round, (unsigned long long)todo, parked, rms);
+        }
+        // (no wait here: the next round's launch -- or the read-back behind the loop -- follows the chain launch in stream order;
+        //  the rounds' kernel times are read from their event pairs behind the last round)
         if (!parked) break;
         todo = parked;
     }
@@ -1943,6 +1956,11 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
     if (verify_sample) HIP_TRY(hipMemcpyAsync(&n_rec_s, g->counters.p + 40, sizeof(n_rec_s), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipMemcpyAsync(&nr, g->counters.p + 6, sizeof(nr), hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    for (int r = 0; r < n_rounds; r++) {
+        float rms = 0;
+        HIP_TRY(hipEventElapsedTime(&rms, g->round_ev[2 * (size_t)r], g->round_ev[2 * (size_t)r + 1]));
+        g->lane_ms += rms;
+    }
     if (verify_sample && n_rec_s) {   // the sample of ALL rounds (the records accumulate across them): re-decided by the chain, one launch
         const unsigned long long n_chk = n_rec_s < la.ver_cap ? n_rec_s : la.ver_cap;
         g->ver_dropped += n_rec_s - n_chk;
