@@ -460,8 +460,13 @@ static void make_lane_work_items(const uint32_t *indptr, const uint32_t *indices
         }                                                                                                        \
     } while (0)
 
-static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d_edge_row, bool has_loop) {
-    if (!g->nnz) return 0;
+static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d_edge_row, bool has_loop, void *pre_lines = nullptr,
+                            uint64_t pre_bytes = 0) {
+    // (pre_lines: the edge lines' memory, allocated by pw_csr_create's helper thread beside the host pass and the first kernels
+    //  -- device memory a fresh box hands out for the first time costs up to ~25 ms per GB of hipMalloc; owned by g from here on)
+    if (pre_lines) g->d_lines = (pw::ELine *)pre_lines;
+    auto no_index = [&]() { if (g->d_lines) { (void)hipFree(g->d_lines); g->d_lines = nullptr; } return 0; };
+    if (!g->nnz) return no_index();
     const uint32_t nnz = g->nnz, n_nodes = g->n_nodes;
     const bool dbg = getenv("PECANPY_AMD_CREATE_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -475,7 +480,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     };
     std::vector<pw::LaneBuildItem> &small = items.small, &large = items.large;
     const uint64_t segcnt_total = items.segcnt_total;
-    if (segcnt_total >= 0xffffffffull) return 0;   // (rows this long and this many: no lane index)
+    if (segcnt_total >= 0xffffffffull) return no_index();   // (rows this long and this many: no lane index)
     // + one OVERFLOW line per vertex (walk_lanes.hip.h: vline_init_kernel): the pair of its mirrored choice == degree read
     const bool vlines = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
     const uint32_t n_lines = vlines ? nnz + n_nodes : nnz;
@@ -483,7 +488,8 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     (void)hipMemGetInfo(&free_b, &total_b);
     stamp("hipMemGetInfo");
     const uint64_t line_bytes = (uint64_t)n_lines * sizeof(pw::ELine) + 64;
-    if (line_bytes > free_b / 2) return 0;
+    if (g->d_lines && pre_bytes != line_bytes) no_index();   // (cannot happen: the same formula sized it)
+    if (!g->d_lines && line_bytes > free_b / 2) return 0;
     pw::LaneBuildItem *d_small = nullptr, *d_large = nullptr;
     uint32_t *d_segcnt = nullptr;
     uint64_t *d_tiles = nullptr, *d_etiles = nullptr;
@@ -504,7 +510,7 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
         (void)hipGetLastError();
         return rc;
     };
-    hipError_t e = hipMalloc((void **)&g->d_lines, line_bytes);
+    hipError_t e = g->d_lines ? hipSuccess : hipMalloc((void **)&g->d_lines, line_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_small, sizeof(pw::LaneBuildItem) * (small.size() + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&d_large, sizeof(pw::LaneBuildItem) * (large.size() + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&d_segcnt, sizeof(uint32_t) * (size_t)(segcnt_total + 1));
@@ -741,6 +747,25 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     int rc = graph_common_init(g, device);
     if (rc) { pw_graph_destroy(g); return rc; }
     stamp("runtime / streams / events");
+    // the edge lines of the lane index (64 bytes per CSR entry + one per vertex: 4.4 GB at RMAT-22) are allocated by a helper
+    // thread from here on, beside the host pass, the copy of the CSR and the validation / membership kernels: on a box whose
+    // device memory has not been handed out before, that hipMalloc alone costs ~120 ms (EXPERIMENTS.md, rounds 5-6)
+    struct LinesPre {
+        std::thread t; void *p = nullptr; uint64_t bytes = 0; bool taken = false;
+        ~LinesPre() { if (t.joinable()) t.join(); if (p && !taken) (void)hipFree(p); }
+    } lines_pre;
+    if (nnz && !getenv("PECANPY_AMD_NO_LAZY") && !getenv("PECANPY_AMD_NO_PREALLOC")) {
+        const bool vl = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
+        lines_pre.bytes = (uint64_t)(vl ? nnz + n_nodes : nnz) * sizeof(pw::ELine) + 64;
+        try {
+            lines_pre.t = std::thread([&lines_pre, device]() {
+                size_t free_b = 0, total_b = 0;
+                if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+                if (lines_pre.bytes > free_b / 2) return;               // (build_lane_index's rule: no lane index then)
+                if (hipMalloc(&lines_pre.p, lines_pre.bytes) != hipSuccess) { lines_pre.p = nullptr; (void)hipGetLastError(); }
+            });
+        } catch (const std::system_error &) {}   // (thread limit: build_lane_index allocates)
+    }
     g->kind = 0;
     g->n_nodes = n_nodes;
     g->nnz = nnz;
@@ -856,7 +881,9 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         // node2vec+ tables pair the two directions' lists entry by entry, and the fix makes their lengths differ).
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
         item_thread.join();
-        rc = build_lane_index(g, items, d_edge_row, has_loop);
+        if (lines_pre.t.joinable()) lines_pre.t.join();
+        lines_pre.taken = lines_pre.p != nullptr;
+        rc = build_lane_index(g, items, d_edge_row, has_loop, lines_pre.p, lines_pre.bytes);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
     (void)hipStreamSynchronize(g->stream);
