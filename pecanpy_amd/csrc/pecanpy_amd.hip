@@ -586,9 +586,27 @@ static int build_lane_index(pw_graph *g, LaneWorkItems &items, const uint32_t *d
     }
     auto lists = [&](bool fill) {
         if (!large.empty()) {
-            if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
-            else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false, true>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
-            else hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false>), dim3((unsigned)large.size()), dim3(256), 0, g->stream, ba, d_large);
+            // wavefronts per workgroup of the long rows' kernel (PECANPY_AMD_INDEX_THREADS = 256 / 512 / 1024 lanes): a workgroup holds
+            // 8192 row positions in LDS (33 KB: four workgroups per CU) and its wavefronts wait for the 13 dependent LDS reads of
+            // a search most of the time (SQ_WAIT_ANY 74 % of the wave cycles at 3.7 wavefronts per SIMD, profiles/r06_pmc_headline.txt)
+            // -- with 512 lanes the same LDS serves EIGHT wavefronts per SIMD instead of four (26-32 VGPRs: the registers allow
+            // it).  RMAT-22, same box: index kernels 170.6 -> 117.0 ms with 512 (the default since round 6's fourth session),
+            // 122.7 with 1024; COUNT + FILL of the long rows 130 -> ~77 ms.
+            static const int ith = getenv("PECANPY_AMD_INDEX_THREADS") ? atoi(getenv("PECANPY_AMD_INDEX_THREADS")) : 512;
+            const dim3 lg((unsigned)large.size());
+            if (ith == 512) {
+                if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<512, pw::LB_SEG, true>), lg, dim3(512), 0, g->stream, ba, d_large);
+                else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<512, pw::LB_SEG, false, true>), lg, dim3(512), 0, g->stream, ba, d_large);
+                else hipLaunchKernelGGL((pw::lane_lists_kernel<512, pw::LB_SEG, false>), lg, dim3(512), 0, g->stream, ba, d_large);
+            } else if (ith == 1024) {
+                if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<1024, pw::LB_SEG, true>), lg, dim3(1024), 0, g->stream, ba, d_large);
+                else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<1024, pw::LB_SEG, false, true>), lg, dim3(1024), 0, g->stream, ba, d_large);
+                else hipLaunchKernelGGL((pw::lane_lists_kernel<1024, pw::LB_SEG, false>), lg, dim3(1024), 0, g->stream, ba, d_large);
+            } else {
+                if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, true>), lg, dim3(256), 0, g->stream, ba, d_large);
+                else if (logged) hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false, true>), lg, dim3(256), 0, g->stream, ba, d_large);
+                else hipLaunchKernelGGL((pw::lane_lists_kernel<256, pw::LB_SEG, false>), lg, dim3(256), 0, g->stream, ba, d_large);
+            }
         }
         if (!small.empty()) {
             if (fill) hipLaunchKernelGGL((pw::lane_lists_kernel<64, pw::LB_SMALL, true>), dim3((unsigned)small.size()), dim3(64), 0, g->stream, ba, d_small);

@@ -252,8 +252,8 @@ __device__ unsigned long long g_lprof[16];
             if (a.lines[(uint64_t)a.nnz + vtx_].nxt != NOT_FOUND) oe_ = a.nnz + vtx_;           \
         }                                                                                       \
         if (choice >= A.d && oe_ == NOT_FOUND) {   /* walk_kernel takes the walk over AT THIS STEP (WalkArgs::resume) */ \
-            const unsigned long long slot_ = atomicAdd(a.redo_count, 1ull);                     \
-            a.redo_list[slot_] = A.job;                                                         \
+            const unsigned long long slot_ = atomicAdd(LAP(unsigned long long *, redo_count), 1ull);                     \
+            LAP(uint32_t *, redo_list)[slot_] = A.job;                                                         \
             const uint32_t st_ = (A.j - 1u) & 3u;   /* staged cells out, length cell = A.j */     \
             uint32_t *row_ = a.out + (uint64_t)A.job * W;                                       \
             if (st_ >= 1u) row_[A.j - st_] = ob.v[0];                                           \
@@ -264,7 +264,7 @@ __device__ unsigned long long g_lprof[16];
         } else {                                                                                \
             A.e = oe_ != NOT_FOUND ? oe_ : A.s0 + choice;                                       \
             if (oe_ != NOT_FOUND) {   /* (~1e-5 of the steps: counted where it happens; a sampled transition too) */ \
-                atomicAdd(a.stats + 1, 1ull); atomicAdd(a.stats + 0, 1ull);                     \
+                atomicAdd(LAP(unsigned long long *, stats) + 1, 1ull); atomicAdd(LAP(unsigned long long *, stats) + 0, 1ull);                     \
             }                                                                                   \
             fetch_ = true;                                                                      \
         }                                                                                       \
@@ -531,6 +531,15 @@ walk_lanes_kernel(LanesArgs a) {
     const uint32_t L = a.L;
     const uint64_t W = (uint64_t)L + 2;
     const uint64_t n_work = a.resume ? a.n_resume : (a.job_list ? a.n_list : a.n_jobs);
+    // Rarely used kernel arguments -- counters, queues, the job list, the verification buffer -- are RE-READ from the kernarg segment
+    // where they are used (wave.h: kernarg<T>, an s_load) instead of staying live across the loop: kept live they do not fit
+    // the 102 scalar registers of a wavefront, the allocator parks them in VGPR lanes and every use becomes one v_readlane per
+    // dword -- 430 of them in the QUAD instantiation before this (round 6, fourth session), each a vector-ALU issue slot of a
+    // kernel that is bound by exactly those.
+#define LA64(field) kernarg<uint64_t>(offsetof(LanesArgs, field))
+#define LA32(field) kernarg<uint32_t>(offsetof(LanesArgs, field))
+#define LAP(T, field) ((T)LA64(field))
+    const bool resuming = a.resume != nullptr;
     const float w_out = a.w_out, w_prev = a.w_prev;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
 #ifdef PW_PROF_LANES
@@ -586,9 +595,9 @@ walk_lanes_kernel(LanesArgs a) {
         const uint64_t old_lo = sp_lo;
         uint64_t new_lo = 0;
         if (left < np) {
-            const unsigned long long chunk = a.susp_chunk > np - left ? a.susp_chunk : np - left;
+            const unsigned long long sc_ = LA32(susp_chunk), chunk = sc_ > np - left ? sc_ : np - left;
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(a.susp_count, chunk);
+            if (lane == 0) base = atomicAdd(LAP(unsigned long long *, susp_count), chunk);
             new_lo = readfirst_u64(base);
             sp_lo = new_lo + (np - left);
             sp_hi = new_lo + chunk;
@@ -718,14 +727,14 @@ walk_lanes_kernel(LanesArgs a) {
                     const uint64_t vm = ballot(rec);
                     if (vm) {
                         unsigned long long vb = 0;
-                        if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                        if (lane == 0) vb = atomicAdd(LAP(unsigned long long *, ver_count), (unsigned long long)__popcll(vm));
                         vb = readfirst_u64(vb);
                         const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
-                        if (rec && slot < a.ver_cap) {
+                        if (rec && slot < LA64(ver_cap)) {
                             const uint4 p0 = pool[0][lane], p1 = pool[1][lane], p4 = pool[4][lane];
                             const float wo_s = p0.y >= 2u ? w_out : 1.0f;
-                            uint4 *vp = (uint4 *)(a.ver + slot);
-                            vp[0] = make_uint4(kmax_s, p1.x, p1.y, (a.ver_poison && (slot & 1023u) == 0u) ? ch ^ 1u : ch);
+                            uint4 *vp = (uint4 *)(LAP(VerRec *, ver) + slot);
+                            vp[0] = make_uint4(kmax_s, p1.x, p1.y, (LA32(ver_poison) && (slot & 1023u) == 0u) ? ch ^ 1u : ch);
                             vp[1] = make_uint4(p1.z, p1.w, p0.w, p0.x);
                             vp[2] = make_uint4(__float_as_uint((float)lane_row_total(p0.w, p1.x, p1.y, wo_s, w_prev)), __float_as_uint(wo_s), p4.x, p4.y);
                         }
@@ -739,7 +748,7 @@ walk_lanes_kernel(LanesArgs a) {
                     if (mine && ch == LANE_AMBIGUOUS) {
                         const uint4 p0 = pool[0][lane], p1 = pool[1][lane], p2 = pool[2][lane], p4 = pool[4][lane];
                         const float wo_s = p0.y >= 2u ? w_out : 1.0f;
-                        uint4 *qp = (uint4 *)(a.susp + qs);
+                        uint4 *qp = (uint4 *)(LAP(SuspRec *, susp) + qs);
                         qp[0] = p0;
                         qp[1] = p1;
                         qp[2] = make_uint4(p2.x, LANE_AMBIGUOUS, p2.y, p2.z);
@@ -832,19 +841,19 @@ walk_lanes_kernel(LanesArgs a) {
             // jobs are taken from a wavefront-local pool; the shared counter is touched once per PW_LANES_CHUNK jobs
             // (one atomic per refill made every wavefront queue on ONE address ~40 M times a second -- the counter's
             // L2 channel, not the walks, set the pace).  Near the end of the work the chunks shrink to what is needed.
-            if ((a.resume || win_pos == win_cnt) && pool_lo == pool_hi) {
+            if ((resuming || win_pos == win_cnt) && pool_lo == pool_hi) {
                 const uint64_t left = n_work > pool_hi ? n_work - pool_hi : 0;   // (as far as this wavefront knows)
-                const unsigned long long chunk = left > 4ull * grid_lanes ? (unsigned long long)a.job_chunk
-                                                                         : (unsigned long long)__popcll(need) * (a.resume ? 1ull : 2ull);
+                const unsigned long long chunk = left > 4ull * grid_lanes ? (unsigned long long)LA32(job_chunk)
+                                                                         : (unsigned long long)__popcll(need) * (resuming ? 1ull : 2ull);
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(a.job_counter, chunk);
+                if (lane == 0) base = atomicAdd(LAP(unsigned long long *, job_counter), chunk);
                 base = readfirst_u64(base);
                 pool_lo = base;
                 pool_hi = base + chunk < n_work ? base + chunk : n_work;
                 if (pool_lo >= n_work) { pool_lo = pool_hi = n_work; exhausted = true; continue; }
             }
             const uint32_t rank = (uint32_t)__popcll(need & lane_lt);
-            if (!a.resume) {
+            if (!resuming) {
                 // JOB WINDOW (round 5: compacted).  The next WIN_N jobs of the pool are fetched together -- job, start vertex, its
                 // row, stream position, first draw: three dependent scattered loads, once per batch instead of once per
                 // refill -- and the jobs whose start has no neighbours (52 % of an R-MAT job array) are FINISHED right
@@ -859,17 +868,18 @@ walk_lanes_kernel(LanesArgs a) {
                     uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
                     if ((uint32_t)lane < nb) {
                         const uint64_t widx = pool_lo + (uint64_t)lane;
-                        const uint32_t job = a.job_list ? a.job_list[widx] : (uint32_t)widx;
-                        const uint32_t start = a.starts[job];
-                        const uint4 vr = a.vrec[start];
+                        const uint32_t *jl_ = LAP(const uint32_t *, job_list);
+                        const uint32_t job = jl_ ? jl_[widx] : (uint32_t)widx;
+                        const uint32_t start = LAP(const uint32_t *, starts)[job];
+                        const uint4 vr = LAP(const uint4 *, vrec)[start];
                         uint32_t *row = a.out + (uint64_t)job * W;
                         row[0] = start;
                         if (vr.y == 0) {
                             row[L + 1] = 1;          // start without neighbours; cells 1..L stay 0
-                            if (a.job_list)          // a repaired row may hold an older walk
+                            if (jl_)          // a repaired row may hold an older walk
                                 for (uint32_t z = 1; z <= L; z++) row[z] = 0;
                         } else {
-                            const uint64_t so = a.stream_off[job] - a.rng_base;
+                            const uint64_t so = LAP(const uint64_t *, stream_off)[job] - LA64(rng_base);
                             double r0 = 0.0;
                             if (!PW_LANES_DRAW_LDS) r0 = a.rng[so];
                             w0 = make_uint4(job, start, vr.x, vr.y);
@@ -911,7 +921,7 @@ walk_lanes_kernel(LanesArgs a) {
             pool_lo += take;
             if (!(A.flags & F_ACTIVE) && !exhausted && rank < take) {
                 const uint64_t widx = pool_base + rank;
-                const uint4 *qp = (const uint4 *)(a.resume + widx);
+                const uint4 *qp = (const uint4 *)(LAP(const SuspRec *, resume) + widx);
                 const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
                 if (q0.x != NOT_FOUND) {                        // (void: a reserved slot no walk was parked in)
                     A.job = q0.x; A.j = q0.y; A.s0 = q0.z; A.d = q0.w;
@@ -1008,12 +1018,12 @@ walk_lanes_kernel(LanesArgs a) {
                         const uint64_t vm = ballot(rec);
                         if (vm) {
                             unsigned long long vb = 0;
-                            if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                            if (lane == 0) vb = atomicAdd(LAP(unsigned long long *, ver_count), (unsigned long long)__popcll(vm));
                             vb = readfirst_u64(vb);
                             const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
-                            if (rec && slot < a.ver_cap) {
-                                uint4 *vp = (uint4 *)(a.ver + slot);
-                                vp[0] = make_uint4(A.d, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
+                            if (rec && slot < LA64(ver_cap)) {
+                                uint4 *vp = (uint4 *)(LAP(VerRec *, ver) + slot);
+                                vp[0] = make_uint4(A.d, A.n_in, A.pp, (LA32(ver_poison) && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
                                 vp[1] = make_uint4(A.e, A.coff, A.d, A.job);
                                 vp[2] = make_uint4(__float_as_uint(tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                                    (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
@@ -1233,12 +1243,12 @@ walk_lanes_kernel(LanesArgs a) {
                 const uint64_t vm = ballot(rec);
                 if (vm) {
                     unsigned long long vb = 0;
-                    if (lane == 0) vb = atomicAdd(a.ver_count, (unsigned long long)__popcll(vm));
+                    if (lane == 0) vb = atomicAdd(LAP(unsigned long long *, ver_count), (unsigned long long)__popcll(vm));
                     vb = readfirst_u64(vb);
                     const uint64_t slot = vb + (uint64_t)__popcll(vm & lane_lt);
-                    if (rec && slot < a.ver_cap) {
-                        uint4 *vp = (uint4 *)(a.ver + slot);
-                        vp[0] = make_uint4(ls.kmax, A.n_in, A.pp, (a.ver_poison && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
+                    if (rec && slot < LA64(ver_cap)) {
+                        uint4 *vp = (uint4 *)(LAP(VerRec *, ver) + slot);
+                        vp[0] = make_uint4(ls.kmax, A.n_in, A.pp, (LA32(ver_poison) && (slot & 1023u) == 0u) ? choice ^ 1u : choice);
                         vp[1] = make_uint4(A.e, A.coff, A.d, A.job);
                         vp[2] = make_uint4(__float_as_uint(ls.tot), __float_as_uint(wo), (uint32_t)__double_as_longlong(r),
                                            (uint32_t)((unsigned long long)__double_as_longlong(r) >> 32));
@@ -1255,7 +1265,7 @@ walk_lanes_kernel(LanesArgs a) {
             if (pm) {
                 const uint64_t qs = queue_slot(pm);   // (queue slots come from a wavefront-local reservation too)
                 if (park) {
-                    uint4 *qp = (uint4 *)(a.susp + qs);
+                    uint4 *qp = (uint4 *)(LAP(SuspRec *, susp) + qs);
                     qp[0] = make_uint4(A.job, A.j, A.s0, A.d);
                     qp[1] = make_uint4(A.n_in, A.pp, A.e, A.coff);
                     qp[2] = make_uint4(ls.kmax, LANE_AMBIGUOUS, (uint32_t)A.soff, (uint32_t)(A.soff >> 32));
@@ -1339,8 +1349,8 @@ walk_lanes_kernel(LanesArgs a) {
 #undef PW_DRAW_STAGE
 #undef PW_DRAW_READ
 #undef PW_LINE_STAGE
-    if (a.susp)
-        for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) a.susp[v].job = NOT_FOUND;   // reserved, unused
+    if (LA64(susp))
+        for (uint64_t v = sp_lo + (uint64_t)lane; v < sp_hi; v += WAVE) LAP(SuspRec *, susp)[v].job = NOT_FOUND;   // reserved, unused
 #ifdef PW_PROF_LANES
     if (lane == 0) for (int i = 0; i < 16; i++) if (lp[i]) atomicAdd(&g_lprof[i], lp[i]);
 #endif
@@ -1351,13 +1361,16 @@ walk_lanes_kernel(LanesArgs a) {
         probes_w += (unsigned long long)__shfl_down((long long)probes_w, (unsigned)off, WAVE);
     }
     if (lane == 0) {
-        if (n_steps) atomicAdd(a.stats + 0, n_steps);
-        if (dead_w) atomicAdd(a.stats + 3, dead_w);
-        if (probes_w) atomicAdd(a.stats + 6, probes_w);
-        if (n_amb) atomicAdd(a.stats + 7, n_amb);
-        if (n_wave) atomicAdd(a.stats + 9, n_wave);
+        if (n_steps) atomicAdd(LAP(unsigned long long *, stats) + 0, n_steps);
+        if (dead_w) atomicAdd(LAP(unsigned long long *, stats) + 3, dead_w);
+        if (probes_w) atomicAdd(LAP(unsigned long long *, stats) + 6, probes_w);
+        if (n_amb) atomicAdd(LAP(unsigned long long *, stats) + 7, n_amb);
+        if (n_wave) atomicAdd(LAP(unsigned long long *, stats) + 9, n_wave);
     }
 }
+#undef LA64
+#undef LA32
+#undef LAP
 
 // ---- the float32 chains of a whole queue of parked walks, one lane each, every lane busy ------------------------------
 #ifndef PW_CHAIN_TAILS
