@@ -268,6 +268,7 @@ csr_validate_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restr
     if (v >= n_nodes) atomicMin(&flags[0], (unsigned long long)e);
     if (e > indptr[u] && indices[e - 1] >= v) atomicMin(&flags[1], (unsigned long long)e);
     if (data && data[e] != 1.0f) flags[2] = 1ull;
+    if (data && !(data[e] >= 0.0f && data[e] <= 3.0e38f)) flags[4] = 1ull;   // negative, NaN or infinite weight
     if (u == v) flags[3] = 1ull;
 }
 

@@ -824,7 +824,7 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     // ---- device side: validation, weight scan, membership index ------------------------------------------------
     uint32_t *d_edge_row = nullptr;
     unsigned long long *d_flags = nullptr;   // [0] first entry with index >= n_nodes  [1] first entry out of order
-                                             // [2] some weight != 1.0f  [3] self loop present
+                                             // [2] some weight != 1.0f  [3] self loop present  [4] some weight negative / NaN / inf
     auto bail = [&](int code, const std::string &msg) {
         if (d_edge_row) (void)hipFree(d_edge_row);
         if (d_flags) (void)hipFree(d_flags);
@@ -832,8 +832,8 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         return fail(code, msg);
     };
     hipError_t e = hipMalloc((void **)&d_edge_row, sizeof(uint32_t) * (size_t)(nnz ? nnz : 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 4 * sizeof(unsigned long long));
-    unsigned long long h_flags[4] = {~0ull, ~0ull, 0ull, 0ull};
+    if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 5 * sizeof(unsigned long long));
+    unsigned long long h_flags[5] = {~0ull, ~0ull, 0ull, 0ull, 0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, g->stream);
     g->index_build_ms = 0;
     INDEX_KERNELS_BEGIN(g);
@@ -864,6 +864,13 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     g->unit = !(data && h_flags[2]);
     if (g->unit && g->d_data) { (void)hipFree(g->d_data); g->d_data = nullptr; }   // unit weights are never read
     const bool has_loop = h_flags[3] != 0;
+    // A negative, NaN or infinite weight: the reference turns it into meaningless "probabilities" (w / w.sum(), cumsum, searchsorted:
+    // pecanpy.py:556-557) without complaint; the exact scans here (wave kernel: monotone partial sums; weighted lane form: a float64
+    // bound that takes the sign of a common neighbour's delta from q alone, seqscan.h: WeightedRow::margin) would NOT reproduce that
+    // garbage bit for bit, so such a graph is refused instead of walked differently (error behaviour)
+    if (data && h_flags[4] != 0)
+        return bail(PW_ERR_INVALID, "edge weights must be finite and >= 0 (a negative, NaN or infinite weight makes the reference's "
+                                    "transition probabilities w / w.sum() meaningless; this library does not reproduce them)");
 
     rc = up((void **)&g->d_foff, foff.data(), sizeof(uint32_t) * foff.size());
     if (!rc) rc = up((void **)&g->d_tab_off, off.data(), sizeof(uint64_t) * off.size());

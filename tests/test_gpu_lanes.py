@@ -479,6 +479,28 @@ def test_weighted_lane_form_equals_the_oracle_and_the_wave_kernel(extend, gamma,
     assert np.array_equal(small, want[:300])
 
 
+def test_negative_or_non_finite_weights_are_refused():
+    """A weight that is negative, NaN or infinite makes the reference's probabilities w / w.sum() meaningless (it walks on without
+    complaint: cumsum + searchsorted over whatever comes out).  The exact scans of this library assume weights >= 0 (ADVICE r05:
+    WeightedRow::margin takes the sign of a common neighbour's delta from q alone; the wave kernel's partial sums are monotone), so
+    pw_csr_create refuses such a graph loudly instead of walking it differently; zero weights are fine."""
+    from pecanpy_amd import _lib
+
+    indptr, indices, data = rmat_csr(10, seed=6, weighted=True)
+    for bad in (-0.25, float("nan"), float("inf")):
+        d = data.copy()
+        d[37] = bad
+        with pytest.raises(_lib.PwError, match="finite and >= 0"):
+            WalkEngine.from_csr(indptr, indices, d)
+    d = data.copy()
+    d[37] = 0.0
+    eng = WalkEngine.from_csr(indptr, indices, d)
+    starts = orc.shuffled_starts(indptr.size - 1, 2, 3)
+    with np.errstate(all="ignore"):
+        want = orc.walks_sparse_otf(indptr, indices, d, 0.5, 2.0, starts, 20, 5)
+    assert np.array_equal(eng.simulate("SparseOTF", 0.5, 2.0, False, starts, 20, seed=5), want)
+
+
 def test_weighted_lane_form_on_a_directed_graph_with_dead_ends(monkeypatch):
     """Weighted DIRECTED graphs through the weighted lane form: entries without a reverse edge (prev is not in cur's row),
     dead ends that shorten walks and shift the stream addresses (repair passes: job lists, wave kernel).  A graph with a
