@@ -40,8 +40,8 @@
 //   lane_chain : the float32 chain itself (1.2 % of the steps).  Queueing form: the walk is PARKED (SuspRec into a global
 //                queue), lanes_chain_kernel settles a whole queue at full width and the next ROUND of this kernel resumes the
 //                walks (host loop: pecanpy_amd.hip, launch_lane_walks); the last, small round runs them in place.  CHAINS form
-//                (round 5, small job arrays): the open steps stay in the pool and the wavefront runs their chains itself, 20
-//                at a time -- one launch, no rounds.
+//                (round 5, small job arrays; round 6: also the LATE rounds of a large one, PECANPY_AMD_LATE_CHAINS): the open steps
+//                stay in the pool and the wavefront runs their chains itself, 20 at a time -- one launch, no further rounds.
 // Other forms of the same kernel: FLOATS (unit weights, 1/p or 1/q not a power of two: a float64-bounded decision from
 // closed-form prefix sums and per-line row totals, chains for what it leaves open) and WEIGHTED (the same bound over per-(p, q)
 // tables; open steps decided by lanes_eager_weighted_kernel).

@@ -276,7 +276,7 @@ def test_parked_walks_and_chain_kernel_equal_in_place_chains_and_oracle(p, q, mo
 
 @pytest.mark.parametrize("p,q", [(0.5, 2), (0.25, 4)])
 def test_chains_form_equals_the_rounds_and_the_oracle(p, q, monkeypatch):
-    """Round 5, CHAINS form: job arrays of 1..32 jobs per resident lane run in ONE launch whose wavefronts run the float chains
+    """Round 5, CHAINS form: job arrays of 1..16 jobs per resident lane (rounds 5-6: 32) run in ONE launch whose wavefronts run the float chains
     themselves, from the pool (no parking, no chain kernel, no rounds).  Same walks as the queueing form with its rounds, as the
     plain in-place launch, and as the oracle on a prefix -- on an R-MAT graph large enough for the form to be picked by the
     engine's own rule, and on the hub graph forced into it (chains on long rows, overflow lists searched sector by sector)."""
