@@ -914,7 +914,10 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     (void)hipStreamSynchronize(g->stream);
     stamp("lane index");
     g->create_wall_ms = (now() - t_begin) * 1e3;
-    (void)hipFree(d_edge_row);
+    // a PARTIAL index keeps the source vertex of every CSR entry (4 bytes per entry): lanes_eager_kernel reads the vertex a
+    // parked step came from there instead of bisecting indptr for it (22 dependent loads per step)
+    if (g->d_lines && g->list_max_len != 0xffffffffu && !g->d_wedge_row) g->d_wedge_row = d_edge_row;
+    else (void)hipFree(d_edge_row);
     (void)hipFree(d_flags);
     *out = g;
     return PW_OK;
@@ -1538,10 +1541,11 @@ static int ensure_wlane_tables(pw_graph *g, const pw::WalkArgs &wa, bool extend,
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_dprev, sizeof(double) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wl_off, sizeof(unsigned long long) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wck_off, sizeof(unsigned long long) * (size_t)nnz);
-        if (e == hipSuccess) e = hipMalloc((void **)&g->d_wedge_row, sizeof(uint32_t) * (size_t)nnz);
+        const bool have_rows = g->d_wedge_row != nullptr;   // (a handle with a PARTIAL index kept them from its creation: pw_csr_create)
+        if (e == hipSuccess && !have_rows) e = hipMalloc((void **)&g->d_wedge_row, sizeof(uint32_t) * (size_t)nnz);
         if (e == hipSuccess) e = hipMalloc((void **)&g->d_wp1, sizeof(pw::PrefixPair) * (size_t)nnz);
         if (e != hipSuccess) return give_up();
-        hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_wedge_row);
+        if (!have_rows) hipLaunchKernelGGL(pw::csr_edge_rows_kernel, dim3(g->n_cu * 8), dim3(256), 0, g->stream, g->d_indptr, g->n_nodes, g->d_wedge_row);
         hipLaunchKernelGGL(pw::wprefix_kernel, dim3((unsigned)(((uint64_t)g->n_nodes * pw::WAVE + 255) / 256)), dim3(256), 0, g->stream, g->d_indptr,
                            (const float *)g->d_data, g->n_nodes, g->d_wp1);
     }
@@ -1986,7 +1990,8 @@ static int launch_lane_walks(pw_graph *g, pw::WalkArgs &wa, uint64_t *n_redo, bo
                 HIP_TRY(hipMemsetAsync(g->counters.p + 13, 0, sizeof(unsigned long long), g->stream));
                 const uint64_t want_e = (parked + pw::WAVES_PER_BLOCK - 1) / pw::WAVES_PER_BLOCK;
                 hipLaunchKernelGGL(pw::lanes_eager_kernel, dim3((unsigned)std::min<uint64_t>(want_e, (uint64_t)g->n_cu * 8)),
-                                   dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa, g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12);
+                                   dim3(pw::WAVES_PER_BLOCK * pw::WAVE), 0, g->stream, wa, g->susp[round & 1].p, (uint64_t)parked, g->counters.p + 12,
+                                   (const uint32_t *)g->d_wedge_row);
                 HIP_TRY(hipGetLastError());
             }
         }

@@ -1481,7 +1481,7 @@ unit_tot_kernel(const ELine *__restrict__ lines, const uint8_t *__restrict__ cli
 // step_edge = none), the float32 chain decides, and the record's `choice` is what the next lane round applies.
 // n, q: kernel arguments behind WalkArgs (read from the kernarg segment like walk_kernel's)
 __global__ void __launch_bounds__(WAVES_PER_BLOCK *WAVE, PW_MIN_WAVES)
-lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused) {
+lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsigned long long *stats_unused, const uint32_t *edge_row_unused) {
     // (persistent: the wavefronts of a fixed grid stride over the records -- one workgroup per record is bound by the dispatch
     //  rate, see lanes_eager_weighted_kernel)
     __shared__ uint32_t s_mask_all[WAVES_PER_BLOCK][MASK_WORDS];
@@ -1504,6 +1504,7 @@ lanes_eager_kernel(WalkArgs a_unused, SuspRec *q_unused, uint64_t n_unused, unsi
     const uint32_t cur = uni(lines[e].nxt);
     uint32_t prev;
     if (e >= la.g.nnz) prev = e - la.g.nnz;                     // an overflow line: the walk came from vertex e - nnz
+    else if (kernarg<uint64_t>(XARG + 24) != 0ull) prev = uni(as_scalar<uint32_t>(kernarg<uint64_t>(XARG + 24))[e]);   // (kept by a partial index)
     else {                                                      // the row that holds CSR entry e
         uint32_t lo = 0, hi = la.g.n_nodes;                     // last v with indptr[v] <= e
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (uni(la.g.indptr[mid]) <= e) lo = mid; else hi = mid; }
