@@ -300,7 +300,7 @@ def main():
     chunk_of = [tapered_bounds(b[1] - b[0], n_chunks) for b in all_bounds]
 
     acc = {k: [] for k in ("walk_kernel_ms", "lane_kernel_ms", "rng_kernel_ms", "total_steps", "list_entries_read",
-                           "ambiguous_steps", "wave_chain_steps", "redo_walks", "overflow_reads")}
+                           "ambiguous_steps", "wave_chain_steps", "redo_walks", "overflow_reads", "verify_checked", "verify_mismatch")}
     param_index_ms = [0.0]   # (p, q)-dependent index built by the first call (normaliser table of weighted graphs)
 
     pass_no = [0]
@@ -508,6 +508,10 @@ def main():
         roofline["list_entries_per_step"] = round(acc["list_entries_read"][-1] / max(steps0, 1), 2)
         roofline["redo_walks"] = int(acc["redo_walks"][-1])
         roofline["lane_rounds"] = int(st["lane_rounds"])
+        # the safety net under the argued bounds of the interval decision: 1/1024 of the steps it settles are
+        # re-decided by the float chain inside every call -- summed over the timed passes
+        roofline["verify_sampled_decisions"] = int(sum(acc["verify_checked"][-args.steps:]))
+        roofline["verify_mismatches"] = int(sum(acc["verify_mismatch"][-args.steps:]))
         roofline["launch_note"] = ("one pass = lane_rounds launches of walk_lanes_kernel (walks whose step needs the float32 chain "
                                    "are parked and resumed by the next round) + one lanes_chain_kernel launch per queue; "
                                    "avg_launch_ms and declared_bytes_per_launch are per PASS (sum over these launches)")
