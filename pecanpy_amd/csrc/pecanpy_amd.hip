@@ -765,22 +765,43 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
     int rc = graph_common_init(g, device);
     if (rc) { pw_graph_destroy(g); return rc; }
     stamp("runtime / streams / events");
-    // the edge lines of the lane index (64 bytes per CSR entry + one per vertex: 4.4 GB at RMAT-22) are allocated by a helper
-    // thread from here on, beside the host pass, the copy of the CSR and the validation / membership kernels: on a box whose
-    // device memory has not been handed out before, that hipMalloc alone costs ~120 ms (EXPERIMENTS.md, rounds 5-6)
-    struct LinesPre {
-        std::thread t; void *p = nullptr; uint64_t bytes = 0; bool taken = false;
-        ~LinesPre() { if (t.joinable()) t.join(); if (p && !taken) (void)hipFree(p); }
-    } lines_pre;
+    // Two helper threads, from here on beside the host pass below: (1) the CSR arrays go to the device (261 MB of column indices
+    // at RMAT-22 from pageable memory: ~25 ms); (2) the edge lines of the lane index (64 bytes per CSR entry + one per vertex:
+    // 4.4 GB at RMAT-22) are allocated -- on a box whose device memory has not been handed out before, that hipMalloc alone
+    // costs ~120 ms (EXPERIMENTS.md, rounds 5-6); it runs beside the validation / membership kernels too.
+    struct Pre {
+        std::thread t_up, t_lines;
+        void *indptr = nullptr, *indices = nullptr, *data = nullptr;   // (1): handed to g once t_up is joined
+        hipError_t err = hipSuccess;
+        void *lines = nullptr; uint64_t line_bytes = 0; bool lines_taken = false, csr_taken = false;   // (2)
+        ~Pre() {
+            if (t_up.joinable()) t_up.join();
+            if (t_lines.joinable()) t_lines.join();
+            if (lines && !lines_taken) (void)hipFree(lines);
+            if (!csr_taken) for (void *q : {indptr, indices, data}) if (q) (void)hipFree(q);
+        }
+    } pre;
+    auto up_work = [&pre, device, indptr, indices, data, n_nodes, nnz]() {
+        if ((pre.err = hipSetDevice(device)) != hipSuccess) return;
+        auto up1 = [&](void **dst, const void *src, size_t bytes) {
+            if (pre.err != hipSuccess) return;
+            pre.err = hipMalloc(dst, bytes ? bytes : 4);
+            if (pre.err == hipSuccess && bytes) pre.err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        };
+        up1(&pre.indptr, indptr, sizeof(uint32_t) * ((size_t)n_nodes + 1));
+        up1(&pre.indices, indices, sizeof(uint32_t) * (size_t)nnz);
+        if (data) up1(&pre.data, data, sizeof(float) * (size_t)nnz);
+    };
+    try { pre.t_up = std::thread(up_work); } catch (const std::system_error &) { up_work(); }   // (thread limit: on this thread)
     if (nnz && !getenv("PECANPY_AMD_NO_LAZY") && !getenv("PECANPY_AMD_NO_PREALLOC")) {
         const bool vl = (uint64_t)nnz + n_nodes < 0xffffffffull && !getenv("PECANPY_AMD_NO_VLINES");
-        lines_pre.bytes = (uint64_t)(vl ? nnz + n_nodes : nnz) * sizeof(pw::ELine) + 64;
+        pre.line_bytes = (uint64_t)(vl ? nnz + n_nodes : nnz) * sizeof(pw::ELine) + 64;
         try {
-            lines_pre.t = std::thread([&lines_pre, device]() {
+            pre.t_lines = std::thread([&pre, device]() {
                 size_t free_b = 0, total_b = 0;
                 if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-                if (lines_pre.bytes > free_b / 2) return;               // (build_lane_index's rule: no lane index then)
-                if (hipMalloc(&lines_pre.p, lines_pre.bytes) != hipSuccess) { lines_pre.p = nullptr; (void)hipGetLastError(); }
+                if (pre.line_bytes > free_b / 2) return;               // (build_lane_index's rule: no lane index then)
+                if (hipMalloc(&pre.lines, pre.line_bytes) != hipSuccess) { pre.lines = nullptr; (void)hipGetLastError(); }
             });
         } catch (const std::system_error &) {}   // (thread limit: build_lane_index allocates)
     }
@@ -815,10 +836,11 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     };
-    rc = up((void **)&g->d_indptr, indptr, sizeof(uint32_t) * ((size_t)n_nodes + 1));
-    if (!rc) rc = up((void **)&g->d_indices, indices, sizeof(uint32_t) * (size_t)nnz);
-    if (!rc && data) rc = up(&g->d_data, data, sizeof(float) * (size_t)nnz);
-    if (rc) { pw_graph_destroy(g); return rc; }
+    // the CSR arrays, uploaded by the helper thread meanwhile (the lines' allocation may still be running: joined further down)
+    if (pre.t_up.joinable()) pre.t_up.join();
+    if (pre.err != hipSuccess) { pw_graph_destroy(g); return fail(pre.err == hipErrorOutOfMemory ? PW_ERR_NOMEM : PW_ERR_HIP, std::string("CSR upload: ") + hipGetErrorString(pre.err)); }
+    g->d_indptr = (uint32_t *)pre.indptr; g->d_indices = (uint32_t *)pre.indices; g->d_data = pre.data;
+    pre.csr_taken = true;
     stamp("host pass + H2D of the CSR");
 
     // ---- device side: validation, weight scan, membership index ------------------------------------------------
@@ -906,9 +928,9 @@ PW_EXPORT int pw_csr_create(const uint32_t *indptr, const uint32_t *indices, con
         // node2vec+ tables pair the two directions' lists entry by entry, and the fix makes their lengths differ).
         g->lanes_off = getenv("PECANPY_AMD_NO_LANES") != nullptr;
         item_thread.join();
-        if (lines_pre.t.joinable()) lines_pre.t.join();
-        lines_pre.taken = lines_pre.p != nullptr;
-        rc = build_lane_index(g, items, d_edge_row, has_loop, lines_pre.p, lines_pre.bytes);
+        if (pre.t_lines.joinable()) pre.t_lines.join();
+        pre.lines_taken = pre.lines != nullptr;
+        rc = build_lane_index(g, items, d_edge_row, has_loop, pre.lines, pre.line_bytes);
         if (rc) { (void)hipFree(d_edge_row); (void)hipFree(d_flags); pw_graph_destroy(g); return rc; }
     }
     (void)hipStreamSynchronize(g->stream);
