@@ -2400,7 +2400,8 @@ static int expand_stream(pw_graph *g, uint32_t seed, bool cacheable, uint64_t st
     }
     // (measured and not kept, round 6: the block in two LDS copies -- three barriers per block instead of six -- with 64 / 128 /
     //  256 lanes per generator: 8.4 / 6.9 / 6.06 ms of jump + expansion per RMAT-22 pass against 6.08-6.16: the expansion is bound
-    //  by its 12.9 GB of stores at ~3 TB/s, not by the barriers)
+    //  neither by its barriers nor by its stores (3 TB/s; a plain fill of the 12.9 GB: 4.8 TB/s) but by the per-generator chain of LDS
+    //  round trips at eight workgroups per CU)
     hipLaunchKernelGGL(pw::mt_expand_kernel, dim3(n_gen), dim3(256), 0, g->stream, mt_states,
                        (uint32_t *)nullptr, g->rng.p, per_gen, n_blocks);
     HIP_TRY(hipGetLastError());
